@@ -1,0 +1,123 @@
+"""Oracle: MLP / Gaussian / categorical heads as plain functions of a param dict.
+
+TEST INFRASTRUCTURE (see ``oracle/__init__.py``).  Restates
+  * ``torch/modules/multi_headed_mlp_module.py:136-151`` + ``mlp_module.py:62-73``
+    (Linear -> tanh stack, linear output head)
+  * ``torch/modules/gaussian_mlp_module.py:158-192,288-305`` (scalar log-std
+    broadcast, lower clamp at log(min_std), exp parameterisation,
+    ``Independent(Normal(mean, std), 1)``)
+  * ``torch/policies/gaussian_mlp_policy.py:89-102`` (agent_info mean/log_std)
+  * ``torch/value_functions/gaussian_mlp_value_function.py:81-112`` (value =
+    distribution mean, loss = Gaussian NLL with a learned scalar log-std)
+  * ``torch/policies/categorical_cnn_policy.py:138-139`` for the categorical
+    head convention (softmax output passed as ``logits=``).
+
+Parameters live in an ordered ``dict[str, torch.Tensor]`` that uses the
+reference's ``state_dict`` key names, so a golden ``state_dict`` captured from
+the real classes drops straight in.
+"""
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+from torch.distributions import Categorical, Independent, Normal
+
+POLICY_PREFIX = '_module.'
+VALUE_PREFIX = 'module.'
+
+
+def xavier_uniform(rng, fan_out, fan_in):
+    """``nn.init.xavier_uniform_`` bound, drawn from a numpy RandomState."""
+    bound = math.sqrt(6.0 / (fan_in + fan_out))
+    return rng.uniform(-bound, bound, size=(fan_out, fan_in)).astype(np.float32)
+
+
+def init_gaussian_mlp(rng, prefix, in_dim, out_dim, hidden_sizes,
+                      init_std=1.0, min_std=None):
+    """Param dict shaped like ``GaussianMLPModule.state_dict()``.
+
+    xavier-uniform weights and zero biases are the reference defaults
+    (``gaussian_mlp_policy.py:55-60``); values come from ``rng`` so product and
+    oracle can be given identical parameters.
+    """
+    p = OrderedDict()
+    p[prefix + '_init_std'] = torch.tensor([math.log(init_std)],
+                                           dtype=torch.float32)
+    if min_std is not None:
+        p[prefix + 'min_std_param'] = torch.tensor([min_std]).log()
+    prev = in_dim
+    for i, h in enumerate(hidden_sizes):
+        base = '{}_mean_module._layers.{}.linear.'.format(prefix, i)
+        p[base + 'weight'] = torch.from_numpy(xavier_uniform(rng, h, prev))
+        p[base + 'bias'] = torch.zeros(h)
+        prev = h
+    base = prefix + '_mean_module._output_layers.0.linear.'
+    p[base + 'weight'] = torch.from_numpy(xavier_uniform(rng, out_dim, prev))
+    p[base + 'bias'] = torch.zeros(out_dim)
+    return p
+
+
+def trainable_keys(params):
+    """Everything but the registered buffer (``min_std_param``)."""
+    return [k for k in params if not k.endswith('min_std_param')]
+
+
+def n_hidden(params, prefix):
+    i = 0
+    while '{}_mean_module._layers.{}.linear.weight'.format(prefix, i) in params:
+        i += 1
+    return i
+
+
+def mlp_mean(params, prefix, x):
+    """tanh MLP trunk + linear head."""
+    for i in range(n_hidden(params, prefix)):
+        base = '{}_mean_module._layers.{}.linear.'.format(prefix, i)
+        x = torch.tanh(
+            torch.nn.functional.linear(x, params[base + 'weight'],
+                                       params[base + 'bias']))
+    base = prefix + '_mean_module._output_layers.0.linear.'
+    return torch.nn.functional.linear(x, params[base + 'weight'],
+                                      params[base + 'bias'])
+
+
+def gaussian_dist(params, prefix, x):
+    """``GaussianMLPBaseModule.forward`` (``gaussian_mlp_module.py:158-192``)."""
+    mean = mlp_mean(params, prefix, x)
+    log_std = torch.zeros(*mean.shape) + params[prefix + '_init_std']
+    key = prefix + 'min_std_param'
+    if key in params:
+        log_std = log_std.clamp(min=params[key].item())
+    return Independent(Normal(mean, log_std.exp()), 1)
+
+
+def policy_forward(params, obs):
+    """(dist, agent_info) of ``GaussianMLPPolicy.forward``."""
+    dist = gaussian_dist(params, POLICY_PREFIX, obs)
+    return dist, dict(mean=dist.mean, log_std=(dist.variance**.5).log())
+
+
+def value_forward(params, obs):
+    """``GaussianMLPValueFunction.forward``: ``(..., O) -> (...)``."""
+    return gaussian_dist(params, VALUE_PREFIX, obs).mean.flatten(-2)
+
+
+def value_loss(params, obs, returns):
+    """``GaussianMLPValueFunction.compute_loss``: ``-mean log N(G | v, s^2)``."""
+    dist = gaussian_dist(params, VALUE_PREFIX, obs)
+    return -dist.log_prob(returns.reshape(-1, 1)).mean()
+
+
+def categorical_dist(params, prefix, x, double_softmax=True):
+    """Categorical head for the discrete configs (no torch MLP precedent).
+
+    The only torch categorical policies in the reference feed
+    ``softmax(net(x))`` to ``Categorical(logits=...)``
+    (``categorical_cnn_policy.py:138-139``); ``double_softmax=True`` keeps that
+    convention, ``False`` treats the MLP output as logits.
+    """
+    out = mlp_mean(params, prefix, x)
+    if double_softmax:
+        out = torch.softmax(out, dim=-1)
+    return Categorical(logits=out)

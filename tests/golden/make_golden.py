@@ -1,0 +1,509 @@
+"""Generate the committed golden vectors by running the REAL reference.
+
+Run in the build container only (needs ``/root/reference``)::
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Outputs ``tests/golden/*.npz`` (inputs + expected outputs, a few hundred KB).
+The reference itself never travels; these arrays do.  Items follow SURVEY.md
+Appendix C.  See ``_ref_harness.py`` for how the reference is imported.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+import _ref_harness as ref  # noqa: E402
+
+ref.install()
+
+import akro  # noqa: E402  (the in-memory stub)
+import garage  # noqa: E402
+from garage import EnvSpec, EpisodeBatch, StepType  # noqa: E402
+from garage import Environment, EnvStep  # noqa: E402
+from garage.np import discount_cumsum, pad_batch_array  # noqa: E402
+from garage.sampler import (DefaultWorker, FragmentWorker,  # noqa: E402
+                            LocalSampler, VecWorker, WorkerFactory)
+from garage.torch import compute_advantages  # noqa: E402
+from garage.torch.algos import PPO, VPG  # noqa: E402
+import garage.torch.algos.vpg as vpg_mod  # noqa: E402
+import garage._functions as gfun  # noqa: E402
+from garage.torch.optimizers import OptimizerWrapper  # noqa: E402
+from garage.torch.policies import GaussianMLPPolicy  # noqa: E402
+from garage.torch.value_functions import \
+    GaussianMLPValueFunction  # noqa: E402
+
+from oracle import envs as oenvs  # noqa: E402  (env *definitions* only)
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **arrays)
+    print('wrote', path, sum(np.asarray(a).nbytes for a in arrays.values()),
+          'bytes')
+
+
+# ---------------------------------------------------------------------------
+# Reference-side environment wrappers around the oracle's env definitions.
+class RefEnv(Environment):
+    """A real ``garage.Environment`` that delegates dynamics to ``inner``."""
+
+    def __init__(self, inner, obs_dim, act_dim, max_episode_length,
+                 discrete=False):
+        self._inner = inner
+        self._obs_space = akro.Box(-np.inf, np.inf, (obs_dim, ))
+        self._act_space = (akro.Discrete(act_dim) if discrete else akro.Box(
+            -np.inf, np.inf, (act_dim, )))
+        self._spec = EnvSpec(self._obs_space, self._act_space,
+                             max_episode_length=max_episode_length)
+
+    @property
+    def action_space(self):
+        return self._act_space
+
+    @property
+    def observation_space(self):
+        return self._obs_space
+
+    @property
+    def spec(self):
+        return self._spec
+
+    @property
+    def render_modes(self):
+        return []
+
+    def reset(self):
+        return self._inner.reset()
+
+    def step(self, action):
+        s = self._inner.step(action)
+        return EnvStep(env_spec=self._spec, action=s.action, reward=s.reward,
+                       observation=s.observation, env_info=s.env_info,
+                       step_type=StepType(int(s.step_type)))
+
+    def render(self, mode):
+        pass
+
+    def visualize(self):
+        pass
+
+    def close(self):
+        pass
+
+
+class ScriptedVecPolicy:
+    """Deterministic agent: action = [sum(obs), t_call] (no RNG)."""
+
+    def __init__(self, act_dim):
+        self.act_dim = act_dim
+        self.calls = 0
+        self.name = 'scripted'
+
+    def reset(self, do_resets=None):
+        pass
+
+    def get_actions(self, observations):
+        obs = np.asarray(observations, dtype=np.float32)
+        a = np.zeros((obs.shape[0], self.act_dim), dtype=np.float32)
+        a[:, 0] = obs.sum(axis=1)
+        a[:, -1] = self.calls
+        self.calls += 1
+        return a, {'tag': a[:, 0] * 2}
+
+    def get_action(self, observation):
+        a, info = self.get_actions(np.asarray(observation)[None])
+        return a[0], {k: v[0] for k, v in info.items()}
+
+    def get_param_values(self):
+        return None
+
+    def set_param_values(self, _):
+        pass
+
+
+def batch_arrays(prefix, eps):
+    out = {
+        prefix + 'observations': eps.observations,
+        prefix + 'last_observations': eps.last_observations,
+        prefix + 'actions': eps.actions,
+        prefix + 'rewards': eps.rewards,
+        prefix + 'step_types': np.asarray([int(s) for s in eps.step_types]),
+        prefix + 'lengths': eps.lengths,
+        prefix + 'lengths_dtype': np.asarray(str(eps.lengths.dtype)),
+        prefix + 'rewards_dtype': np.asarray(str(eps.rewards.dtype)),
+    }
+    for k, v in eps.agent_infos.items():
+        out[prefix + 'agent_' + k] = v
+    return out
+
+
+# ---------------------------------------------------------------------------
+def gen_returns():
+    rng = np.random.RandomState(1)
+    out = {}
+    # (1) the literal vector of tests/garage/test_functions.py:49-97
+    rew = np.array([
+        0.34026529, 0.58263177, 0.84307509, 0.97651095, 0.81723901,
+        0.22631398, 0.03421301, 0.97515046, 0.64311832, 0.65068933,
+        0.17657714, 0.04783857, 0.73904013, 0.41364329, 0.52235551,
+        0.24203526, 0.43328910
+    ])
+    lengths = np.array([10, 5, 1, 1])
+    out['lp_rewards'], out['lp_lengths'] = rew, lengths
+    start = 0
+    firsts = []
+    for L in lengths:
+        firsts.append(discount_cumsum(rew[start:start + L], 0.8)[0])
+        start += L
+    out['lp_first_returns'] = np.asarray(firsts)
+    for i, g in enumerate((0.8, 0.99, 1.0)):
+        x64 = rng.randn(5, 33)
+        x32 = x64.astype(np.float32)
+        out['dc_x64_%d' % i] = x64
+        out['dc_y64_%d' % i] = np.stack(
+            [discount_cumsum(r, g) for r in x64])
+        out['dc_x32_%d' % i] = x32
+        out['dc_y32_%d' % i] = np.stack(
+            [discount_cumsum(r, g) for r in x32])
+        out['dc_g_%d' % i] = np.asarray(g)
+    save('returns', **out)
+
+
+def gen_advantages():
+    out = {}
+    ONES, ZEROS = np.ones(6), np.zeros(6)
+    ARR, PI, FIBS = np.arange(6), np.array([3, 1, 4, 1, 5, 9]), np.array(
+        [1, 1, 2, 3, 5, 8])
+    idx = 0
+    for discount in (1, 0.95):
+        for num_eps in (1, 5):
+            for lam in (0, 0.5, 1):
+                for r, b in ((ONES, ZEROS), (PI, ARR), (ONES, FIBS)):
+                    rewards = torch.Tensor(np.repeat(r[None], num_eps, 0))
+                    base = torch.Tensor(np.repeat(b[None], num_eps, 0))
+                    adv = compute_advantages(discount, lam, 6, base, rewards)
+                    out['t%d_in' % idx] = np.stack(
+                        [rewards.numpy(), base.numpy()])
+                    out['t%d_cfg' % idx] = np.asarray([discount, lam, 6.0])
+                    out['t%d_adv' % idx] = adv.numpy()
+                    idx += 1
+    out['n_test_cases'] = np.asarray(idx)
+    # ragged cases, non-zero V(0) in the padding (Q2)
+    rng = np.random.RandomState(2)
+    k = 0
+    for P in (1, 2, 8, 32):
+        for discount, lam in ((0.99, 0.97), (1.0, 1.0), (0.9, 0.0)):
+            lens = sorted({1, max(1, P // 2), max(1, P - 1), P})
+            lens = np.asarray(lens + [P])
+            N = len(lens)
+            v0 = np.float32(rng.randn())
+            rewards = np.zeros((N, P), np.float32)
+            base = np.full((N, P), v0, np.float32)
+            for i, L in enumerate(lens):
+                rewards[i, :L] = rng.randn(L)
+                base[i, :L] = rng.randn(L)
+            adv = compute_advantages(discount, lam, P, torch.Tensor(base),
+                                     torch.Tensor(rewards))
+            out['r%d_rewards' % k], out['r%d_base' % k] = rewards, base
+            out['r%d_lens' % k] = lens
+            out['r%d_cfg' % k] = np.asarray([discount, lam, P, v0])
+            out['r%d_adv' % k] = adv.numpy()
+            k += 1
+    out['n_ragged_cases'] = np.asarray(k)
+    save('advantages', **out)
+
+
+def gen_padding_and_steptypes():
+    out = {}
+    lens = np.array([10, 20, 7, 25, 25, 40, 10, 5])
+    rng = np.random.RandomState(3)
+    obs = rng.randn(lens.sum(), 3).astype(np.float32)
+    rew = rng.randn(lens.sum())
+    out['lens'], out['obs'], out['rew'] = lens, obs, rew
+    out['padded_obs'] = pad_batch_array(obs, lens, 100)
+    out['padded_rew'] = pad_batch_array(rew, lens, 100)
+    out['padded_obs_default'] = pad_batch_array(obs, lens)
+    table = []
+    for step_cnt in (1, 2, 5, 9, 10, 11):
+        for max_len in (None, 10):
+            for done in (False, True):
+                table.append([
+                    step_cnt, -1 if max_len is None else max_len, int(done),
+                    int(StepType.get_step_type(step_cnt, max_len, done))
+                ])
+    out['steptype_table'] = np.asarray(table)
+    save('padding_steptypes', **out)
+
+
+def gen_sampler():
+    out = {}
+    P = 6
+    n = 4
+    cyc = [[3, 6, 2], [4, 4, 4], [6, 1, 5], [2, 2, 6]]
+
+    def envs():
+        return [
+            RefEnv(oenvs.CountingEnv(i, cyc[i], P), 3, 2, P) for i in range(n)
+        ]
+
+    # VecWorker (real): bookkeeping oracle
+    pol = ScriptedVecPolicy(2)
+    wf = WorkerFactory(seed=1, n_workers=1, worker_class=VecWorker,
+                       worker_args=dict(n_envs=n), max_episode_length=P)
+    sampler = LocalSampler.from_worker_factory(wf, pol, [envs()])
+    eps = sampler.obtain_samples(0, 30, None)
+    out.update(batch_arrays('vec_', eps))
+    eps2 = sampler.obtain_samples(1, 17, None)  # second call: Q12 reset
+    out.update(batch_arrays('vec2_', eps2))
+    out['vec_total_env_steps'] = np.asarray(sampler.total_env_steps)
+
+    # DefaultWorker (real): observation oracle, one worker per env
+    pol = ScriptedVecPolicy(2)
+    wf = WorkerFactory(seed=1, n_workers=n, worker_class=DefaultWorker,
+                       max_episode_length=P)
+    sampler = LocalSampler.from_worker_factory(wf, pol, envs())
+    eps = sampler.obtain_exact_episodes(3, None)
+    out.update(batch_arrays('def_', eps))
+
+    # FragmentWorker (real)
+    for tpc in (1, 2):
+        pol = ScriptedVecPolicy(2)
+        wf = WorkerFactory(seed=1, n_workers=1, worker_class=FragmentWorker,
+                           worker_args=dict(n_envs=n, timesteps_per_call=tpc),
+                           max_episode_length=P)
+        sampler = LocalSampler.from_worker_factory(wf, pol, [envs()])
+        eps = sampler.obtain_samples(0, 20, None)
+        out.update(batch_arrays('frag%d_' % tpc, eps))
+    out['cfg'] = np.asarray([P, n])
+    out['cycles'] = np.asarray(cyc)
+    save('sampler', **out)
+
+
+def state_arrays(prefix, module):
+    return {
+        prefix + k: v.detach().numpy().copy()
+        for k, v in module.state_dict().items()
+    }
+
+
+def gen_networks():
+    out = {}
+    torch.manual_seed(5)
+    rng = np.random.RandomState(5)
+    for tag, O, A, hs in (('tiny', 4, 2, (8, 8)), ('c2', 4, 2, (64, 64)),
+                          ('c3', 17, 6, (256, 256)),
+                          ('deep', 11, 3, (16, 12, 8))):
+        spec = EnvSpec(akro.Box(-1, 1, (O, )), akro.Box(-1, 1, (A, )),
+                       max_episode_length=8)
+        pol = GaussianMLPPolicy(spec, hidden_sizes=hs)
+        vf = GaussianMLPValueFunction(spec, hidden_sizes=hs)
+        with torch.no_grad():  # move off the zero-bias / unit-std init
+            for p in list(pol.parameters()) + list(vf.parameters()):
+                p.add_(torch.randn_like(p) * 0.1)
+        obs = torch.Tensor(rng.randn(37, O))
+        act = torch.Tensor(rng.randn(37, A))
+        ret = torch.Tensor(rng.randn(37))
+        with torch.no_grad():
+            dist, info = pol(obs)
+            out[tag + '_mean'] = info['mean'].numpy()
+            out[tag + '_log_std'] = info['log_std'].numpy()
+            out[tag + '_log_prob'] = dist.log_prob(act).numpy()
+            out[tag + '_entropy'] = dist.entropy().numpy()
+            out[tag + '_value'] = vf(obs).numpy()
+            out[tag + '_vf_loss'] = vf.compute_loss(obs, ret).numpy()
+        out[tag + '_obs'], out[tag + '_act'], out[tag + '_ret'] = (
+            obs.numpy(), act.numpy(), ret.numpy())
+        out.update(state_arrays(tag + '_pol:', pol))
+        out.update(state_arrays(tag + '_vf:', vf))
+        out[tag + '_hidden'] = np.asarray(hs)
+    save('networks', **out)
+
+
+def make_ragged_batch(rng, spec, lens, O, A):
+    S = int(np.sum(lens))
+    st = []
+    for L in lens:
+        t = [StepType.MID] * L
+        t[0] = StepType.FIRST
+        t[-1] = (StepType.TIMEOUT
+                 if L == spec.max_episode_length else StepType.TERMINAL)
+        st += t
+    return EpisodeBatch(
+        env_spec=spec, episode_infos={},
+        observations=rng.randn(S, O).astype(np.float32),
+        last_observations=rng.randn(len(lens), O).astype(np.float32),
+        actions=rng.randn(S, A).astype(np.float32),
+        rewards=rng.randn(S),
+        env_infos={}, agent_infos={},
+        step_types=np.asarray(st, dtype=StepType),
+        lengths=np.asarray(lens, dtype='l'))
+
+
+def gen_train_once():
+    """Item 8: full ``_train_once`` iterations through the real PPO / VPG."""
+    cases = [
+        dict(tag='ppo', algo='ppo', kw={}),
+        dict(tag='ppo_pos', algo='ppo', kw=dict(positive_adv=True)),
+        dict(tag='ppo_reg', algo='ppo',
+             kw=dict(entropy_method='regularized', policy_ent_coeff=0.02)),
+        dict(tag='ppo_max', algo='ppo',
+             kw=dict(entropy_method='max', policy_ent_coeff=0.05,
+                     center_adv=False, stop_entropy_gradient=True,
+                     use_softplus_entropy=True)),
+        dict(tag='vpg', algo='vpg', kw={}),
+        dict(tag='ppo_full', algo='ppo', kw={}, mb=None),
+    ]
+    out = {}
+    for case in cases:
+        tag = case['tag']
+        O, A, P, hs = 4, 2, 8, (8, 8)
+        E, mb = 2, case.get('mb', 5)
+        spec = EnvSpec(akro.Box(-np.inf, np.inf, (O, )),
+                       akro.Box(-np.inf, np.inf, (A, )),
+                       max_episode_length=P)
+        torch.manual_seed(11)
+        rng = np.random.RandomState(11)
+        pol = GaussianMLPPolicy(spec, hidden_sizes=hs)
+        vf = GaussianMLPValueFunction(spec, hidden_sizes=hs)
+        with torch.no_grad():
+            for p in list(pol.parameters()) + list(vf.parameters()):
+                p.add_(torch.randn_like(p) * 0.1)
+        out.update(state_arrays(tag + '_pol0:', pol))
+        out.update(state_arrays(tag + '_vf0:', vf))
+        cls = PPO if case['algo'] == 'ppo' else VPG
+        algo = cls(env_spec=spec, policy=pol, value_function=vf, sampler=None,
+                   policy_optimizer=OptimizerWrapper(
+                       (torch.optim.Adam, dict(lr=2.5e-4)), pol,
+                       max_optimization_epochs=E, minibatch_size=mb),
+                   vf_optimizer=OptimizerWrapper(
+                       (torch.optim.Adam, dict(lr=2.5e-4)), vf,
+                       max_optimization_epochs=E, minibatch_size=mb),
+                   **case['kw'])
+        rec = ref.TabularRecorder()
+        vpg_mod.tabular = rec
+        gfun.tabular = rec
+        for it in range(2):  # two iterations: Adam state + old-policy sync
+            lens = [8, 3, 5, 8, 1, 6] if it == 0 else [2, 8, 7, 4]
+            eps = make_ragged_batch(rng, spec, lens, O, A)
+            np.random.seed(100 + it)
+            avg_ret = algo._train_once(it, eps)
+            pre = '%s_it%d_' % (tag, it)
+            out[pre + 'observations'] = eps.observations
+            out[pre + 'actions'] = eps.actions
+            out[pre + 'rewards'] = eps.rewards
+            out[pre + 'lengths'] = eps.lengths
+            out[pre + 'step_types'] = np.asarray(
+                [int(s) for s in eps.step_types])
+            out[pre + 'np_seed'] = np.asarray(100 + it)
+            out[pre + 'avg_return'] = np.asarray(avg_ret)
+            for k, v in rec.values.items():
+                out[pre + 'log:' + k] = np.asarray(v)
+            out.update(state_arrays(pre + 'pol:', pol))
+            out.update(state_arrays(pre + 'vf:', vf))
+            for name, opt in (('pol', algo._policy_optimizer._optimizer),
+                              ('vf', algo._vf_optimizer._optimizer)):
+                for j, p in enumerate(opt.param_groups[0]['params']):
+                    st = opt.state[p]
+                    out['%sadam_%s_%d_m' % (pre, name, j)] = \
+                        st['exp_avg'].numpy().copy()
+                    out['%sadam_%s_%d_v' % (pre, name, j)] = \
+                        st['exp_avg_sq'].numpy().copy()
+                    out['%sadam_%s_%d_step' % (pre, name, j)] = \
+                        np.asarray(float(st['step']))
+        out[tag + '_cfg'] = np.asarray([O, A, P, E, -1 if mb is None else mb])
+    save('train_once', **out)
+
+
+def gen_compute_advantage():
+    """Item 3: centre / positive variants incl. the single-sample edge."""
+    out = {}
+    spec = EnvSpec(akro.Box(-1, 1, (3, )), akro.Box(-1, 1, (2, )),
+                   max_episode_length=8)
+    pol = GaussianMLPPolicy(spec, hidden_sizes=(4, ))
+    vf = GaussianMLPValueFunction(spec, hidden_sizes=(4, ))
+    rng = np.random.RandomState(7)
+    k = 0
+    for lens in ([8, 3, 5, 1], [1]):
+        N, P = len(lens), 8
+        rewards = np.zeros((N, P), np.float32)
+        base = np.full((N, P), 0.3, np.float32)
+        for i, L in enumerate(lens):
+            rewards[i, :L] = rng.randn(L)
+            base[i, :L] = rng.randn(L)
+        for center in (True, False):
+            for positive in (True, False):
+                algo = PPO(env_spec=spec, policy=pol, value_function=vf,
+                           sampler=None, center_adv=center,
+                           positive_adv=positive)
+                a = algo._compute_advantage(torch.Tensor(rewards),
+                                            np.asarray(lens),
+                                            torch.Tensor(base))
+                out['c%d_rewards' % k], out['c%d_base' % k] = rewards, base
+                out['c%d_lens' % k] = np.asarray(lens)
+                out['c%d_flags' % k] = np.asarray([center, positive])
+                out['c%d_adv' % k] = a.numpy()
+                k += 1
+    out['n_cases'] = np.asarray(k)
+    save('compute_advantage', **out)
+
+
+def gen_normalized_env():
+    from garage.envs import normalize
+    P = 5
+    inner = RefEnv(oenvs.SyntheticEnv(0, 3, 2, P, seed=9), 3, 2, P)
+    env = normalize(inner, normalize_obs=True)
+    raw, normed, means, variances = [], [], [], []
+    obs, _ = env.reset()
+    twin = oenvs.SyntheticEnv(0, 3, 2, P, seed=9)
+    raw.append(twin.reset()[0])
+    normed.append(obs)
+    means.append(env._obs_mean.copy())
+    variances.append(env._obs_var.copy())
+    for _ in range(3):
+        a = np.array([0.25, -0.5], dtype=np.float32)
+        es = env.step(a)
+        raw.append(twin.step(a).observation)
+        normed.append(es.observation)
+        means.append(env._obs_mean.copy())
+        variances.append(env._obs_var.copy())
+    save('normalized_env', raw=np.asarray(raw), normed=np.asarray(normed),
+         means=np.asarray(means), variances=np.asarray(variances),
+         alpha=np.asarray(0.001))
+
+
+def gen_log_performance():
+    out = {}
+    spec = EnvSpec(akro.Box(-1, 1, (3, )), akro.Box(-1, 1, (2, )),
+                   max_episode_length=4)
+    rng = np.random.RandomState(4)
+    for tag, lens in (('mixed', [4, 2, 1, 3]), ('timeout', [4, 4, 4])):
+        eps = make_ragged_batch(rng, spec, lens, 3, 2)
+        rec = ref.TabularRecorder()
+        gfun.tabular = rec
+        und = gfun.log_performance(3, eps, 0.9, prefix='Evaluation')
+        out[tag + '_rewards'] = eps.rewards
+        out[tag + '_lengths'] = eps.lengths
+        out[tag + '_step_types'] = np.asarray([int(s) for s in eps.step_types])
+        out[tag + '_undiscounted'] = np.asarray(und)
+        for k, v in rec.values.items():
+            out[tag + ':' + k] = np.asarray(v)
+    save('log_performance', **out)
+
+
+if __name__ == '__main__':
+    print('reference:', garage.__file__)
+    gen_returns()
+    gen_advantages()
+    gen_padding_and_steptypes()
+    gen_sampler()
+    gen_networks()
+    gen_compute_advantage()
+    gen_train_once()
+    gen_normalized_env()
+    gen_log_performance()
