@@ -1,0 +1,145 @@
+"""ctypes binding of ``libgarage_amd.so`` (the C ABI in ``include/garage_amd.h``).
+
+There is no CPU fallback: if the library is missing or a symbol is absent the
+import of any compute path fails loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, '_C', 'libgarage_amd.so')
+
+c_i32, c_i64, c_u32, c_u64 = C.c_int32, C.c_int64, C.c_uint32, C.c_uint64
+c_f32, c_f64, c_int, ptr = C.c_float, C.c_double, C.c_int, C.c_void_p
+
+
+class MlpDesc(C.Structure):
+    """``ga_mlp_desc``."""
+    _fields_ = [('n_layers', c_i32), ('dims', c_i32 * 9), ('w_off', c_i64 * 8),
+                ('b_off', c_i64 * 8), ('act_off', c_i64 * 8)]
+
+
+class SynthEnv(C.Structure):
+    """``ga_synth_env``."""
+    _fields_ = [('n', c_i64), ('env_id0', c_i64), ('obs_dim', c_i32),
+                ('act_dim', c_i32), ('discrete', c_i32), ('min_len', c_i32),
+                ('max_len', c_i32), ('seed', c_u64), ('episode', ptr),
+                ('t', ptr), ('len', ptr)]
+
+
+class HeadArgs(C.Structure):
+    """``ga_head_args``."""
+    _fields_ = [('n', c_i64), ('env_id0', c_i64), ('A', c_i32), ('kind', c_i32),
+                ('head', ptr), ('ldh', c_i64), ('log_std', ptr),
+                ('has_min', c_i32), ('has_max', c_i32), ('min_log_std', c_f32),
+                ('max_log_std', c_f32), ('noise', ptr), ('ldn', c_i64),
+                ('seed', c_u64), ('step', c_u32), ('double_softmax', c_i32),
+                ('obs', ptr), ('ldo', c_i64), ('obs_dim', c_i32),
+                ('col', c_i64), ('Tcap', c_i64), ('action', ptr),
+                ('lda', c_i64), ('obs_buf', ptr), ('act_buf', ptr),
+                ('head_buf', ptr)]
+
+
+class RecordArgs(C.Structure):
+    """``ga_record_args``."""
+    _fields_ = [('n', c_i64), ('col', c_i64), ('Tcap', c_i64),
+                ('max_episode_length', c_i32), ('reward', ptr),
+                ('step_type', ptr), ('next_obs', ptr), ('ldo', c_i64),
+                ('obs_dim', c_i32), ('ep_t', ptr), ('rew_buf', ptr),
+                ('st_buf', ptr), ('tail_buf', ptr), ('lastobs_buf', ptr),
+                ('done', ptr), ('step_eps', ptr), ('step_samples', ptr)]
+
+
+# name -> (restype, argtypes); mirrors include/garage_amd.h one to one.
+SIGNATURES = {
+    'ga_abi_version': (c_int, []),
+    'ga_last_error': (C.c_char_p, []),
+    'ga_gae_scan_f32': (c_int, [ptr, ptr, ptr, ptr, ptr, c_i64, c_i64, c_i64,
+                                c_i64, c_int, c_int, c_f64, c_f64, c_f32,
+                                c_f32, ptr, ptr, ptr]),
+    'ga_mlp_forward_f32': (c_int, [C.POINTER(MlpDesc), ptr, ptr, c_i64, ptr,
+                                   c_i64, ptr, ptr, c_i64, ptr]),
+    'ga_mlp_backward_splits': (c_i64, [C.POINTER(MlpDesc), c_i64]),
+    'ga_mlp_backward_f32': (c_int, [C.POINTER(MlpDesc), ptr, ptr, c_i64, ptr,
+                                    c_i64, ptr, ptr, c_i64, ptr, ptr, c_i64,
+                                    c_i64, ptr]),
+    'ga_gemm_nt_f32': (c_int, [ptr, c_i64, ptr, c_i64, ptr, c_i64, c_i64,
+                               c_i64, c_i64, ptr]),
+    'ga_reduction_workspace_doubles': (c_i64, []),
+    'ga_ppo_gaussian_loss_f32': (c_int, [ptr, c_i64, ptr, c_i64, ptr, ptr, ptr,
+                                         ptr, c_int, c_f32, c_int, c_f32,
+                                         c_i64, c_int, c_int, c_f32, c_f32,
+                                         c_int, ptr, ptr, ptr, ptr, c_i64,
+                                         c_i64, ptr, ptr]),
+    'ga_gaussian_nll_loss_f32': (c_int, [ptr, c_i64, ptr, ptr, ptr, c_i64, ptr,
+                                         ptr, ptr, c_i64, c_i64, ptr, ptr]),
+    'ga_gaussian_kl_f32': (c_int, [ptr, ptr, c_i64, c_i64, c_int, c_f32, c_f32,
+                                   ptr, ptr, ptr]),
+    'ga_reduce_slabs_f32': (c_int, [ptr, c_i64, c_i64, c_i64, c_f32, ptr, ptr]),
+    'ga_adam_step_f32': (c_int, [ptr, ptr, ptr, ptr, c_i64, c_i64, c_f64,
+                                 c_f64, c_f64, c_f64, ptr]),
+    'ga_stats_f32': (c_int, [ptr, c_i64, c_int, ptr, ptr, ptr]),
+    'ga_adv_center_f32': (c_int, [ptr, c_i64, ptr, c_f32, ptr]),
+    'ga_sub_scalar_f32': (c_int, [ptr, c_i64, ptr, ptr]),
+    'ga_synth_env_reset': (c_int, [C.POINTER(SynthEnv), ptr, ptr, c_i64, ptr]),
+    'ga_synth_env_step': (c_int, [C.POINTER(SynthEnv), ptr, c_i64, ptr, ptr,
+                                  c_i64, ptr, ptr, ptr]),
+    'ga_policy_head_sample': (c_int, [C.POINTER(HeadArgs), ptr]),
+    'ga_record_step': (c_int, [C.POINTER(RecordArgs), ptr]),
+    'ga_pack_episodes': (c_int, [ptr, c_i64, c_i64, c_i64, ptr, ptr, ptr, ptr,
+                                 ptr]),
+    'ga_pack_src_index': (c_int, [ptr, ptr, ptr, ptr, c_i64, c_i64, ptr, ptr]),
+    'ga_gather_rows_f32': (c_int, [ptr, c_i64, ptr, c_i64, c_i64, ptr, c_i64,
+                                   ptr]),
+    'ga_gather_f32': (c_int, [ptr, ptr, c_i64, ptr, ptr]),
+    'ga_gather_u8': (c_int, [ptr, ptr, c_i64, ptr, ptr]),
+    'ga_episode_sums_f32': (c_int, [ptr, ptr, c_i64, ptr, ptr]),
+}
+
+
+class GarageAmdError(RuntimeError):
+    """A C-ABI call returned a negative status."""
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once) and attach the prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            'garage_amd: HIP extension not built: {} is missing. Run `make` '
+            '(or `python -c "import __graft_entry__ as g; g.build()"`) in the '
+            'repository root. There is no CPU fallback.'.format(LIB_PATH))
+    lib = C.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError = missing export: fail loudly
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    """Invoke ``name`` and raise :class:`GarageAmdError` on a negative status."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        msg = lib.ga_last_error().decode('utf-8', 'replace')
+        raise GarageAmdError('{} failed ({}): {}'.format(name, rc, msg))
+
+
+def dptr(t):
+    """Device (or host) address of a torch tensor / None -> NULL."""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    """Current HIP stream of torch as a ``void*``."""
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,70 @@
+// Shared helpers for the gfx950 kernels of garage_amd.  CDNA4 only: wave = 64.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#define GA_WAVE 64
+
+// ---- error plumbing (thread-local message, negative return codes) ----------
+extern "C" const char* ga_last_error(void);
+void ga_set_error(const char* fmt, ...);
+
+#define GA_OK 0
+#define GA_ERR_ARG (-1)
+#define GA_ERR_HIP (-2)
+
+#define GA_REQUIRE(cond, ...)            \
+  do {                                   \
+    if (!(cond)) {                       \
+      ga_set_error(__VA_ARGS__);         \
+      return GA_ERR_ARG;                 \
+    }                                    \
+  } while (0)
+
+#define GA_CHECK_LAUNCH(name)                                          \
+  do {                                                                 \
+    hipError_t e__ = hipGetLastError();                                \
+    if (e__ != hipSuccess) {                                           \
+      ga_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+      return GA_ERR_HIP;                                               \
+    }                                                                  \
+  } while (0)
+
+static inline bool ga_aligned16(const void* p) {
+  return (reinterpret_cast<uintptr_t>(p) & 15u) == 0;
+}
+
+static inline int64_t ga_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- device helpers --------------------------------------------------------
+__device__ __forceinline__ float ga_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;  // valid in lane 0
+}
+
+__device__ __forceinline__ double ga_wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ float ga_wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_down(v, o, 64));
+  return v;
+}
+
+// Block-wide sum of doubles for blockDim.x == 256 (4 waves); result in thread 0.
+__device__ __forceinline__ double ga_block_sum_256(double v, double* smem4) {
+  v = ga_wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) smem4[w] = v;
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x == 0) r = smem4[0] + smem4[1] + smem4[2] + smem4[3];
+  __syncthreads();
+  return r;
+}

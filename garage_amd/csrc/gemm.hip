@@ -1,0 +1,425 @@
+// fp32 MFMA GEMM family for the MLP policy / value networks (gfx950).
+//
+// One LDS-tiled kernel, C(m,n) = epi(sum_k A(m,k) * B(k,n)), instantiated for
+// the three products an MLP layer needs (reference: nn.Linear forward/backward
+// inside torch/modules/multi_headed_mlp_module.py:136-151, driven by
+// torch/algos/vpg.py:250-293):
+//   forward      Y  = act(X W^T + b)          A, B both k-contiguous
+//   data grad    dX = (dY W) * (1 - H^2)      A k-contiguous, B n-contiguous
+//   weight grad  dW = dY^T X (+ db = 1^T dY)  A, B both "row"-contiguous,
+//                                             split-K over the batch into slabs
+// Arithmetic is exact fp32 on v_mfma_f32_32x32x2_f32 (the parity bar is 1e-5 on
+// losses, so no reduced-precision operands).  Every matrix this file touches
+// has a leading dimension that is a multiple of 4 floats and a 16-B aligned
+// base (garage_amd pads obs / weights / activations accordingly), so all
+// global traffic is 16-B vector loads; ragged edges are masked, not branched.
+//
+// Operand tiles live in LDS as [BK][BR + 4] (k-major, +4 floats keeps rows
+// 16-B aligned and the per-instruction 32-lane reads on distinct banks): the
+// MFMA A operand of lane l is tile[2*kk + (l >> 5)][row0 + (l & 31)] and B is
+// read the same way, one ds_read_b32 each.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;
+constexpr int PAD = 4;
+
+enum Epilogue { EPI_BIAS_ACT = 0, EPI_MUL_DTANH = 1, EPI_PLAIN = 2 };
+
+struct GemmParams {
+  const float* A;
+  int64_t lda;           // floats between consecutive memory lines of A
+  const int32_t* a_idx;  // optional gather applied to A's memory-line index
+  const float* B;
+  int64_t ldb;
+  const int32_t* b_idx;
+  float* C;
+  int64_t c_rs, c_cs;    // C(m,n) at C[m * c_rs + n * c_cs]
+  int M, N, K;
+  int epi;
+  const float* bias;     // EPI_BIAS_ACT: per-n bias (may be null)
+  int act;               // 0 identity, 1 tanh
+  const float* H;        // EPI_MUL_DTANH: tanh outputs, H[m * ldh + n]
+  int64_t ldh;
+  int k_per_split;       // multiple of BK
+  int64_t c_split_stride;
+  float* colsum;         // optional: sum_k of operand A (or B) -> colsum[line]
+  int colsum_of_b;       // 0: columns of A tile (index m), 1: of B tile (index n)
+  int64_t colsum_split_stride;
+};
+
+// Load one [BR x BK] operand tile into registers (16-B vectors).
+//   KC = true : memory line = r (tile row), contiguous along k
+//   KC = false: memory line = k,            contiguous along r
+template <int BR, bool KC>
+struct TileLoader {
+  static constexpr int NV = BR * BK / 4 / 256;  // float4 per thread
+  float4 regs[NV];
+
+  __device__ __forceinline__ void load(const float* __restrict__ base, int64_t ld,
+                                       const int32_t* __restrict__ idx, int r0,
+                                       int R, int k0, int kend) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int f = tid + 256 * i;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (KC) {
+        const int r = r0 + (f >> 3);
+        const int k = k0 + 4 * (f & 7);
+        if (r < R && k < kend) {
+          const int64_t line = idx ? (int64_t)idx[r] : (int64_t)r;
+          v = *reinterpret_cast<const float4*>(base + line * ld + k);
+          if (k + 1 >= kend) v.y = 0.f;
+          if (k + 2 >= kend) v.z = 0.f;
+          if (k + 3 >= kend) v.w = 0.f;
+        }
+      } else {
+        constexpr int VPL = BR / 4;  // vectors per memory line
+        const int k = k0 + f / VPL;
+        const int r = r0 + 4 * (f % VPL);
+        if (k < kend && r < R) {
+          const int64_t line = idx ? (int64_t)idx[k] : (int64_t)k;
+          v = *reinterpret_cast<const float4*>(base + line * ld + r);
+          if (r + 1 >= R) v.y = 0.f;
+          if (r + 2 >= R) v.z = 0.f;
+          if (r + 3 >= R) v.w = 0.f;
+        }
+      }
+      regs[i] = v;
+    }
+  }
+
+  __device__ __forceinline__ void store(float* __restrict__ tile) const {
+    constexpr int LD = BR + PAD;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int f = tid + 256 * i;
+      if (KC) {
+        const int r = f >> 3;
+        const int k = 4 * (f & 7);
+        tile[(k + 0) * LD + r] = regs[i].x;
+        tile[(k + 1) * LD + r] = regs[i].y;
+        tile[(k + 2) * LD + r] = regs[i].z;
+        tile[(k + 3) * LD + r] = regs[i].w;
+      } else {
+        constexpr int VPL = BR / 4;
+        const int k = f / VPL;
+        const int r = 4 * (f % VPL);
+        *reinterpret_cast<float4*>(tile + k * LD + r) = regs[i];
+      }
+    }
+  }
+};
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int LDA_S = BM + PAD, LDB_S = BN + PAD;
+  __shared__ __attribute__((aligned(16))) float lds[BK * LDA_S + BK * LDB_S];
+  float* As = lds;
+  float* Bs = lds + BK * LDA_S;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int wm0 = (wave / WAVES_N) * WM;
+  const int wn0 = (wave % WAVES_N) * WN;
+  const int m0 = blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const int split = blockIdx.z;
+  const int kbeg = split * p.k_per_split;
+  const int kend = min(p.K, kbeg + p.k_per_split);
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float csum = 0.f;  // colsum accumulator (threads < BM or < BN)
+  const bool do_colsum =
+      p.colsum != nullptr &&
+      (p.colsum_of_b ? (blockIdx.x == 0) : (blockIdx.y == 0));
+
+  TileLoader<BM, A_KC> la;
+  TileLoader<BN, B_KC> lb;
+  const int nk = (kend - kbeg + BK - 1) / BK;
+  if (nk > 0) {
+    la.load(p.A, p.lda, p.a_idx, m0, p.M, kbeg, kend);
+    lb.load(p.B, p.ldb, p.b_idx, n0, p.N, kbeg, kend);
+    la.store(As);
+    lb.store(Bs);
+  }
+  __syncthreads();
+
+  for (int s = 0; s < nk; ++s) {
+    const bool more = (s + 1 < nk);
+    if (more) {
+      const int k0 = kbeg + (s + 1) * BK;
+      la.load(p.A, p.lda, p.a_idx, m0, p.M, k0, kend);
+      lb.load(p.B, p.ldb, p.b_idx, n0, p.N, k0, kend);
+    }
+    const int half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        a[i] = As[(2 * kk + half) * LDA_S + wm0 + 32 * i + l31];
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        b[j] = Bs[(2 * kk + half) * LDB_S + wn0 + 32 * j + l31];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j],
+                                                           0, 0, 0);
+    }
+    if (do_colsum) {
+      const float* T = p.colsum_of_b ? Bs : As;
+      const int LD = p.colsum_of_b ? LDB_S : LDA_S;
+      const int W = p.colsum_of_b ? BN : BM;
+      if ((int)threadIdx.x < W) {
+#pragma unroll 8
+        for (int k = 0; k < BK; ++k) csum += T[k * LD + threadIdx.x];
+      }
+    }
+    __syncthreads();
+    if (more) {
+      la.store(As);
+      lb.store(Bs);
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: D(row, col): col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  float* Cout = p.C + (int64_t)split * p.c_split_stride;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn0 + 32 * j + (lane & 31);
+      if (n >= p.N) continue;
+      float bias = 0.f;
+      if (p.epi == EPI_BIAS_ACT && p.bias) bias = p.bias[n];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m >= p.M) continue;
+        float v = acc[i][j][r];
+        if (p.epi == EPI_BIAS_ACT) {
+          v += bias;
+          if (p.act == 1) v = tanhf(v);
+        } else if (p.epi == EPI_MUL_DTANH) {
+          const float h = p.H[(int64_t)m * p.ldh + n];
+          v *= (1.f - h * h);
+        }
+        Cout[(int64_t)m * p.c_rs + (int64_t)n * p.c_cs] = v;
+      }
+    }
+  }
+  if (do_colsum) {
+    const int W = p.colsum_of_b ? BN : BM;
+    const int base = p.colsum_of_b ? n0 : m0;
+    const int lim = p.colsum_of_b ? p.N : p.M;
+    if ((int)threadIdx.x < W && base + (int)threadIdx.x < lim)
+      p.colsum[(int64_t)split * p.colsum_split_stride + base + threadIdx.x] = csum;
+  }
+}
+
+template <bool A_KC, bool B_KC>
+int launch_gemm(const GemmParams& p, int splits, hipStream_t stream) {
+  if (p.N <= 32) {
+    dim3 grid((unsigned)ga_ceil_div(p.M, 256), (unsigned)ga_ceil_div(p.N, 32),
+              (unsigned)splits);
+    hipLaunchKernelGGL((gemm_f32_kernel<256, 32, 4, 1, A_KC, B_KC>), grid,
+                       dim3(256), 0, stream, p);
+  } else {
+    dim3 grid((unsigned)ga_ceil_div(p.M, 128), (unsigned)ga_ceil_div(p.N, 128),
+              (unsigned)splits);
+    hipLaunchKernelGGL((gemm_f32_kernel<128, 128, 2, 2, A_KC, B_KC>), grid,
+                       dim3(256), 0, stream, p);
+  }
+  GA_CHECK_LAUNCH("gemm_f32");
+  return GA_OK;
+}
+
+inline int round4(int v) { return (v + 3) & ~3; }
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// C ABI (see include/garage_amd.h)
+// ---------------------------------------------------------------------------
+struct ga_mlp_desc {
+  int32_t n_layers;    // linear layers (hidden + output), 1..8
+  int32_t dims[9];     // dims[0] = input width, dims[l + 1] = output width of layer l
+  int64_t w_off[8];    // offset (floats) of W_l [dims[l+1]][round4(dims[l])] in params
+  int64_t b_off[8];    // offset (floats) of b_l [dims[l+1]]
+  int64_t act_off[8];  // offset (floats) of layer l's output in the activation
+                       // workspace, row stride round4(dims[l + 1]) (hidden layers)
+};
+
+static int check_desc(const ga_mlp_desc* d, const char* who) {
+  GA_REQUIRE(d != nullptr, "%s: null descriptor", who);
+  GA_REQUIRE(d->n_layers >= 1 && d->n_layers <= 8, "%s: n_layers %d not in 1..8",
+             who, d->n_layers);
+  for (int l = 0; l <= d->n_layers; ++l)
+    GA_REQUIRE(d->dims[l] >= 1, "%s: dims[%d] < 1", who, l);
+  for (int l = 0; l < d->n_layers; ++l)
+    GA_REQUIRE(d->w_off[l] % 4 == 0 && d->act_off[l] % 4 == 0,
+               "%s: offsets of layer %d not 16-B aligned", who, l);
+  return GA_OK;
+}
+
+extern "C" int ga_mlp_forward_f32(const ga_mlp_desc* d, const float* params,
+                                  const float* X, int64_t ldx,
+                                  const int32_t* row_idx, int64_t M, float* acts,
+                                  float* out, int64_t ldo, hipStream_t stream) {
+  int rc = check_desc(d, "ga_mlp_forward_f32");
+  if (rc) return rc;
+  GA_REQUIRE(params && X && out, "ga_mlp_forward_f32: null pointer");
+  GA_REQUIRE(d->n_layers == 1 || acts, "ga_mlp_forward_f32: acts workspace needed");
+  GA_REQUIRE(M >= 0 && M < (1ll << 31), "ga_mlp_forward_f32: bad M");
+  GA_REQUIRE(ldx % 4 == 0 && ldx >= d->dims[0], "ga_mlp_forward_f32: ldx %lld",
+             (long long)ldx);
+  GA_REQUIRE(ldo >= d->dims[d->n_layers], "ga_mlp_forward_f32: ldo too small");
+  GA_REQUIRE(ga_aligned16(params) && ga_aligned16(X) && (!acts || ga_aligned16(acts)),
+             "ga_mlp_forward_f32: pointers must be 16-B aligned");
+  if (M == 0) return GA_OK;
+  const int L = d->n_layers;
+  for (int l = 0; l < L; ++l) {
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    if (l == 0) {
+      p.A = X; p.lda = ldx; p.a_idx = row_idx;
+    } else {
+      p.A = acts + d->act_off[l - 1]; p.lda = round4(d->dims[l]);
+    }
+    p.B = params + d->w_off[l];
+    p.ldb = round4(d->dims[l]);
+    const bool last = (l == L - 1);
+    p.C = last ? out : acts + d->act_off[l];
+    p.c_rs = last ? ldo : round4(d->dims[l + 1]);
+    p.c_cs = 1;
+    p.M = (int)M; p.N = d->dims[l + 1]; p.K = d->dims[l];
+    p.epi = EPI_BIAS_ACT;
+    p.bias = params + d->b_off[l];
+    p.act = last ? 0 : 1;
+    p.k_per_split = (int)ga_ceil_div(p.K, BK) * BK;
+    rc = launch_gemm<true, true>(p, 1, stream);
+    if (rc) return rc;
+  }
+  return GA_OK;
+}
+
+extern "C" int64_t ga_mlp_backward_splits(const ga_mlp_desc* d, int64_t M) {
+  (void)d;
+  // Rows of the batch each weight-gradient workgroup reduces before writing a
+  // slab: large enough to amortise the slab write, small enough to fill 256 CUs.
+  int64_t s = ga_ceil_div(M, 1024);
+  if (s < 1) s = 1;
+  if (s > 64) s = 64;
+  return s;
+}
+
+extern "C" int ga_mlp_backward_f32(const ga_mlp_desc* d, const float* params,
+                                   const float* X, int64_t ldx,
+                                   const int32_t* row_idx, int64_t M,
+                                   const float* acts, const float* dout,
+                                   int64_t ldo, float* dacts, float* grad_slabs,
+                                   int64_t slab_stride, int64_t n_splits,
+                                   hipStream_t stream) {
+  int rc = check_desc(d, "ga_mlp_backward_f32");
+  if (rc) return rc;
+  GA_REQUIRE(params && X && dout && grad_slabs, "ga_mlp_backward_f32: null pointer");
+  GA_REQUIRE(d->n_layers == 1 || (acts && dacts),
+             "ga_mlp_backward_f32: workspaces needed");
+  GA_REQUIRE(M > 0 && M < (1ll << 31), "ga_mlp_backward_f32: bad M");
+  GA_REQUIRE(ldx % 4 == 0 && ldo % 4 == 0 && slab_stride % 4 == 0,
+             "ga_mlp_backward_f32: strides must be multiples of 4");
+  GA_REQUIRE(n_splits >= 1 && n_splits <= 1024, "ga_mlp_backward_f32: n_splits");
+  GA_REQUIRE(ga_aligned16(params) && ga_aligned16(X) && ga_aligned16(dout) &&
+                 ga_aligned16(grad_slabs) && (!acts || ga_aligned16(acts)) &&
+                 (!dacts || ga_aligned16(dacts)),
+             "ga_mlp_backward_f32: pointers must be 16-B aligned");
+  const int L = d->n_layers;
+  int kps = (int)(ga_ceil_div(ga_ceil_div(M, n_splits), BK) * BK);
+  for (int l = L - 1; l >= 0; --l) {
+    const float* dz = (l == L - 1) ? dout : dacts + d->act_off[l];
+    const int64_t lddz = (l == L - 1) ? ldo : round4(d->dims[l + 1]);
+    const int out_w = d->dims[l + 1], in_w = d->dims[l];
+    // ---- weight + bias gradient slabs: dW[o][i] = sum_b dz[b][o] * in[b][i]
+    {
+      GemmParams p;
+      memset(&p, 0, sizeof(p));
+      const float* in = (l == 0) ? X : acts + d->act_off[l - 1];
+      const int64_t ldin = (l == 0) ? ldx : round4(in_w);
+      const int32_t* in_idx = (l == 0) ? row_idx : nullptr;
+      p.K = (int)M;
+      p.k_per_split = kps;
+      p.epi = EPI_PLAIN;
+      p.c_split_stride = slab_stride;
+      p.colsum = grad_slabs + d->b_off[l];
+      p.colsum_split_stride = slab_stride;
+      if (in_w <= 32 && out_w > 32) {
+        // (out x in), narrow in: natural orientation, 256x32 tiles
+        p.A = dz; p.lda = lddz; p.B = in; p.ldb = ldin; p.b_idx = in_idx;
+        p.M = out_w; p.N = in_w;
+        p.C = grad_slabs + d->w_off[l]; p.c_rs = round4(in_w); p.c_cs = 1;
+        p.colsum_of_b = 0;
+      } else if (out_w <= 32) {
+        // narrow out: compute dW^T = in^T dz so the narrow side is N
+        p.A = in; p.lda = ldin; p.a_idx = in_idx; p.B = dz; p.ldb = lddz;
+        p.M = in_w; p.N = out_w;
+        p.C = grad_slabs + d->w_off[l]; p.c_rs = 1; p.c_cs = round4(in_w);
+        p.colsum_of_b = 1;
+      } else {
+        p.A = dz; p.lda = lddz; p.B = in; p.ldb = ldin; p.b_idx = in_idx;
+        p.M = out_w; p.N = in_w;
+        p.C = grad_slabs + d->w_off[l]; p.c_rs = round4(in_w); p.c_cs = 1;
+        p.colsum_of_b = 0;
+      }
+      rc = launch_gemm<false, false>(p, (int)n_splits, stream);
+      if (rc) return rc;
+    }
+    // ---- data gradient for the layer below
+    if (l > 0) {
+      GemmParams p;
+      memset(&p, 0, sizeof(p));
+      p.A = dz; p.lda = lddz;
+      p.B = params + d->w_off[l]; p.ldb = round4(in_w);
+      p.C = dacts + d->act_off[l - 1]; p.c_rs = round4(in_w); p.c_cs = 1;
+      p.M = (int)M; p.N = in_w; p.K = out_w;
+      p.epi = EPI_MUL_DTANH;
+      p.H = acts + d->act_off[l - 1]; p.ldh = round4(in_w);
+      p.k_per_split = (int)ga_ceil_div(p.K, BK) * BK;
+      rc = launch_gemm<true, false>(p, 1, stream);
+      if (rc) return rc;
+    }
+  }
+  return GA_OK;
+}
+
+// Plain GEMM entry used by tests: C[M,N] = A[M,K] * B[N,K]^T (both k-contiguous).
+extern "C" int ga_gemm_nt_f32(const float* A, int64_t lda, const float* B,
+                              int64_t ldb, float* C, int64_t ldc, int64_t M,
+                              int64_t N, int64_t K, hipStream_t stream) {
+  GA_REQUIRE(A && B && C, "ga_gemm_nt_f32: null pointer");
+  GA_REQUIRE(lda % 4 == 0 && ldb % 4 == 0 && ga_aligned16(A) && ga_aligned16(B),
+             "ga_gemm_nt_f32: operands must be 16-B aligned with ld %% 4 == 0");
+  GemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.C = C; p.c_rs = ldc; p.c_cs = 1;
+  p.M = (int)M; p.N = (int)N; p.K = (int)K; p.epi = EPI_PLAIN;
+  p.k_per_split = (int)ga_ceil_div(K, BK) * BK;
+  return launch_gemm<true, true>(p, 1, stream);
+}

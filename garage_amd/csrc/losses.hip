@@ -1,0 +1,520 @@
+// Fused loss / gradient-seed / optimiser kernels of the PPO update (gfx950).
+//
+//   ga_ppo_gaussian_loss_f32   PPO._compute_objective + VPG._compute_loss_with_adv
+//                              (torch/algos/ppo.py:96-132, vpg.py:324-347,408-454)
+//                              forward AND the gradient wrt the policy mean /
+//                              scalar log-std, in one pass over the minibatch
+//   ga_gaussian_nll_loss_f32   GaussianMLPValueFunction.compute_loss
+//                              (torch/value_functions/gaussian_mlp_value_function.py:81-98)
+//   ga_gaussian_kl_f32         VPG._compute_kl_constraint (vpg.py:381-406)
+//   ga_reduce_slabs_f32 / ga_adam_step_f32
+//                              OptimizerWrapper.step == torch.optim.Adam.step
+//                              (torch/optimizers/optimizer_wrapper.py:53-63)
+//   ga_stats_* / ga_adv_center_f32 / ga_sub_scalar_f32
+//                              VPG._compute_advantage centring (vpg.py:371-377)
+//
+// All are HBM / latency bound elementwise passes: one thread per sample (rows
+// are <= a few tens of floats), fp32 math, fp64 block partials reduced in a
+// fixed order (bitwise reproducible run to run; no float atomics).
+#include "common.h"
+
+namespace {
+
+constexpr int RED_BLOCKS = 512;  // upper bound on partial-producing blocks
+constexpr double HALF_LOG_2PI = 0.91893853320467274178;
+
+__device__ __forceinline__ float softplusf(float x) {
+  // F.softplus with beta=1, threshold=20 (torch default)
+  return x > 20.f ? x : log1pf(expf(x));
+}
+__device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
+
+struct PpoLossParams {
+  const float* mean;      // [M, ldm] policy means of the minibatch rows
+  int64_t ldm;
+  const float* actions;   // [*, lda] gathered through idx (or row i when null)
+  int64_t lda;
+  const float* old_ll;    // gathered through idx
+  const float* adv;       // gathered through idx
+  const int32_t* idx;
+  const float* log_std;   // device scalar parameter (unclamped)
+  float min_log_std;      // lower clamp, applied when has_min
+  int has_min;
+  float max_log_std;
+  int has_max;
+  int64_t M;
+  int A;
+  int algo;               // 0 PPO clipped surrogate, 1 VPG (ll * adv)
+  float clip;
+  float ent_coeff;        // added to the objective when ent_regularized
+  int ent_regularized, ent_softplus, ent_stop_grad;
+  float* dmean;           // optional [M, ldm]: dLoss/dmean (already / M)
+  float* ll_out;          // optional [M]: new log-likelihoods
+  double* partials;       // [gridDim.x][2]: sum objective, sum dLoss/dlog_std * M
+};
+
+__global__ __launch_bounds__(256) void ppo_gaussian_loss_kernel(PpoLossParams p) {
+  __shared__ double red[4];
+  float s_raw = *p.log_std;
+  float s = s_raw;
+  bool s_grad = true;  // clamp passes gradient inside [min, max] (inclusive)
+  if (p.has_min && s < p.min_log_std) { s = p.min_log_std; s_grad = false; }
+  if (p.has_max && s > p.max_log_std) { s = p.max_log_std; s_grad = false; }
+  const float inv_var = expf(-2.f * s);
+  const float lognorm = s + (float)HALF_LOG_2PI;
+  const float invM = 1.f / (float)p.M;
+
+  double obj_sum = 0.0, ds_sum = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < p.M;
+       i += (int64_t)gridDim.x * 256) {
+    const int64_t src = p.idx ? (int64_t)p.idx[i] : i;
+    const float* mu = p.mean + i * p.ldm;
+    const float* a = p.actions + src * p.lda;
+    float ll = 0.f, q = 0.f;  // q = sum (a-mu)^2 / var
+    for (int j = 0; j < p.A; ++j) {
+      const float d = a[j] - mu[j];
+      const float z = d * d * inv_var;
+      q += z;
+      ll += -0.5f * z - lognorm;
+    }
+    if (p.ll_out) p.ll_out[i] = ll;
+    const float adv = p.adv[src];
+    float obj, g;  // g = d obj / d ll
+    if (p.algo == 1) {
+      obj = ll * adv;
+      g = adv;
+    } else {
+      const float ratio = expf(ll - p.old_ll[src]);
+      const float lo = 1.f - p.clip, hi = 1.f + p.clip;
+      const float rc = fminf(fmaxf(ratio, lo), hi);
+      const float s1 = ratio * adv, s2 = rc * adv;
+      obj = fminf(s1, s2);
+      const float g1 = adv * ratio;                                  // via surr
+      const float g2 = (ratio >= lo && ratio <= hi) ? adv * ratio : 0.f;  // via clip
+      // torch.min backward: the smaller input gets the gradient, ties split it
+      g = (s1 < s2) ? g1 : ((s1 > s2) ? g2 : 0.5f * (g1 + g2));
+    }
+    obj_sum += (double)obj;
+    if (p.dmean) {
+      float* dm = p.dmean + i * p.ldm;
+      const float scale = -g * invM * inv_var;
+      for (int j = 0; j < p.A; ++j) dm[j] = scale * (a[j] - mu[j]);
+    }
+    // d ll / d s = sum_j ((a-mu)^2/var - 1)
+    ds_sum += (double)(-g * (q - (float)p.A));
+  }
+  const double o = ga_block_sum_256(obj_sum, red);
+  const double d = ga_block_sum_256(ds_sum, red);
+  if (threadIdx.x == 0) {
+    p.partials[2 * blockIdx.x + 0] = o;
+    p.partials[2 * blockIdx.x + 1] = d;
+  }
+  (void)s_grad;
+  (void)s_raw;
+}
+
+struct PpoFinalizeParams {
+  const double* partials;
+  int nblocks;
+  const float* log_std;
+  float min_log_std, max_log_std;
+  int has_min, has_max;
+  int64_t M;
+  int A;
+  float ent_coeff;
+  int ent_regularized, ent_softplus, ent_stop_grad;
+  float* loss_out;      // scalar
+  float* grad_slab0;    // optional: slot that receives dLoss/dlog_std
+  int64_t slab_stride;  // the same slot of slabs 1..n_splits-1 is zeroed
+  int64_t n_splits;
+};
+
+__global__ void ppo_gaussian_finalize_kernel(PpoFinalizeParams p) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double obj = 0.0, ds = 0.0;
+  for (int b = 0; b < p.nblocks; ++b) {
+    obj += p.partials[2 * b + 0];
+    ds += p.partials[2 * b + 1];
+  }
+  float s = *p.log_std;
+  bool s_grad = true;
+  if (p.has_min && s < p.min_log_std) { s = p.min_log_std; s_grad = false; }
+  if (p.has_max && s > p.max_log_std) { s = p.max_log_std; s_grad = false; }
+  double mean_obj = obj / (double)p.M;
+  double dlogstd = ds / (double)p.M;  // d(-mean obj)/ds through the likelihood
+  if (p.ent_regularized) {
+    // Independent Normal entropy: A * (0.5 + 0.5 log 2pi + s), state independent
+    float ent = (float)p.A * (0.5f + (float)HALF_LOG_2PI + s);
+    float dent = (float)p.A;
+    if (p.ent_softplus) {
+      dent *= sigmoidf(ent);
+      ent = softplusf(ent);
+    }
+    mean_obj += (double)(p.ent_coeff * ent);
+    if (!p.ent_stop_grad) dlogstd += -(double)(p.ent_coeff * dent);
+  }
+  *p.loss_out = (float)(-mean_obj);
+  if (p.grad_slab0) {
+    p.grad_slab0[0] = s_grad ? (float)dlogstd : 0.f;
+    for (int64_t k = 1; k < p.n_splits; ++k) p.grad_slab0[k * p.slab_stride] = 0.f;
+  }
+}
+
+struct NllParams {
+  const float* v;        // [M, ldv], value in column 0
+  int64_t ldv;
+  const float* returns;  // gathered through idx
+  const int32_t* idx;
+  const float* log_std;  // device scalar, no clamp (min_std=None, max_std=None)
+  int64_t M;
+  float* dv;             // optional [M, ldv] column 0
+  double* partials;      // [gridDim.x][2]
+};
+
+__global__ __launch_bounds__(256) void gaussian_nll_kernel(NllParams p) {
+  __shared__ double red[4];
+  const float s = *p.log_std;
+  const float inv_var = expf(-2.f * s);
+  const float invM = 1.f / (float)p.M;
+  double nll = 0.0, ds = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < p.M;
+       i += (int64_t)gridDim.x * 256) {
+    const int64_t src = p.idx ? (int64_t)p.idx[i] : i;
+    const float d = p.returns[src] - p.v[i * p.ldv];
+    const float z = d * d * inv_var;
+    nll += (double)(0.5f * z + s + (float)HALF_LOG_2PI);
+    ds += (double)(1.f - z);
+    if (p.dv) p.dv[i * p.ldv] = -d * inv_var * invM;
+  }
+  const double a = ga_block_sum_256(nll, red);
+  const double b = ga_block_sum_256(ds, red);
+  if (threadIdx.x == 0) {
+    p.partials[2 * blockIdx.x + 0] = a;
+    p.partials[2 * blockIdx.x + 1] = b;
+  }
+}
+
+__global__ void gaussian_nll_finalize_kernel(const double* partials, int nblocks,
+                                             int64_t M, float* loss_out,
+                                             float* grad_slab0, int64_t slab_stride,
+                                             int64_t n_splits) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double a = 0.0, b = 0.0;
+  for (int k = 0; k < nblocks; ++k) {
+    a += partials[2 * k];
+    b += partials[2 * k + 1];
+  }
+  *loss_out = (float)(a / (double)M);
+  if (grad_slab0) {
+    grad_slab0[0] = (float)(b / (double)M);
+    for (int64_t k = 1; k < n_splits; ++k) grad_slab0[k * slab_stride] = 0.f;
+  }
+}
+
+// KL(old || new) of Independent Normals with scalar log-stds, summed over rows.
+__global__ __launch_bounds__(256) void gaussian_kl_kernel(
+    const float* mean_old, const float* mean_new, int64_t ld, int64_t M, int A,
+    float s_old, float s_new, double* partials) {
+  __shared__ double red[4];
+  // torch kl_normal_normal: 0.5 * (var_ratio + t1 - 1 - log(var_ratio))
+  const float ratio = expf(s_old - s_new);
+  const float var_ratio = ratio * ratio;
+  const float inv_std_new = expf(-s_new);
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < M;
+       i += (int64_t)gridDim.x * 256) {
+    float kl = 0.f;
+    for (int j = 0; j < A; ++j) {
+      const float t = (mean_old[i * ld + j] - mean_new[i * ld + j]) * inv_std_new;
+      kl += 0.5f * (var_ratio + t * t - 1.f - logf(var_ratio));
+    }
+    acc += (double)kl;
+  }
+  const double r = ga_block_sum_256(acc, red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = r;
+}
+
+__global__ void sum_partials_kernel(const double* partials, int nblocks, double* out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double a = 0.0;
+  for (int k = 0; k < nblocks; ++k) a += partials[k];
+  *out = a;
+}
+
+// ---- optimiser --------------------------------------------------------------
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* slabs,
+                                                           int64_t n_splits,
+                                                           int64_t stride, int64_t n,
+                                                           float* out, float scale) {
+  const int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i4 >= n) return;  // n is a multiple of 4 (flat buffers are padded)
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t s = 0; s < n_splits; ++s) {
+    const float4 v = *reinterpret_cast<const float4*>(slabs + s * stride + i4);
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  acc.x *= scale; acc.y *= scale; acc.z *= scale; acc.w *= scale;
+  *reinterpret_cast<float4*>(out + i4) = acc;
+}
+
+struct AdamParams {
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  int64_t n;
+  float lerp_w;        // 1 - beta1
+  float beta2, one_minus_beta2;
+  float neg_step_size; // -lr / (1 - beta1^t)
+  float bc2_sqrt;      // sqrt(1 - beta2^t)
+  float eps;
+};
+
+__global__ __launch_bounds__(256) void adam_kernel(AdamParams a) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n) return;
+  const float g = a.g[i];
+  float m = a.m[i], v = a.v[i];
+  m = m + a.lerp_w * (g - m);                 // exp_avg.lerp_(grad, 1 - beta1)
+  v = v * a.beta2 + a.one_minus_beta2 * g * g;  // mul_(beta2).addcmul_(g, g, 1-beta2)
+  const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+  a.p[i] = a.p[i] + (a.neg_step_size * m) / denom;  // addcdiv_
+  a.m[i] = m;
+  a.v[i] = v;
+}
+
+// ---- advantage statistics ---------------------------------------------------
+// stats (device, double[4]): [0] sum, [1] count, [2] sum of squared deviations,
+// [3] minimum.  Between the stages a multi-GPU caller all-reduces the slots.
+template <int WHAT>  // 0: sum, 1: squared deviations from stats mean, 2: min
+__global__ __launch_bounds__(256) void stats_partial_kernel(const float* x, int64_t n,
+                                                            const double* stats,
+                                                            double* partials) {
+  __shared__ double red[4];
+  double mean = 0.0;
+  if (WHAT == 1) mean = stats[0] / stats[1];
+  double acc = (WHAT == 2) ? 1.0e300 : 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * 256) {
+    const double v = (double)x[i];
+    if (WHAT == 0) acc += v;
+    if (WHAT == 1) acc += (v - mean) * (v - mean);
+    if (WHAT == 2) acc = fmin(acc, v);
+  }
+  if (WHAT == 2) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc = fmin(acc, __shfl_down(acc, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0)
+      partials[blockIdx.x] = fmin(fmin(red[0], red[1]), fmin(red[2], red[3]));
+  } else {
+    const double r = ga_block_sum_256(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = r;
+  }
+}
+
+template <int WHAT>
+__global__ void stats_finalize_kernel(const double* partials, int nblocks, int64_t n,
+                                      double* stats) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (WHAT == 2) {
+    double a = 1.0e300;
+    for (int k = 0; k < nblocks; ++k) a = fmin(a, partials[k]);
+    stats[3] = a;
+  } else {
+    double a = 0.0;
+    for (int k = 0; k < nblocks; ++k) a += partials[k];
+    if (WHAT == 0) {
+      stats[0] = a;
+      stats[1] = (double)n;
+    } else {
+      stats[2] = a;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void adv_center_kernel(float* x, int64_t n,
+                                                         const double* stats,
+                                                         float eps) {
+  // (a - mean) / (var + 1e-8), unbiased variance, in fp32 like the reference
+  const float mean = (float)(stats[0] / stats[1]);
+  const float var = (float)(stats[2] / (stats[1] - 1.0));
+  const float denom = var + eps;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * 256)
+    x[i] = (x[i] - mean) / denom;
+}
+
+__global__ __launch_bounds__(256) void sub_scalar_kernel(float* x, int64_t n,
+                                                         const double* scalar) {
+  const float s = (float)(*scalar);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * 256)
+    x[i] -= s;
+}
+
+inline int red_blocks(int64_t n) {
+  int64_t b = ga_ceil_div(n, 256 * 4);
+  if (b < 1) b = 1;
+  if (b > RED_BLOCKS) b = RED_BLOCKS;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" int64_t ga_reduction_workspace_doubles(void) { return 2 * RED_BLOCKS; }
+
+extern "C" int ga_ppo_gaussian_loss_f32(
+    const float* mean, int64_t ldm, const float* actions, int64_t lda,
+    const float* old_ll, const float* adv, const int32_t* idx, const float* log_std,
+    int has_min, float min_log_std, int has_max, float max_log_std, int64_t M, int A,
+    int algo, float clip, float ent_coeff, int ent_flags, float* dmean,
+    float* ll_out, float* loss_out, float* grad_slab0, int64_t slab_stride,
+    int64_t n_splits, double* workspace, hipStream_t stream) {
+  GA_REQUIRE(mean && actions && adv && log_std && loss_out && workspace,
+             "ga_ppo_gaussian_loss_f32: null pointer");
+  GA_REQUIRE(algo == 1 || old_ll, "ga_ppo_gaussian_loss_f32: PPO needs old_ll");
+  GA_REQUIRE(M > 0 && A > 0 && ldm >= A && lda >= A,
+             "ga_ppo_gaussian_loss_f32: bad sizes");
+  PpoLossParams p;
+  p.mean = mean; p.ldm = ldm; p.actions = actions; p.lda = lda; p.old_ll = old_ll;
+  p.adv = adv; p.idx = idx; p.log_std = log_std; p.min_log_std = min_log_std;
+  p.has_min = has_min; p.max_log_std = max_log_std; p.has_max = has_max; p.M = M;
+  p.A = A; p.algo = algo; p.clip = clip; p.ent_coeff = ent_coeff;
+  p.ent_regularized = ent_flags & 1; p.ent_softplus = (ent_flags >> 1) & 1;
+  p.ent_stop_grad = (ent_flags >> 2) & 1;
+  p.dmean = dmean; p.ll_out = ll_out; p.partials = workspace;
+  const int nb = red_blocks(M);
+  hipLaunchKernelGGL(ppo_gaussian_loss_kernel, dim3(nb), dim3(256), 0, stream, p);
+  GA_CHECK_LAUNCH("ppo_gaussian_loss");
+  PpoFinalizeParams f;
+  f.partials = workspace; f.nblocks = nb; f.log_std = log_std;
+  f.min_log_std = min_log_std; f.max_log_std = max_log_std; f.has_min = has_min;
+  f.has_max = has_max; f.M = M; f.A = A; f.ent_coeff = ent_coeff;
+  f.ent_regularized = p.ent_regularized; f.ent_softplus = p.ent_softplus;
+  f.ent_stop_grad = p.ent_stop_grad; f.loss_out = loss_out;
+  f.grad_slab0 = grad_slab0; f.slab_stride = slab_stride; f.n_splits = n_splits;
+  hipLaunchKernelGGL(ppo_gaussian_finalize_kernel, dim3(1), dim3(64), 0, stream, f);
+  GA_CHECK_LAUNCH("ppo_gaussian_finalize");
+  return GA_OK;
+}
+
+extern "C" int ga_gaussian_nll_loss_f32(const float* v, int64_t ldv,
+                                        const float* returns, const int32_t* idx,
+                                        const float* log_std, int64_t M, float* dv,
+                                        float* loss_out, float* grad_slab0,
+                                        int64_t slab_stride, int64_t n_splits,
+                                        double* workspace, hipStream_t stream) {
+  GA_REQUIRE(v && returns && log_std && loss_out && workspace,
+             "ga_gaussian_nll_loss_f32: null pointer");
+  GA_REQUIRE(M > 0 && ldv >= 1, "ga_gaussian_nll_loss_f32: bad sizes");
+  NllParams p;
+  p.v = v; p.ldv = ldv; p.returns = returns; p.idx = idx; p.log_std = log_std;
+  p.M = M; p.dv = dv; p.partials = workspace;
+  const int nb = red_blocks(M);
+  hipLaunchKernelGGL(gaussian_nll_kernel, dim3(nb), dim3(256), 0, stream, p);
+  GA_CHECK_LAUNCH("gaussian_nll");
+  hipLaunchKernelGGL(gaussian_nll_finalize_kernel, dim3(1), dim3(64), 0, stream,
+                     (const double*)workspace, nb, M, loss_out, grad_slab0,
+                     slab_stride, n_splits);
+  GA_CHECK_LAUNCH("gaussian_nll_finalize");
+  return GA_OK;
+}
+
+extern "C" int ga_gaussian_kl_f32(const float* mean_old, const float* mean_new,
+                                  int64_t ld, int64_t M, int A, float log_std_old,
+                                  float log_std_new, double* kl_sum_out,
+                                  double* workspace, hipStream_t stream) {
+  GA_REQUIRE(mean_old && mean_new && kl_sum_out && workspace,
+             "ga_gaussian_kl_f32: null pointer");
+  GA_REQUIRE(M > 0 && A > 0 && ld >= A, "ga_gaussian_kl_f32: bad sizes");
+  const int nb = red_blocks(M);
+  hipLaunchKernelGGL(gaussian_kl_kernel, dim3(nb), dim3(256), 0, stream, mean_old,
+                     mean_new, ld, M, A, log_std_old, log_std_new, workspace);
+  GA_CHECK_LAUNCH("gaussian_kl");
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, stream,
+                     (const double*)workspace, nb, kl_sum_out);
+  GA_CHECK_LAUNCH("sum_partials");
+  return GA_OK;
+}
+
+extern "C" int ga_reduce_slabs_f32(const float* slabs, int64_t n_splits,
+                                   int64_t slab_stride, int64_t n, float scale,
+                                   float* out, hipStream_t stream) {
+  GA_REQUIRE(slabs && out, "ga_reduce_slabs_f32: null pointer");
+  GA_REQUIRE(n > 0 && n % 4 == 0 && slab_stride % 4 == 0 && n_splits >= 1,
+             "ga_reduce_slabs_f32: n and stride must be multiples of 4");
+  GA_REQUIRE(ga_aligned16(slabs) && ga_aligned16(out),
+             "ga_reduce_slabs_f32: 16-B alignment required");
+  const int64_t nb = ga_ceil_div(n / 4, 256);
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)nb), dim3(256), 0, stream,
+                     slabs, n_splits, slab_stride, n, out, scale);
+  GA_CHECK_LAUNCH("reduce_slabs");
+  return GA_OK;
+}
+
+extern "C" int ga_adam_step_f32(float* params, const float* grads, float* exp_avg,
+                                float* exp_avg_sq, int64_t n, int64_t step, double lr,
+                                double beta1, double beta2, double eps,
+                                hipStream_t stream) {
+  GA_REQUIRE(params && grads && exp_avg && exp_avg_sq, "ga_adam_step_f32: null pointer");
+  GA_REQUIRE(n > 0 && step >= 1, "ga_adam_step_f32: bad n / step");
+  AdamParams a;
+  a.p = params; a.g = grads; a.m = exp_avg; a.v = exp_avg_sq; a.n = n;
+  a.lerp_w = (float)(1.0 - beta1);
+  a.beta2 = (float)beta2;
+  a.one_minus_beta2 = (float)(1.0 - beta2);
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  const double bc2 = 1.0 - pow(beta2, (double)step);
+  a.neg_step_size = (float)(-(lr / bc1));
+  a.bc2_sqrt = (float)sqrt(bc2);
+  a.eps = (float)eps;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)ga_ceil_div(n, 256)), dim3(256), 0,
+                     stream, a);
+  GA_CHECK_LAUNCH("adam");
+  return GA_OK;
+}
+
+extern "C" int ga_stats_f32(const float* x, int64_t n, int what, double* stats,
+                            double* workspace, hipStream_t stream) {
+  GA_REQUIRE(x && stats && workspace, "ga_stats_f32: null pointer");
+  GA_REQUIRE(n > 0 && what >= 0 && what <= 2, "ga_stats_f32: bad arguments");
+  const int nb = red_blocks(n);
+  if (what == 0) {
+    hipLaunchKernelGGL(stats_partial_kernel<0>, dim3(nb), dim3(256), 0, stream, x, n,
+                       (const double*)stats, workspace);
+    hipLaunchKernelGGL(stats_finalize_kernel<0>, dim3(1), dim3(64), 0, stream,
+                       (const double*)workspace, nb, n, stats);
+  } else if (what == 1) {
+    hipLaunchKernelGGL(stats_partial_kernel<1>, dim3(nb), dim3(256), 0, stream, x, n,
+                       (const double*)stats, workspace);
+    hipLaunchKernelGGL(stats_finalize_kernel<1>, dim3(1), dim3(64), 0, stream,
+                       (const double*)workspace, nb, n, stats);
+  } else {
+    hipLaunchKernelGGL(stats_partial_kernel<2>, dim3(nb), dim3(256), 0, stream, x, n,
+                       (const double*)stats, workspace);
+    hipLaunchKernelGGL(stats_finalize_kernel<2>, dim3(1), dim3(64), 0, stream,
+                       (const double*)workspace, nb, n, stats);
+  }
+  GA_CHECK_LAUNCH("stats");
+  return GA_OK;
+}
+
+extern "C" int ga_adv_center_f32(float* x, int64_t n, const double* stats, float eps,
+                                 hipStream_t stream) {
+  GA_REQUIRE(x && stats && n > 0, "ga_adv_center_f32: bad arguments");
+  hipLaunchKernelGGL(adv_center_kernel, dim3(red_blocks(n)), dim3(256), 0, stream, x,
+                     n, stats, eps);
+  GA_CHECK_LAUNCH("adv_center");
+  return GA_OK;
+}
+
+extern "C" int ga_sub_scalar_f32(float* x, int64_t n, const double* scalar,
+                                 hipStream_t stream) {
+  GA_REQUIRE(x && scalar && n > 0, "ga_sub_scalar_f32: bad arguments");
+  hipLaunchKernelGGL(sub_scalar_kernel, dim3(red_blocks(n)), dim3(256), 0, stream, x,
+                     n, scalar);
+  GA_CHECK_LAUNCH("sub_scalar");
+  return GA_OK;
+}

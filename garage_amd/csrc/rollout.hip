@@ -1,0 +1,574 @@
+// Rollout-side kernels: action sampling heads, the synthetic batched
+// environment, per-step episode bookkeeping and the ragged -> packed compaction.
+//
+// Together they replace the Python per-env loop of VecWorker.step_episode /
+// _gather_episode / collect_episode (sampler/vec_worker.py:139-219) and
+// StochasticPolicy.get_actions' dist.sample() (torch/policies/stochastic_policy.py:
+// 46-89).  Rollout buffers are env-major (n_envs, Tcap[, width]) in HBM; one
+// thread owns one env (its row tails are 16-B friendly: widths are padded to 4).
+#include "common.h"
+
+namespace {
+
+// ---- Philox4x32-10 (Random123; Salmon et al. SC'11) --------------------------
+struct U4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2,
+                                            uint32_t c3, uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+    const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+    const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return U4{c0, c1, c2, c3};
+}
+
+// uint32 -> fp32 uniform on [-sqrt3, sqrt3): every step exact or singly rounded,
+// so the CPU twin (oracle/envs.py) reproduces it bit for bit.
+__device__ __forceinline__ float u32_unit_variance(uint32_t u) {
+  const float f = __fmul_rn((float)(u >> 8), 1.1920928955078125e-07f);  // 2^-23
+  return __fmul_rn(__fsub_rn(f, 1.0f), 1.7320508f);
+}
+__device__ __forceinline__ float u32_unit_interval(uint32_t u) {
+  return ((float)(u >> 8) + 0.5f) * 5.9604644775390625e-08f;  // (0,1)
+}
+
+constexpr uint32_t STREAM_OBS = 0, STREAM_REWARD = 1, STREAM_LENGTH = 2;
+constexpr uint32_t STREAM_ACTION = 3;
+
+// ---- synthetic environment ---------------------------------------------------
+struct SynthEnv {
+  int64_t n;
+  int64_t env_id0;       // global id of env 0 of this shard
+  int obs_dim, act_dim, discrete;
+  int min_len, max_len;
+  uint32_t k0, k1;       // seed
+  int32_t* episode;      // [n] episode counter (-1 before the first reset)
+  int32_t* t;            // [n] steps taken in the current episode
+  int32_t* len;          // [n] length of the current episode
+};
+
+__device__ __forceinline__ void synth_obs(const SynthEnv& e, uint32_t env,
+                                          uint32_t episode, uint32_t t, float* out) {
+  for (int b = 0; b * 4 < e.obs_dim; ++b) {
+    const U4 r = philox4x32_10(env, episode, t, (STREAM_OBS << 16) | (uint32_t)b,
+                               e.k0, e.k1);
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+    for (int j = 0; j < 4 && b * 4 + j < e.obs_dim; ++j)
+      out[b * 4 + j] = u32_unit_variance(w[j]);
+  }
+}
+
+__device__ __forceinline__ int synth_len(const SynthEnv& e, uint32_t env,
+                                         uint32_t episode) {
+  if (e.min_len >= e.max_len) return e.max_len;
+  const U4 r = philox4x32_10(env, episode, 0, STREAM_LENGTH << 16, e.k0, e.k1);
+  return e.min_len + (int)(r.x % (uint32_t)(e.max_len - e.min_len + 1));
+}
+
+// reset envs where mask != 0 (mask == null: all); writes the first observation.
+__global__ __launch_bounds__(256) void synth_reset_kernel(SynthEnv e,
+                                                          const uint8_t* mask,
+                                                          float* obs, int64_t ldo) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= e.n) return;
+  if (mask && !mask[i]) return;
+  const uint32_t env = (uint32_t)(e.env_id0 + i);
+  const int ep = e.episode[i] + 1;
+  e.episode[i] = ep;
+  e.t[i] = 0;
+  e.len[i] = synth_len(e, env, (uint32_t)ep);
+  synth_obs(e, env, (uint32_t)ep, 0u, obs + i * ldo);
+}
+
+// one env step: reward, step type and the (true) next observation.
+__global__ __launch_bounds__(256) void synth_step_kernel(
+    SynthEnv e, const float* actions, int64_t lda, const float* obs, float* next_obs,
+    int64_t ldo, float* reward, uint8_t* step_type) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= e.n) return;
+  const uint32_t env = (uint32_t)(e.env_id0 + i);
+  const uint32_t ep = (uint32_t)e.episode[i];
+  const int t = e.t[i];
+  const U4 r = philox4x32_10(env, ep, (uint32_t)t, STREAM_REWARD << 16, e.k0, e.k1);
+  const float noise = u32_unit_variance(r.x);
+  const float* o = obs + i * ldo;
+  const float* a = actions + i * lda;
+  float shaped = 0.f;
+  if (e.discrete) {
+    shaped = o[((int)a[0]) % e.obs_dim];
+  } else {
+    const int m = min(e.act_dim, e.obs_dim);
+    for (int j = 0; j < m; ++j) {
+      const float aj = fminf(fmaxf(a[j], -1.f), 1.f);
+      shaped = __fadd_rn(shaped, __fmul_rn(aj, o[j]));  // no fma: matches numpy
+    }
+  }
+  reward[i] = __fadd_rn(noise, __fmul_rn(0.1f, shaped));
+  const int tn = t + 1;
+  e.t[i] = tn;
+  synth_obs(e, env, ep, (uint32_t)tn, next_obs + i * ldo);
+  // StepType.get_step_type (_dtypes.py:42-68): TIMEOUT wins over done
+  uint8_t st;
+  if (tn >= e.max_len) st = 3;
+  else if (tn >= e.len[i]) st = 2;
+  else if (tn == 1) st = 0;
+  else st = 1;
+  step_type[i] = st;
+}
+
+// ---- action heads --------------------------------------------------------------
+struct HeadParams {
+  int64_t n;
+  int64_t env_id0;
+  int A;                  // action dim (gaussian) or number of classes (categorical)
+  const float* head;      // [n, ldh] means or class scores
+  int64_t ldh;
+  const float* log_std;   // gaussian: device scalar
+  int has_min, has_max;
+  float min_log_std, max_log_std;
+  const float* noise;     // optional [n, ldn]: N(0,1) (gaussian) / U(0,1) (categorical)
+  int64_t ldn;
+  uint32_t k0, k1;
+  uint32_t step;          // global step counter (Philox counter)
+  int double_softmax;
+  const float* obs;       // [n, ldo] current observations (copied into the buffer)
+  int64_t ldo;
+  int obs_dim;
+  // rollout buffers, column `col`
+  int64_t col, Tcap;
+  float* action;          // [n, lda] actions handed to the env
+  int64_t lda;
+  float* obs_buf;         // [n, Tcap, ldo]
+  float* act_buf;         // [n, Tcap, lda]
+  float* head_buf;        // optional [n, Tcap, ldh]: agent_info 'mean' / probs
+};
+
+__device__ __forceinline__ void box_muller(uint32_t u0, uint32_t u1, float* z0,
+                                           float* z1) {
+  const float a = u32_unit_interval(u0), b = u32_unit_interval(u1);
+  const float rad = sqrtf(-2.f * logf(a));
+  float s, c;
+  sincosf(6.28318530717958647692f * b, &s, &c);
+  *z0 = rad * c;
+  *z1 = rad * s;
+}
+
+__global__ __launch_bounds__(256) void gaussian_head_kernel(HeadParams p) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.n) return;
+  float s = *p.log_std;
+  if (p.has_min) s = fmaxf(s, p.min_log_std);
+  if (p.has_max) s = fminf(s, p.max_log_std);
+  const float std = expf(s);
+  const uint32_t env = (uint32_t)(p.env_id0 + i);
+  const float* mu = p.head + i * p.ldh;
+  float* act = p.action + i * p.lda;
+  const int64_t cell = i * p.Tcap + p.col;
+  float* act_row = p.act_buf + cell * p.lda;
+  for (int b = 0; b * 4 < p.A; ++b) {
+    float z[4];
+    if (p.noise) {
+      for (int j = 0; j < 4 && b * 4 + j < p.A; ++j)
+        z[j] = p.noise[i * p.ldn + b * 4 + j];
+    } else {
+      const U4 r = philox4x32_10(env, p.step, (uint32_t)b, STREAM_ACTION << 16, p.k0,
+                                 p.k1);
+      box_muller(r.x, r.y, &z[0], &z[1]);
+      box_muller(r.z, r.w, &z[2], &z[3]);
+    }
+    for (int j = 0; j < 4 && b * 4 + j < p.A; ++j) {
+      const float a = mu[b * 4 + j] + std * z[j];
+      act[b * 4 + j] = a;
+      act_row[b * 4 + j] = a;
+    }
+  }
+  if (p.head_buf) {
+    float* h = p.head_buf + cell * p.ldh;
+    for (int j = 0; j < p.A; ++j) h[j] = mu[j];
+  }
+  const float* o = p.obs + i * p.ldo;
+  float* ob = p.obs_buf + cell * p.ldo;
+  for (int j = 0; j < p.obs_dim; ++j) ob[j] = o[j];
+}
+
+__global__ __launch_bounds__(256) void categorical_head_kernel(HeadParams p) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.n) return;
+  const float* sc = p.head + i * p.ldh;
+  const int64_t cell = i * p.Tcap + p.col;
+  // probabilities: softmax(scores), or softmax(softmax(scores))
+  float mx = sc[0];
+  for (int j = 1; j < p.A; ++j) mx = fmaxf(mx, sc[j]);
+  float den = 0.f;
+  for (int j = 0; j < p.A; ++j) den += expf(sc[j] - mx);
+  float den2 = 0.f;
+  if (p.double_softmax)
+    for (int j = 0; j < p.A; ++j) den2 += expf(expf(sc[j] - mx) / den);
+  float u;
+  if (p.noise) {
+    u = p.noise[i * p.ldn];
+  } else {
+    const U4 r = philox4x32_10((uint32_t)(p.env_id0 + i), p.step, 0u,
+                               STREAM_ACTION << 16, p.k0, p.k1);
+    u = u32_unit_interval(r.x);
+  }
+  float cdf = 0.f;
+  int pick = p.A - 1;
+  float* h = p.head_buf ? p.head_buf + cell * p.ldh : nullptr;
+  bool found = false;
+  for (int j = 0; j < p.A; ++j) {
+    float pr = expf(sc[j] - mx) / den;
+    if (p.double_softmax) pr = expf(pr) / den2;
+    if (h) h[j] = pr;
+    cdf += pr;
+    if (!found && u < cdf) { pick = j; found = true; }
+  }
+  p.action[i * p.lda] = (float)pick;
+  p.act_buf[cell * p.lda] = (float)pick;
+  const float* o = p.obs + i * p.ldo;
+  float* ob = p.obs_buf + cell * p.ldo;
+  for (int j = 0; j < p.obs_dim; ++j) ob[j] = o[j];
+}
+
+// ---- per-step bookkeeping (VecWorker.step_episode, vec_worker.py:176-204) ------
+struct RecordParams {
+  int64_t n, col, Tcap;
+  int max_episode_length;
+  const float* reward;       // [n]
+  const uint8_t* step_type;  // [n]
+  const float* next_obs;     // [n, ldo]
+  int64_t ldo;
+  int obs_dim;
+  int32_t* ep_t;             // [n] steps so far in the running episode
+  float* rew_buf;            // [n, Tcap]
+  uint8_t* st_buf;           // [n, Tcap]
+  uint16_t* tail_buf;        // [n, Tcap] episode length at its last step, else 0
+  float* lastobs_buf;        // [n, Tcap, ldo] written at episode ends only
+  uint8_t* done;             // [n] 1 where the env must be reset
+  int32_t* step_eps;         // [Tcap] episodes finished at this step
+  int32_t* step_samples;     // [Tcap] their total length
+};
+
+__global__ __launch_bounds__(256) void record_step_kernel(RecordParams p) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int ended_len = 0;
+  if (i < p.n) {
+    const int64_t cell = i * p.Tcap + p.col;
+    const int t = p.ep_t[i] + 1;
+    const uint8_t st = p.step_type[i];
+    const bool ended = (t >= p.max_episode_length) || (st >= 2);
+    p.rew_buf[cell] = p.reward[i];
+    p.st_buf[cell] = st;
+    p.tail_buf[cell] = ended ? (uint16_t)t : (uint16_t)0;
+    p.done[i] = ended ? 1 : 0;
+    p.ep_t[i] = ended ? 0 : t;
+    if (ended) {
+      ended_len = t;
+      const float* o = p.next_obs + i * p.ldo;
+      float* lo = p.lastobs_buf + cell * p.ldo;
+      for (int j = 0; j < p.obs_dim; ++j) lo[j] = o[j];
+    }
+  }
+  // wave-aggregated integer atomics (deterministic: integer adds commute)
+  const uint64_t ballot = __ballot(ended_len > 0);
+  int sum = ended_len;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o, 64);
+  if ((threadIdx.x & 63) == 0 && ballot) {
+    atomicAdd(&p.step_eps[p.col], (int)__popcll(ballot));
+    atomicAdd(&p.step_samples[p.col], sum);
+  }
+}
+
+// ---- ragged -> packed ------------------------------------------------------------
+// Episodes in batch order = (completion step, env index).
+// One block per completion step t <= t_star ranks the envs that ended there.
+__global__ __launch_bounds__(256) void pack_episodes_kernel(
+    const uint16_t* tail_buf, int64_t n, int64_t Tcap, const int32_t* ep_base,
+    int32_t* ep_env, int32_t* ep_end, int32_t* ep_len) {
+  __shared__ int wave_cnt[4];
+  __shared__ int running;
+  const int t = blockIdx.x;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (threadIdx.x == 0) running = ep_base[t];
+  __syncthreads();
+  for (int64_t i0 = 0; i0 < n; i0 += 256) {
+    const int64_t i = i0 + threadIdx.x;
+    const int L = (i < n) ? (int)tail_buf[i * Tcap + t] : 0;
+    const uint64_t ballot = __ballot(L > 0);
+    const int before = (int)__popcll(ballot & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_cnt[w] = (int)__popcll(ballot);
+    __syncthreads();
+    int base = running;
+    for (int k = 0; k < w; ++k) base += wave_cnt[k];
+    if (L > 0) {
+      const int e = base + before;
+      ep_env[e] = (int)i;
+      ep_end[e] = t;
+      ep_len[e] = L;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+      running += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    __syncthreads();
+  }
+}
+
+// src[off[e] + j] = env * Tcap + (end - len + 1 + j): flat cell of packed sample.
+__global__ __launch_bounds__(256) void pack_src_index_kernel(
+    const int32_t* ep_env, const int32_t* ep_end, const int32_t* ep_len,
+    const int64_t* ep_off, int64_t n_eps, int64_t Tcap, int32_t* src) {
+  const int64_t e = blockIdx.x;
+  if (e >= n_eps) return;
+  const int L = ep_len[e];
+  const int64_t first = (int64_t)ep_env[e] * Tcap + (ep_end[e] - L + 1);
+  const int64_t off = ep_off[e];
+  for (int j = threadIdx.x; j < L; j += 256) src[off + j] = (int32_t)(first + j);
+}
+
+// dst[i, 0:width] = src[idx[i], 0:width]  (width multiple of 4, 16-B vectors)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* src,
+                                                          int64_t lds_,
+                                                          const int32_t* idx,
+                                                          int64_t rows, int width4,
+                                                          float* dst, int64_t ldd) {
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t row = g / width4;
+  const int v = (int)(g % width4);
+  if (row >= rows) return;
+  const int64_t s = idx[row];
+  const float4 x = *reinterpret_cast<const float4*>(src + s * lds_ + 4 * v);
+  *reinterpret_cast<float4*>(dst + row * ldd + 4 * v) = x;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gather_scalar_kernel(const T* src,
+                                                            const int32_t* idx,
+                                                            int64_t n, T* dst) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = src[idx[i]];
+}
+
+// per-episode undiscounted reward sums (log_performance, _functions.py:233-275)
+__global__ __launch_bounds__(256) void episode_sums_kernel(const float* rewards,
+                                                           const int64_t* ep_off,
+                                                           int64_t n_eps,
+                                                           double* sums) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n_eps) return;
+  double acc = 0.0;
+  for (int64_t j = ep_off[e]; j < ep_off[e + 1]; ++j) acc += (double)rewards[j];
+  sums[e] = acc;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// C ABI (see include/garage_amd.h)
+// ---------------------------------------------------------------------------
+struct ga_synth_env {
+  int64_t n;
+  int64_t env_id0;
+  int32_t obs_dim, act_dim, discrete, min_len, max_len;
+  uint64_t seed;
+  int32_t* episode;
+  int32_t* t;
+  int32_t* len;
+};
+
+static SynthEnv to_dev(const ga_synth_env* e) {
+  SynthEnv d;
+  d.n = e->n; d.env_id0 = e->env_id0; d.obs_dim = e->obs_dim; d.act_dim = e->act_dim;
+  d.discrete = e->discrete; d.min_len = e->min_len; d.max_len = e->max_len;
+  d.k0 = (uint32_t)(e->seed & 0xffffffffu); d.k1 = (uint32_t)(e->seed >> 32);
+  d.episode = e->episode; d.t = e->t; d.len = e->len;
+  return d;
+}
+
+static int check_env(const ga_synth_env* e, const char* who) {
+  GA_REQUIRE(e && e->episode && e->t && e->len, "%s: null env state", who);
+  GA_REQUIRE(e->n > 0 && e->obs_dim > 0 && e->act_dim > 0, "%s: bad env sizes", who);
+  GA_REQUIRE(e->min_len >= 1 && e->min_len <= e->max_len && e->max_len <= 65535,
+             "%s: episode lengths must satisfy 1 <= min <= max <= 65535", who);
+  return GA_OK;
+}
+
+extern "C" int ga_synth_env_reset(const ga_synth_env* env, const uint8_t* mask,
+                                  float* obs, int64_t ldo, hipStream_t stream) {
+  int rc = check_env(env, "ga_synth_env_reset");
+  if (rc) return rc;
+  GA_REQUIRE(obs && ldo >= env->obs_dim, "ga_synth_env_reset: bad obs buffer");
+  hipLaunchKernelGGL(synth_reset_kernel, dim3((unsigned)ga_ceil_div(env->n, 256)),
+                     dim3(256), 0, stream, to_dev(env), mask, obs, ldo);
+  GA_CHECK_LAUNCH("synth_reset");
+  return GA_OK;
+}
+
+extern "C" int ga_synth_env_step(const ga_synth_env* env, const float* actions,
+                                 int64_t lda, const float* obs, float* next_obs,
+                                 int64_t ldo, float* reward, uint8_t* step_type,
+                                 hipStream_t stream) {
+  int rc = check_env(env, "ga_synth_env_step");
+  if (rc) return rc;
+  GA_REQUIRE(actions && obs && next_obs && reward && step_type,
+             "ga_synth_env_step: null pointer");
+  GA_REQUIRE(ldo >= env->obs_dim && lda >= (env->discrete ? 1 : env->act_dim),
+             "ga_synth_env_step: leading dimensions too small");
+  hipLaunchKernelGGL(synth_step_kernel, dim3((unsigned)ga_ceil_div(env->n, 256)),
+                     dim3(256), 0, stream, to_dev(env), actions, lda, obs, next_obs,
+                     ldo, reward, step_type);
+  GA_CHECK_LAUNCH("synth_step");
+  return GA_OK;
+}
+
+struct ga_head_args {
+  int64_t n, env_id0;
+  int32_t A, kind;  // kind 0 gaussian, 1 categorical
+  const float* head; int64_t ldh;
+  const float* log_std; int32_t has_min, has_max; float min_log_std, max_log_std;
+  const float* noise; int64_t ldn;
+  uint64_t seed; uint32_t step; int32_t double_softmax;
+  const float* obs; int64_t ldo; int32_t obs_dim;
+  int64_t col, Tcap;
+  float* action; int64_t lda;
+  float* obs_buf; float* act_buf; float* head_buf;
+};
+
+extern "C" int ga_policy_head_sample(const ga_head_args* a, hipStream_t stream) {
+  GA_REQUIRE(a && a->head && a->obs && a->action && a->obs_buf && a->act_buf,
+             "ga_policy_head_sample: null pointer");
+  GA_REQUIRE(a->n > 0 && a->A > 0 && a->ldh >= a->A && a->ldo >= a->obs_dim,
+             "ga_policy_head_sample: bad sizes");
+  GA_REQUIRE(a->col >= 0 && a->col < a->Tcap, "ga_policy_head_sample: col %lld out of "
+             "range (Tcap %lld)", (long long)a->col, (long long)a->Tcap);
+  GA_REQUIRE(a->kind == 1 || (a->log_std && a->lda >= a->A),
+             "ga_policy_head_sample: gaussian head needs log_std and lda >= A");
+  HeadParams p;
+  p.n = a->n; p.env_id0 = a->env_id0; p.A = a->A; p.head = a->head; p.ldh = a->ldh;
+  p.log_std = a->log_std; p.has_min = a->has_min; p.has_max = a->has_max;
+  p.min_log_std = a->min_log_std; p.max_log_std = a->max_log_std; p.noise = a->noise;
+  p.ldn = a->ldn; p.k0 = (uint32_t)(a->seed & 0xffffffffu);
+  p.k1 = (uint32_t)(a->seed >> 32); p.step = a->step;
+  p.double_softmax = a->double_softmax; p.obs = a->obs; p.ldo = a->ldo;
+  p.obs_dim = a->obs_dim; p.col = a->col; p.Tcap = a->Tcap; p.action = a->action;
+  p.lda = a->lda; p.obs_buf = a->obs_buf; p.act_buf = a->act_buf;
+  p.head_buf = a->head_buf;
+  const dim3 grid((unsigned)ga_ceil_div(a->n, 256));
+  if (a->kind == 0)
+    hipLaunchKernelGGL(gaussian_head_kernel, grid, dim3(256), 0, stream, p);
+  else
+    hipLaunchKernelGGL(categorical_head_kernel, grid, dim3(256), 0, stream, p);
+  GA_CHECK_LAUNCH("policy_head_sample");
+  return GA_OK;
+}
+
+struct ga_record_args {
+  int64_t n, col, Tcap;
+  int32_t max_episode_length;
+  const float* reward; const uint8_t* step_type; const float* next_obs;
+  int64_t ldo; int32_t obs_dim;
+  int32_t* ep_t; float* rew_buf; uint8_t* st_buf; uint16_t* tail_buf;
+  float* lastobs_buf; uint8_t* done; int32_t* step_eps; int32_t* step_samples;
+};
+
+extern "C" int ga_record_step(const ga_record_args* a, hipStream_t stream) {
+  GA_REQUIRE(a && a->reward && a->step_type && a->next_obs && a->ep_t && a->rew_buf &&
+                 a->st_buf && a->tail_buf && a->lastobs_buf && a->done &&
+                 a->step_eps && a->step_samples,
+             "ga_record_step: null pointer");
+  GA_REQUIRE(a->n > 0 && a->col >= 0 && a->col < a->Tcap,
+             "ga_record_step: col %lld out of range (Tcap %lld)", (long long)a->col,
+             (long long)a->Tcap);
+  GA_REQUIRE(a->max_episode_length >= 1 && a->max_episode_length <= 65535,
+             "ga_record_step: max_episode_length must be in 1..65535");
+  RecordParams p;
+  p.n = a->n; p.col = a->col; p.Tcap = a->Tcap;
+  p.max_episode_length = a->max_episode_length; p.reward = a->reward;
+  p.step_type = a->step_type; p.next_obs = a->next_obs; p.ldo = a->ldo;
+  p.obs_dim = a->obs_dim; p.ep_t = a->ep_t; p.rew_buf = a->rew_buf;
+  p.st_buf = a->st_buf; p.tail_buf = a->tail_buf; p.lastobs_buf = a->lastobs_buf;
+  p.done = a->done; p.step_eps = a->step_eps; p.step_samples = a->step_samples;
+  hipLaunchKernelGGL(record_step_kernel, dim3((unsigned)ga_ceil_div(a->n, 256)),
+                     dim3(256), 0, stream, p);
+  GA_CHECK_LAUNCH("record_step");
+  return GA_OK;
+}
+
+extern "C" int ga_pack_episodes(const uint16_t* tail_buf, int64_t n, int64_t Tcap,
+                                int64_t n_steps, const int32_t* ep_base,
+                                int32_t* ep_env, int32_t* ep_end, int32_t* ep_len,
+                                hipStream_t stream) {
+  GA_REQUIRE(tail_buf && ep_base && ep_env && ep_end && ep_len,
+             "ga_pack_episodes: null pointer");
+  GA_REQUIRE(n > 0 && n_steps > 0 && n_steps <= Tcap, "ga_pack_episodes: bad sizes");
+  hipLaunchKernelGGL(pack_episodes_kernel, dim3((unsigned)n_steps), dim3(256), 0,
+                     stream, tail_buf, n, Tcap, ep_base, ep_env, ep_end, ep_len);
+  GA_CHECK_LAUNCH("pack_episodes");
+  return GA_OK;
+}
+
+extern "C" int ga_pack_src_index(const int32_t* ep_env, const int32_t* ep_end,
+                                 const int32_t* ep_len, const int64_t* ep_off,
+                                 int64_t n_eps, int64_t Tcap, int32_t* src,
+                                 hipStream_t stream) {
+  GA_REQUIRE(ep_env && ep_end && ep_len && ep_off && src,
+             "ga_pack_src_index: null pointer");
+  GA_REQUIRE(n_eps > 0 && n_eps < (1ll << 31), "ga_pack_src_index: bad n_eps");
+  hipLaunchKernelGGL(pack_src_index_kernel, dim3((unsigned)n_eps), dim3(256), 0,
+                     stream, ep_env, ep_end, ep_len, ep_off, n_eps, Tcap, src);
+  GA_CHECK_LAUNCH("pack_src_index");
+  return GA_OK;
+}
+
+extern "C" int ga_gather_rows_f32(const float* src, int64_t ld_src,
+                                  const int32_t* idx, int64_t rows, int64_t width,
+                                  float* dst, int64_t ld_dst, hipStream_t stream) {
+  GA_REQUIRE(src && idx && dst, "ga_gather_rows_f32: null pointer");
+  GA_REQUIRE(rows > 0 && width > 0 && width % 4 == 0 && ld_src % 4 == 0 &&
+                 ld_dst % 4 == 0 && ld_src >= width && ld_dst >= width,
+             "ga_gather_rows_f32: widths / strides must be multiples of 4");
+  GA_REQUIRE(ga_aligned16(src) && ga_aligned16(dst),
+             "ga_gather_rows_f32: 16-B alignment required");
+  const int w4 = (int)(width / 4);
+  hipLaunchKernelGGL(gather_rows_kernel,
+                     dim3((unsigned)ga_ceil_div(rows * w4, 256)), dim3(256), 0, stream,
+                     src, ld_src, idx, rows, w4, dst, ld_dst);
+  GA_CHECK_LAUNCH("gather_rows");
+  return GA_OK;
+}
+
+extern "C" int ga_gather_f32(const float* src, const int32_t* idx, int64_t n,
+                             float* dst, hipStream_t stream) {
+  GA_REQUIRE(src && idx && dst && n > 0, "ga_gather_f32: bad arguments");
+  hipLaunchKernelGGL(gather_scalar_kernel<float>,
+                     dim3((unsigned)ga_ceil_div(n, 256)), dim3(256), 0, stream, src,
+                     idx, n, dst);
+  GA_CHECK_LAUNCH("gather_f32");
+  return GA_OK;
+}
+
+extern "C" int ga_gather_u8(const uint8_t* src, const int32_t* idx, int64_t n,
+                            uint8_t* dst, hipStream_t stream) {
+  GA_REQUIRE(src && idx && dst && n > 0, "ga_gather_u8: bad arguments");
+  hipLaunchKernelGGL(gather_scalar_kernel<uint8_t>,
+                     dim3((unsigned)ga_ceil_div(n, 256)), dim3(256), 0, stream, src,
+                     idx, n, dst);
+  GA_CHECK_LAUNCH("gather_u8");
+  return GA_OK;
+}
+
+extern "C" int ga_episode_sums_f32(const float* rewards, const int64_t* ep_off,
+                                   int64_t n_eps, double* sums, hipStream_t stream) {
+  GA_REQUIRE(rewards && ep_off && sums && n_eps > 0, "ga_episode_sums_f32: bad args");
+  hipLaunchKernelGGL(episode_sums_kernel, dim3((unsigned)ga_ceil_div(n_eps, 256)),
+                     dim3(256), 0, stream, rewards, ep_off, n_eps, sums);
+  GA_CHECK_LAUNCH("episode_sums");
+  return GA_OK;
+}

@@ -1,0 +1,206 @@
+/* garage_amd -- C ABI of the MI355X (gfx950) on-policy rollout + PPO update engine.
+ *
+ * The reference (akolobov/garage v2021.03.0) is 100 % Python and has no FFI: its
+ * plugin surface is a set of Python classes.  This header
+ * is the boundary between that Python surface (mirrored by the `garage_amd`
+ * package) and the hand-written HIP kernels; each entry point names the
+ * reference code it replaces (paths relative to /root/reference/src/garage).
+ * INTEGRATION.md shows the ctypes binding a garage maintainer would add.
+ *
+ * Conventions
+ *   - extern "C"; plain pointers and sizes; no torch types.
+ *   - every pointer is a caller-owned DEVICE pointer unless the name ends in
+ *     `_host`; fp32 unless noted; row-major; "ld*" = floats between rows.
+ *   - matrices handed to the MLP entry points must be 16-byte aligned with
+ *     leading dimensions that are multiples of 4 floats (garage_amd pads).
+ *   - asynchronous on `stream` (a hipStream_t, passed as void*); no allocation,
+ *     no synchronisation, graph-capture safe; scratch is passed in.
+ *   - return 0 on success, <0 on error; ga_last_error() returns a thread-local
+ *     message.  Nothing throws across the boundary.
+ */
+#ifndef GARAGE_AMD_H_
+#define GARAGE_AMD_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* ga_stream_t; /* hipStream_t */
+
+int ga_abi_version(void);
+const char* ga_last_error(void);
+
+/* ---- returns + GAE(lambda) -------------------------------------------------
+ * Replaces garage.np.discount_cumsum called per padded row
+ * (np/_functions.py:111-128; call site torch/algos/vpg.py:149-153) and
+ * garage.torch.compute_advantages (torch/_functions.py:25-85) including the
+ * zero-padding semantics of short episodes.
+ *   mode 0: rows are env slices of the (n_rows, T) rollout buffer, row stride
+ *           ld; tail[i] = episode length at an episode's last step, else 0.
+ *   mode 1: every row is one episode (packed batch via offsets[n_rows+1] with
+ *           max_len = longest row, or a padded (N, P) batch with offsets = NULL).
+ * v0 = value of the all-zero observation (content of padded baselines);
+ * bonus / bonus_const = per-step / constant reward bonus added for the
+ * advantages only (entropy_method='max', vpg.py:158-160).
+ * Algorithmic HBM bytes: 16 per step. */
+int ga_gae_scan_f32(const float* rewards, const float* values, const float* bonus,
+                    const uint16_t* tail, const int64_t* offsets, int64_t n_rows,
+                    int64_t T, int64_t ld, int64_t max_len, int mode,
+                    int max_episode_length, double discount, double gae_lambda,
+                    float v0, float bonus_const, float* adv, float* ret,
+                    ga_stream_t stream);
+
+/* ---- MLP forward / backward (fp32 MFMA GEMMs) -------------------------------
+ * Replaces MLPModule / MultiHeadedMLPModule.forward
+ * (torch/modules/multi_headed_mlp_module.py:136-151) and its autograd backward
+ * as used by VPG._train_policy / _train_value_function (vpg.py:250-293).
+ * Hidden activations are tanh (the GaussianMLP* defaults,
+ * torch/policies/gaussian_mlp_policy.py:44-60). */
+typedef struct {
+  int32_t n_layers;   /* linear layers incl. the output layer, 1..8 */
+  int32_t dims[9];    /* dims[0] = input width, dims[l+1] = width of layer l */
+  int64_t w_off[8];   /* W_l [dims[l+1]][round4(dims[l])] offset (floats) in params */
+  int64_t b_off[8];   /* b_l [dims[l+1]] offset (floats) in params */
+  int64_t act_off[8]; /* hidden layer l output offset in the activation workspace,
+                         row stride round4(dims[l+1]) */
+} ga_mlp_desc;
+
+/* out[M, ldo] = MLP(X[row_idx[i]] or X[i]); acts keeps the hidden outputs. */
+int ga_mlp_forward_f32(const ga_mlp_desc* d, const float* params, const float* X,
+                       int64_t ldx, const int32_t* row_idx, int64_t M, float* acts,
+                       float* out, int64_t ldo, ga_stream_t stream);
+/* split count ga_mlp_backward_f32 should be called with for M rows */
+int64_t ga_mlp_backward_splits(const ga_mlp_desc* d, int64_t M);
+/* dout = dLoss/d(out).  Writes n_splits partial gradient slabs, each laid out
+ * like `params` (slab_stride floats apart); ga_reduce_slabs_f32 sums them. */
+int ga_mlp_backward_f32(const ga_mlp_desc* d, const float* params, const float* X,
+                        int64_t ldx, const int32_t* row_idx, int64_t M,
+                        const float* acts, const float* dout, int64_t ldo,
+                        float* dacts, float* grad_slabs, int64_t slab_stride,
+                        int64_t n_splits, ga_stream_t stream);
+/* C[M,N] = A[M,K] B[N,K]^T, exposed for tests of the GEMM core. */
+int ga_gemm_nt_f32(const float* A, int64_t lda, const float* B, int64_t ldb,
+                   float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                   ga_stream_t stream);
+
+/* ---- losses -----------------------------------------------------------------
+ * workspace: ga_reduction_workspace_doubles() doubles of device scratch. */
+int64_t ga_reduction_workspace_doubles(void);
+
+/* PPO clipped surrogate (algo 0; torch/algos/ppo.py:96-132) or VPG objective
+ * (algo 1; vpg.py:434-454) for a Gaussian policy with a scalar log-std
+ * (torch/modules/gaussian_mlp_module.py:158-192), + entropy regularisation
+ * (vpg.py:343-345,408-432; ent_flags bit0 regularized, bit1 softplus, bit2
+ * stop-gradient).  Writes loss = -mean(objective), optionally dLoss/dmean,
+ * the new log-likelihoods and dLoss/dlog_std (into slot 0 of slab 0). */
+int ga_ppo_gaussian_loss_f32(const float* mean, int64_t ldm, const float* actions,
+                             int64_t lda, const float* old_ll, const float* adv,
+                             const int32_t* idx, const float* log_std, int has_min,
+                             float min_log_std, int has_max, float max_log_std,
+                             int64_t M, int A, int algo, float clip, float ent_coeff,
+                             int ent_flags, float* dmean, float* ll_out,
+                             float* loss_out, float* grad_slab0, int64_t slab_stride,
+                             int64_t n_splits, double* workspace, ga_stream_t stream);
+/* GaussianMLPValueFunction.compute_loss
+ * (torch/value_functions/gaussian_mlp_value_function.py:81-98). */
+int ga_gaussian_nll_loss_f32(const float* v, int64_t ldv, const float* returns,
+                             const int32_t* idx, const float* log_std, int64_t M,
+                             float* dv, float* loss_out, float* grad_slab0,
+                             int64_t slab_stride, int64_t n_splits, double* workspace,
+                             ga_stream_t stream);
+/* sum over rows of KL(old || new), VPG._compute_kl_constraint (vpg.py:381-406) */
+int ga_gaussian_kl_f32(const float* mean_old, const float* mean_new, int64_t ld,
+                       int64_t M, int A, float log_std_old, float log_std_new,
+                       double* kl_sum_out, double* workspace, ga_stream_t stream);
+
+/* ---- optimiser: OptimizerWrapper.step == torch.optim.Adam.step
+ * (torch/optimizers/optimizer_wrapper.py:53-63, _functions.py:25-65) */
+int ga_reduce_slabs_f32(const float* slabs, int64_t n_splits, int64_t slab_stride,
+                        int64_t n, float scale, float* out, ga_stream_t stream);
+int ga_adam_step_f32(float* params, const float* grads, float* exp_avg,
+                     float* exp_avg_sq, int64_t n, int64_t step, double lr,
+                     double beta1, double beta2, double eps, ga_stream_t stream);
+
+/* ---- advantage centring: VPG._compute_advantage (vpg.py:371-377)
+ * stats = device double[4]: sum, count, sum of squared deviations, min.
+ * what: 0 -> stats[0..1], 1 -> stats[2] (uses the mean in stats), 2 -> stats[3]. */
+int ga_stats_f32(const float* x, int64_t n, int what, double* stats,
+                 double* workspace, ga_stream_t stream);
+int ga_adv_center_f32(float* x, int64_t n, const double* stats, float eps,
+                      ga_stream_t stream);
+int ga_sub_scalar_f32(float* x, int64_t n, const double* scalar, ga_stream_t stream);
+
+/* ---- rollout ----------------------------------------------------------------
+ * Synthetic batched environment (the benchmark workload of BASELINE.json;
+ * Environment.reset/step contract of _environment.py:237-276). */
+typedef struct {
+  int64_t n;
+  int64_t env_id0;
+  int32_t obs_dim, act_dim, discrete, min_len, max_len;
+  uint64_t seed;
+  int32_t* episode; /* [n] */
+  int32_t* t;       /* [n] */
+  int32_t* len;     /* [n] */
+} ga_synth_env;
+
+int ga_synth_env_reset(const ga_synth_env* env, const uint8_t* mask, float* obs,
+                       int64_t ldo, ga_stream_t stream);
+int ga_synth_env_step(const ga_synth_env* env, const float* actions, int64_t lda,
+                      const float* obs, float* next_obs, int64_t ldo, float* reward,
+                      uint8_t* step_type, ga_stream_t stream);
+
+/* dist.sample() of StochasticPolicy.get_actions
+ * (torch/policies/stochastic_policy.py:46-89) + the per-env list appends of
+ * VecWorker.step_episode (sampler/vec_worker.py:187-197) for observations and
+ * actions. */
+typedef struct {
+  int64_t n, env_id0;
+  int32_t A, kind; /* kind 0 gaussian, 1 categorical */
+  const float* head; int64_t ldh;
+  const float* log_std; int32_t has_min, has_max; float min_log_std, max_log_std;
+  const float* noise; int64_t ldn; /* optional teacher-forced noise */
+  uint64_t seed; uint32_t step; int32_t double_softmax;
+  const float* obs; int64_t ldo; int32_t obs_dim;
+  int64_t col, Tcap;
+  float* action; int64_t lda;
+  float* obs_buf; float* act_buf; float* head_buf;
+} ga_head_args;
+int ga_policy_head_sample(const ga_head_args* args, ga_stream_t stream);
+
+/* Reward / step-type / episode-end bookkeeping of VecWorker.step_episode and
+ * _gather_episode (sampler/vec_worker.py:139-204). */
+typedef struct {
+  int64_t n, col, Tcap;
+  int32_t max_episode_length;
+  const float* reward; const uint8_t* step_type; const float* next_obs;
+  int64_t ldo; int32_t obs_dim;
+  int32_t* ep_t; float* rew_buf; uint8_t* st_buf; uint16_t* tail_buf;
+  float* lastobs_buf; uint8_t* done; int32_t* step_eps; int32_t* step_samples;
+} ga_record_args;
+int ga_record_step(const ga_record_args* args, ga_stream_t stream);
+
+/* EpisodeBatch.concatenate in completion order (sampler/vec_worker.py:206-219,
+ * local_sampler.py:134-166; order = (completion step, env index)). */
+int ga_pack_episodes(const uint16_t* tail_buf, int64_t n, int64_t Tcap,
+                     int64_t n_steps, const int32_t* ep_base, int32_t* ep_env,
+                     int32_t* ep_end, int32_t* ep_len, ga_stream_t stream);
+int ga_pack_src_index(const int32_t* ep_env, const int32_t* ep_end,
+                      const int32_t* ep_len, const int64_t* ep_off, int64_t n_eps,
+                      int64_t Tcap, int32_t* src, ga_stream_t stream);
+int ga_gather_rows_f32(const float* src, int64_t ld_src, const int32_t* idx,
+                       int64_t rows, int64_t width, float* dst, int64_t ld_dst,
+                       ga_stream_t stream);
+int ga_gather_f32(const float* src, const int32_t* idx, int64_t n, float* dst,
+                  ga_stream_t stream);
+int ga_gather_u8(const uint8_t* src, const int32_t* idx, int64_t n, uint8_t* dst,
+                 ga_stream_t stream);
+/* undiscounted return per episode (log_performance, _functions.py:233-275) */
+int ga_episode_sums_f32(const float* rewards, const int64_t* ep_off, int64_t n_eps,
+                        double* sums, ga_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GARAGE_AMD_H_ */

@@ -1,0 +1,45 @@
+"""CPU checks of the boundary: the library loads and exports every symbol the
+header declares; the product never imports the oracle."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    text = open(os.path.join(ROOT, 'include', 'garage_amd.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(ga_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from garage_amd import _lib
+    lib = _lib.load()
+    names = _header_symbols()
+    assert len(names) >= 20
+    for name in names:
+        assert hasattr(lib, name), name
+    # the ctypes table and the header must describe the same set
+    assert sorted(_lib.SIGNATURES) == names
+    assert lib.ga_abi_version() == 1
+
+
+def test_argument_errors_are_reported_without_a_gpu():
+    from garage_amd import _lib
+    with pytest.raises(_lib.GarageAmdError) as e:
+        _lib.call('ga_gae_scan_f32', None, None, None, None, None, 1, 1, 1, 1,
+                  0, 1, 0.99, 0.97, 0.0, 0.0, None, None, None)
+    assert 'null pointer' in str(e.value)
+
+
+def test_product_never_imports_the_oracle():
+    bad = []
+    for base, _, files in os.walk(os.path.join(ROOT, 'garage_amd')):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.cpp', '.h')):
+                src = open(os.path.join(base, f)).read()
+                if re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M):
+                    bad.append(f)
+    assert not bad, bad

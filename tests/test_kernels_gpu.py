@@ -1,0 +1,367 @@
+"""Kernel-level parity: each HIP entry point against the oracle (GPU box)."""
+import ctypes as C
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    from garage_amd.engine import require_gpu
+    return require_gpu()
+
+
+def _params(g, prefix):
+    out = OrderedDict()
+    for k in g.files:
+        if k.startswith(prefix):
+            out[k[len(prefix):]] = torch.from_numpy(g[k].copy())
+    return out
+
+
+def _load_flat(mlp, params, prefix):
+    """Copy an oracle/reference param dict into a FlatMLP."""
+    for key, view in mlp.named_views():
+        view.copy_(params[prefix + key].to(view.device).reshape(view.shape))
+
+
+# ---------------------------------------------------------------------------
+def test_gae_scan_padded_matches_reference_functions(dev):
+    from garage_amd.engine import gae_scan
+    from oracle import returns as orr
+    rng = np.random.RandomState(0)
+    for (N, P, g, lam) in [(5, 6, 0.95, 0.5), (33, 256, 0.99, 0.97),
+                           (7, 300, 0.99, 0.97), (64, 128, 1.0, 1.0),
+                           (3, 1, 0.9, 0.3), (10, 1000, 0.999, 0.95)]:
+        rew = rng.randn(N, P).astype(np.float32)
+        val = rng.randn(N, P).astype(np.float32)
+        adv, ret = gae_scan(torch.from_numpy(rew).to(dev),
+                            torch.from_numpy(val).to(dev), discount=g,
+                            gae_lambda=lam, max_episode_length=P)
+        want_adv = orr.compute_advantages(g, lam, P, torch.from_numpy(val),
+                                          torch.from_numpy(rew)).numpy()
+        want_ret = np.stack([orr.discount_cumsum(r, g)
+                             for r in rew.astype(np.float64)])
+        scale = max(1.0, np.abs(want_adv).max())
+        assert np.allclose(adv.cpu().numpy(), want_adv, atol=2e-5 * scale)
+        assert np.allclose(ret.cpu().numpy(), want_ret.astype(np.float32),
+                           rtol=1e-6, atol=1e-6)
+
+
+def test_gae_scan_golden_ragged_with_v0(dev, golden):
+    """Real compute_advantages outputs on V(0)-padded ragged batches (Q2)."""
+    from garage_amd.engine import gae_scan
+    g = golden('advantages')
+    for k in range(int(g['n_ragged_cases'])):
+        rew, base, lens = (g['r%d_rewards' % k], g['r%d_base' % k],
+                           g['r%d_lens' % k])
+        d, lam, P, v0 = g['r%d_cfg' % k]
+        P = int(P)
+        vals = np.concatenate([base[i, :L] for i, L in enumerate(lens)])
+        rews = np.concatenate([rew[i, :L] for i, L in enumerate(lens)])
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        adv, ret = gae_scan(torch.from_numpy(rews).to(dev),
+                            torch.from_numpy(vals).to(dev), discount=float(d),
+                            gae_lambda=float(lam), max_episode_length=P,
+                            offsets=torch.from_numpy(off).to(dev),
+                            max_len=int(lens.max()), v0=float(v0))
+        want = np.concatenate([g['r%d_adv' % k][i, :L]
+                               for i, L in enumerate(lens)])
+        assert np.allclose(adv.cpu().numpy(), want, atol=1e-5), k
+
+
+def test_gae_scan_rollout_buffer_tails(dev):
+    """mode 0: several episodes per env row, marked by tail lengths."""
+    from garage_amd.engine import gae_scan
+    from oracle import returns as orr
+    rng = np.random.RandomState(3)
+    for (n, T, P) in [(9, 64, 16), (130, 256, 256), (4, 520, 100), (17, 36, 7)]:
+        rew = rng.randn(n, T).astype(np.float32)
+        val = rng.randn(n, T).astype(np.float32)
+        tail = np.zeros((n, T), np.uint16)
+        eps = []
+        for i in range(n):
+            t = 0
+            while True:
+                L = int(rng.randint(1, P + 1))
+                if t + L > T:
+                    break
+                tail[i, t + L - 1] = L
+                eps.append((i, t, L))
+                t += L
+        v0, bonus = 0.37, 0.11
+        adv, ret = gae_scan(torch.from_numpy(rew).to(dev),
+                            torch.from_numpy(val).to(dev), discount=0.99,
+                            gae_lambda=0.95, max_episode_length=P,
+                            tail=torch.from_numpy(tail).to(dev), v0=v0,
+                            bonus_const=bonus)
+        adv, ret = adv.cpu().numpy(), ret.cpu().numpy()
+        for (i, t, L) in eps:
+            # reference semantics on the padded row of this episode
+            r = np.zeros((1, P), np.float32)
+            b = np.full((1, P), v0, np.float32)
+            r[0, :L] = rew[i, t:t + L]
+            b[0, :L] = val[i, t:t + L]
+            want = orr.gae_padded_f64(np.float32(0.99),
+                                      float(np.float32(0.99 * 0.95)) /
+                                      float(np.float32(0.99)), b,
+                                      r + np.float32(bonus))[0, :L]
+            assert np.allclose(adv[i, t:t + L], want, atol=2e-5)
+            want_ret = orr.discount_cumsum(rew[i, t:t + L].astype(np.float64),
+                                           0.99)
+            assert np.allclose(ret[i, t:t + L], want_ret, rtol=1e-6, atol=1e-6)
+
+
+def test_gemm_nt(dev):
+    from garage_amd._lib import call, dptr, stream_ptr
+    rng = np.random.RandomState(1)
+    for (M, N, K) in [(128, 128, 32), (300, 256, 256), (1000, 6, 256),
+                      (77, 200, 20), (4096, 256, 17 + 3), (5, 3, 4)]:
+        A = rng.randn(M, K).astype(np.float32)
+        B = rng.randn(N, K).astype(np.float32)
+        a, b = torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev)
+        c = torch.zeros(M, N, device=dev)
+        call('ga_gemm_nt_f32', dptr(a), K, dptr(b), K, dptr(c), N, M, N, K,
+             stream_ptr())
+        want = A.astype(np.float64) @ B.astype(np.float64).T
+        assert np.allclose(c.cpu().numpy(), want, atol=1e-4 * np.sqrt(K)), \
+            (M, N, K)
+
+
+@pytest.mark.parametrize('tag', ['tiny', 'c2', 'c3', 'deep'])
+def test_mlp_forward_backward_vs_autograd(dev, golden, tag):
+    from garage_amd.engine import FlatMLP, pad_rows
+    from oracle import networks as nets
+    g = golden('networks')
+    pol = _params(g, tag + '_pol:')
+    hs = [int(v) for v in g[tag + '_hidden']]
+    obs = g[tag + '_obs']
+    O, A = obs.shape[1], g[tag + '_act'].shape[1]
+    mlp = FlatMLP(O, A, hs, dev)
+    _load_flat(mlp, pol, '_module.')
+    rng = np.random.RandomState(2)
+    # a larger batch so the 128/256-row tiles and split-K are exercised
+    X = np.concatenate([obs, rng.randn(1500, O).astype(np.float32)])
+    M = X.shape[0]
+    Xd = pad_rows(X)
+    out = mlp.forward(Xd, M)
+    with torch.no_grad():
+        want = nets.mlp_mean(pol, '_module.', torch.from_numpy(X))
+    assert np.allclose(out[:, :A].cpu().numpy(), want.numpy(), atol=2e-6)
+    assert np.allclose(out[:37, :A].cpu().numpy(), g[tag + '_mean'], atol=2e-6)
+    # backward of L = sum(out * G)
+    G = rng.randn(M, A).astype(np.float32)
+    params = OrderedDict((k, v.clone().requires_grad_(v.is_floating_point()
+                                                      and 'min_std' not in k))
+                         for k, v in pol.items())
+    loss = (nets.mlp_mean(params, '_module.', torch.from_numpy(X)) *
+            torch.from_numpy(G)).sum()
+    loss.backward()
+    dout = mlp.dout_view(M)
+    dout.zero_()
+    dout[:, :A] = torch.from_numpy(G).to(dev)
+    mlp.backward(Xd, M, dout)
+    mlp.reduce_grads()
+    for key, view in mlp.named_views(mlp.grads):
+        if key == '_init_std':
+            continue
+        ref = params['_module.' + key].grad.numpy()
+        got = view.cpu().numpy().reshape(ref.shape)
+        tol = 1e-5 * max(1.0, np.abs(ref).max())
+        assert np.allclose(got, ref, atol=tol), key
+
+
+def test_mlp_forward_gathered_rows(dev):
+    from garage_amd.engine import FlatMLP, pad_rows
+    rng = np.random.RandomState(5)
+    mlp = FlatMLP(17, 6, (32, 32), dev)
+    mlp.params.copy_(torch.from_numpy(
+        (rng.randn(mlp.n_flat) * 0.2).astype(np.float32)))
+    # padding columns of the weights must be zero for the layout contract
+    for l in range(3):
+        w = mlp.params[mlp.w_off[l]:mlp.b_off[l]].view(mlp.dims[l + 1], -1)
+        w[:, mlp.dims[l]:] = 0
+    X = pad_rows(rng.randn(500, 17).astype(np.float32))
+    idx = torch.from_numpy(rng.permutation(500)[:333].astype(np.int32)).to(dev)
+    a = mlp.forward(X, 333, row_idx=idx).clone()
+    b = mlp.forward(X[idx.long()].contiguous(), 333).clone()
+    assert torch.equal(a, b)
+
+
+def _ppo_oracle_loss(pol, obs, act, old_ll, adv, clip, algo='ppo', ent=None):
+    from oracle import networks as nets
+    dist = nets.gaussian_dist(pol, '_module.', obs)
+    ll = dist.log_prob(act)
+    if algo == 'vpg':
+        obj = ll * adv
+    else:
+        ratio = (ll - old_ll).exp()
+        obj = torch.min(ratio * adv,
+                        torch.clamp(ratio, 1 - clip, 1 + clip) * adv)
+    if ent is not None:
+        coeff, softplus = ent
+        e = dist.entropy()
+        if softplus:
+            e = torch.nn.functional.softplus(e)
+        obj = obj + coeff * e
+    return -obj.mean(), ll
+
+
+@pytest.mark.parametrize('case', ['fresh', 'moved', 'vpg', 'ent', 'entsp'])
+def test_ppo_gaussian_loss_and_grads(dev, golden, case):
+    from garage_amd._lib import call, dptr, stream_ptr
+    from garage_amd.engine import FlatMLP, pad_rows, reduction_workspace
+    g = golden('networks')
+    tag = 'tiny'
+    pol = _params(g, tag + '_pol:')
+    hs = [int(v) for v in g[tag + '_hidden']]
+    rng = np.random.RandomState(7)
+    M, O, A = 700, 4, 2
+    obs = torch.from_numpy(rng.randn(M, O).astype(np.float32))
+    act = torch.from_numpy(rng.randn(M, A).astype(np.float32))
+    adv = torch.from_numpy(rng.randn(M).astype(np.float32))
+    params = OrderedDict((k, v.clone().requires_grad_('min_std' not in k))
+                         for k, v in pol.items())
+    from oracle import networks as nets
+    with torch.no_grad():
+        old_ll = nets.gaussian_dist(pol, '_module.', obs).log_prob(act)
+    if case != 'fresh':
+        # old policy differs: ratios leave the clip range for many samples
+        old_ll = old_ll + torch.from_numpy(
+            (rng.randn(M) * 0.3).astype(np.float32))
+    algo = 'vpg' if case == 'vpg' else 'ppo'
+    ent = {'ent': (0.02, False), 'entsp': (0.02, True)}.get(case)
+    loss, ll = _ppo_oracle_loss(params, obs, act, old_ll, adv, 0.2, algo, ent)
+    loss.backward()
+
+    mlp = FlatMLP(O, A, hs, dev)
+    _load_flat(mlp, pol, '_module.')
+    X = pad_rows(obs)
+    actd, advd, olld = pad_rows(act), adv.to(dev), old_ll.to(dev)
+    mean = mlp.forward(X, M)
+    dout = mlp.dout_view(M)
+    ll_out = torch.empty(M, device=dev)
+    loss_out = torch.zeros(1, device=dev)
+    ws = reduction_workspace(dev)
+    flags = 0
+    if ent is not None:
+        flags = 1 | (2 if ent[1] else 0)
+    min_ls = float(pol['_module.min_std_param'])
+    mlp._workspace(M)
+    splits = int(mlp._splits)
+    call('ga_ppo_gaussian_loss_f32', dptr(mean), mean.stride(0), dptr(actd),
+         actd.stride(0), dptr(olld), dptr(advd), None, dptr(mlp.log_std), 1,
+         min_ls, 0, 0.0, M, A, 1 if algo == 'vpg' else 0, 0.2,
+         ent[0] if ent else 0.0, flags, dptr(dout), dptr(ll_out),
+         dptr(loss_out), dptr(mlp._slabs), mlp.n_flat, splits, dptr(ws),
+         stream_ptr())
+    used = mlp.backward(X, M, dout)
+    mlp.reduce_grads()
+    assert np.isclose(loss_out.item(), loss.item(), atol=1e-6, rtol=1e-5)
+    assert np.allclose(ll_out.cpu().numpy(), ll.detach().numpy(), atol=1e-5)
+    for key, view in mlp.named_views(mlp.grads):
+        ref = params['_module.' + key].grad.numpy()
+        got = view.cpu().numpy().reshape(ref.shape)
+        assert np.allclose(got, ref, atol=2e-6 + 1e-4 * np.abs(ref).max()), key
+
+
+def test_value_nll_loss_and_grads(dev, golden):
+    from garage_amd._lib import call, dptr, stream_ptr
+    from garage_amd.engine import FlatMLP, pad_rows, reduction_workspace
+    from oracle import networks as nets
+    g = golden('networks')
+    vf = _params(g, 'tiny_vf:')
+    rng = np.random.RandomState(8)
+    M, O = 513, 4
+    obs = torch.from_numpy(rng.randn(M, O).astype(np.float32))
+    ret = torch.from_numpy(rng.randn(M).astype(np.float32))
+    params = OrderedDict((k, v.clone().requires_grad_(True))
+                         for k, v in vf.items())
+    loss = nets.value_loss(params, obs, ret)
+    loss.backward()
+    mlp = FlatMLP(O, 1, [8, 8], dev)
+    _load_flat(mlp, vf, 'module.')
+    X = pad_rows(obs)
+    v = mlp.forward(X, M)
+    assert np.allclose(v[:, 0].cpu().numpy(),
+                       nets.value_forward(vf, obs).detach().numpy(), atol=1e-6)
+    dout = mlp.dout_view(M)
+    dout.zero_()
+    loss_out = torch.zeros(1, device=dev)
+    ws = reduction_workspace(dev)
+    call('ga_gaussian_nll_loss_f32', dptr(v), v.stride(0), dptr(ret.to(dev)),
+         None, dptr(mlp.log_std), M, dptr(dout), dptr(loss_out),
+         dptr(mlp._slabs), mlp.n_flat, int(mlp._splits), dptr(ws),
+         stream_ptr())
+    mlp.backward(X, M, dout)
+    mlp.reduce_grads()
+    assert np.isclose(loss_out.item(), loss.item(), atol=1e-6, rtol=1e-5)
+    for key, view in mlp.named_views(mlp.grads):
+        ref = params['module.' + key].grad.numpy()
+        got = view.cpu().numpy().reshape(ref.shape)
+        assert np.allclose(got, ref, atol=2e-6 + 1e-4 * np.abs(ref).max()), key
+
+
+def test_adam_matches_torch(dev):
+    from garage_amd.engine import FlatMLP
+    rng = np.random.RandomState(9)
+    mlp = FlatMLP(5, 3, (16, ), dev)
+    p0 = (rng.randn(mlp.n_flat) * 0.3).astype(np.float32)
+    mlp.params.copy_(torch.from_numpy(p0))
+    ref = torch.from_numpy(p0.copy()).requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=2.5e-4)
+    for step in range(5):
+        gnp = rng.randn(mlp.n_flat).astype(np.float32)
+        mlp.grads.copy_(torch.from_numpy(gnp))
+        mlp.adam_step(2.5e-4)
+        ref.grad = torch.from_numpy(gnp.copy())
+        opt.step()
+        assert np.allclose(mlp.params.cpu().numpy(), ref.detach().numpy(),
+                           atol=1e-7, rtol=1e-6), step
+    st = opt.state[ref]
+    assert np.allclose(mlp.exp_avg.cpu().numpy(), st['exp_avg'].numpy(),
+                       atol=1e-8, rtol=1e-6)
+    assert np.allclose(mlp.exp_avg_sq.cpu().numpy(), st['exp_avg_sq'].numpy(),
+                       atol=1e-10, rtol=1e-6)
+
+
+def test_center_advantages(dev, golden):
+    from garage_amd.engine import center_advantages
+    rng = np.random.RandomState(10)
+    x = (rng.randn(100003) * 3 + 1).astype(np.float32)
+    for center, positive in [(True, False), (True, True), (False, True)]:
+        t = torch.from_numpy(x.copy())
+        want = t.clone()
+        if center:
+            want = (want - want.mean()) / (want.var() + 1e-8)
+        if positive:
+            want = want - want.min()
+        got = center_advantages(t.to(dev), center=center, positive=positive)
+        assert np.allclose(got.cpu().numpy(), want.numpy(), atol=1e-5,
+                           rtol=1e-5)
+    one = center_advantages(torch.tensor([1.5], device=dev))
+    assert torch.isnan(one).all()  # var of one element: NaN, as in the reference
+
+
+def test_gaussian_kl(dev):
+    from garage_amd._lib import call, dptr, stream_ptr
+    from garage_amd.engine import reduction_workspace
+    from torch.distributions import Independent, Normal, kl_divergence
+    rng = np.random.RandomState(11)
+    M, A = 1234, 6
+    m0 = torch.from_numpy(rng.randn(M, A).astype(np.float32))
+    m1 = m0 + torch.from_numpy((rng.randn(M, A) * 0.1).astype(np.float32))
+    s0, s1 = 0.05, -0.12
+    want = kl_divergence(
+        Independent(Normal(m0, torch.full_like(m0, s0).exp()), 1),
+        Independent(Normal(m1, torch.full_like(m1, s1).exp()), 1)).sum().item()
+    from garage_amd.engine import pad_rows
+    a, b = pad_rows(m0), pad_rows(m1)
+    out = torch.zeros(1, dtype=torch.float64, device=dev)
+    call('ga_gaussian_kl_f32', dptr(a), dptr(b), a.stride(0), M, A, s0, s1,
+         dptr(out), dptr(reduction_workspace(dev)), stream_ptr())
+    assert np.isclose(out.item(), want, rtol=1e-5)
