@@ -93,6 +93,7 @@ SIGNATURES = {
                                    ptr]),
     'ga_gather_f32': (c_int, [ptr, ptr, c_i64, ptr, ptr]),
     'ga_gather_u8': (c_int, [ptr, ptr, c_i64, ptr, ptr]),
+    'ga_permutation_i32': (c_int, [c_i64, c_u64, ptr, ptr]),
     'ga_episode_sums_f32': (c_int, [ptr, ptr, c_i64, ptr, ptr]),
 }
 

@@ -1,0 +1,478 @@
+"""VPG and PPO with garage's ``RLAlgorithm`` surface, device resident.
+
+Mirrors ``garage.torch.algos.VPG`` / ``PPO`` (``torch/algos/vpg.py:17-455``,
+``torch/algos/ppo.py:8-132``): same constructor keywords and defaults, the same
+private method names (``_train_once``, ``_compute_advantage``, ``_train``,
+``_train_policy``, ``_train_value_function`` ...), the same order of operations
+inside an iteration and the same nine logged scalars.  One iteration never
+leaves the GPU except for the episode lengths and the logged scalars.
+"""
+import collections
+import math
+
+import numpy as np
+import torch
+
+from garage_amd import logger
+from garage_amd._dtypes import DeviceEpisodeBatch, StepType, is_discrete
+from garage_amd._lib import call, dptr, stream_ptr
+from garage_amd.engine import (HALF_LOG_2PI, center_advantages, gae_scan,
+                               pad_rows, reduction_workspace, round4)
+from garage_amd.optimizers import OptimizerWrapper
+from garage_amd.policies import GaussianMLPPolicy
+
+
+class _OldPolicy:
+    """Parameter snapshot standing in for ``copy.deepcopy(policy)`` (vpg.py:107)."""
+
+    def __init__(self, policy):
+        self.params = policy.net.params.clone()
+
+    def sync(self, policy):
+        self.params.copy_(policy.net.params)
+
+
+class VPG:
+    """Vanilla Policy Gradient (``torch/algos/vpg.py:17-455``)."""
+
+    def __init__(self,
+                 env_spec,
+                 policy,
+                 value_function,
+                 sampler,
+                 policy_optimizer=None,
+                 vf_optimizer=None,
+                 num_train_per_epoch=1,
+                 discount=0.99,
+                 gae_lambda=1,
+                 center_adv=True,
+                 positive_adv=False,
+                 policy_ent_coeff=0.0,
+                 use_softplus_entropy=False,
+                 stop_entropy_gradient=False,
+                 entropy_method='no_entropy'):
+        self._discount = discount
+        self.policy = policy
+        self.max_episode_length = env_spec.max_episode_length
+        self._value_function = value_function
+        self._gae_lambda = gae_lambda
+        self._center_adv = center_adv
+        self._positive_adv = positive_adv
+        self._policy_ent_coeff = policy_ent_coeff
+        self._use_softplus_entropy = use_softplus_entropy
+        self._stop_entropy_gradient = stop_entropy_gradient
+        self._entropy_method = entropy_method
+        self._n_samples = num_train_per_epoch
+        self._env_spec = env_spec
+        self._maximum_entropy = (entropy_method == 'max')
+        self._entropy_regularzied = (entropy_method == 'regularized')
+        self._check_entropy_configuration(entropy_method, center_adv,
+                                          stop_entropy_gradient,
+                                          policy_ent_coeff)
+        self._episode_reward_mean = collections.deque(maxlen=100)
+        self._sampler = sampler
+        if not isinstance(policy, GaussianMLPPolicy):
+            raise NotImplementedError(
+                'garage_amd.algos supports GaussianMLPPolicy in this round')
+        self._policy_optimizer = policy_optimizer or OptimizerWrapper(
+            torch.optim.Adam, policy)
+        self._vf_optimizer = vf_optimizer or OptimizerWrapper(
+            torch.optim.Adam, value_function)
+        self._old_policy = _OldPolicy(policy)
+        self._algo_id = 1  # VPG objective in the loss kernel
+        self._lr_clip_range = 0.0
+        self._comm = None  # set by garage_amd.distributed.shard_algo
+        self.last_tabular = {}
+
+    @staticmethod
+    def _check_entropy_configuration(entropy_method, center_adv,
+                                     stop_entropy_gradient, policy_ent_coeff):
+        """``vpg.py:109-125``."""
+        if entropy_method not in ('max', 'regularized', 'no_entropy'):
+            raise ValueError('Invalid entropy_method')
+        if entropy_method == 'max':
+            if center_adv:
+                raise ValueError('center_adv should be False when '
+                                 'entropy_method is max')
+            if not stop_entropy_gradient:
+                raise ValueError('stop_gradient should be True when '
+                                 'entropy_method is max')
+        if entropy_method == 'no_entropy':
+            if policy_ent_coeff != 0.0:
+                raise ValueError('policy_ent_coeff should be zero '
+                                 'when there is no entropy method')
+
+    @property
+    def discount(self):
+        return self._discount
+
+    # -- helpers --------------------------------------------------------------
+    def _to_device_batch(self, eps):
+        """Accept any EpisodeBatch-like; upload host arrays when needed."""
+        if isinstance(eps, DeviceEpisodeBatch):
+            return eps
+        dev = self.policy.device
+        lengths = np.asarray(eps.lengths).astype(np.int64)
+        off = np.concatenate([[0], np.cumsum(lengths)])
+        S = int(off[-1])
+        obs = np.asarray(eps.observations, dtype=np.float32).reshape(S, -1)
+        acts = np.asarray(eps.actions, dtype=np.float32).reshape(S, -1)
+        last = np.asarray(eps.last_observations,
+                          dtype=np.float32).reshape(len(lengths), -1)
+        st = np.asarray([int(s) for s in eps.step_types], dtype=np.uint8)
+        return DeviceEpisodeBatch(
+            eps.env_spec, lengths=lengths, obs_dev=pad_rows(obs),
+            last_obs_dev=pad_rows(last), actions_dev=pad_rows(acts),
+            rewards_dev=torch.from_numpy(
+                np.asarray(eps.rewards, dtype=np.float32)).to(dev),
+            step_types_dev=torch.from_numpy(st).to(dev),
+            ep_off_dev=torch.from_numpy(off).to(dev),
+            discrete=is_discrete(eps.env_spec.action_space))
+
+    def _entropy_value(self):
+        """Entropy of the Gaussian policy: state independent (scalar log-std).
+
+        ``Independent(Normal).entropy() = A * (0.5 + 0.5 log 2pi + log_std)``,
+        optionally through softplus (``vpg.py:408-432``).
+        """
+        A = self.policy.net.out_dim
+        s = np.float32(self.policy.clamped_log_std())
+        ent = np.float32(A) * (np.float32(0.5) + np.float32(HALF_LOG_2PI) + s)
+        if self._use_softplus_entropy:
+            ent = np.float32(ent if ent > 20 else math.log1p(math.exp(ent)))
+        return float(ent)
+
+    def _ent_flags(self):
+        return (int(self._entropy_regularzied) |
+                (int(self._use_softplus_entropy) << 1) |
+                (int(self._stop_entropy_gradient) << 2))
+
+    def _policy_loss_pass(self, batch, adv, old_ll, M, idx, params=None,
+                          want_grad=False, ll_out=None):
+        """Forward + fused loss (+ gradient seed) over ``M`` rows."""
+        pol = self.policy
+        net = pol.net
+        saved = None
+        if params is not None:  # evaluate with the old policy's parameters
+            saved, net.params = net.params, params
+        try:
+            mean = net.forward(batch.obs_dev, M, row_idx=idx)
+            dout = net.dout_view(M) if want_grad else None
+            loss = torch.empty(1, dtype=torch.float32, device=net.device)
+            has_min, mn, has_max, mx = pol._std_args()
+            call('ga_ppo_gaussian_loss_f32', dptr(mean), mean.stride(0),
+                 dptr(batch.actions_dev), batch.actions_dev.stride(0),
+                 dptr(old_ll), dptr(adv), dptr(idx), dptr(net.params[0:1]),
+                 has_min, mn, has_max, mx, M, net.out_dim,
+                 self._algo_id if old_ll is not None else 1,
+                 float(self._lr_clip_range), float(self._policy_ent_coeff),
+                 self._ent_flags(), dptr(dout), dptr(ll_out), dptr(loss),
+                 dptr(net._slabs) if want_grad else None, net.n_flat,
+                 int(net._splits) if want_grad else 0,
+                 dptr(reduction_workspace(net.device)), stream_ptr())
+        finally:
+            if saved is not None:
+                net.params = saved
+        return loss, mean, dout
+
+    def _value_loss_pass(self, batch, returns, M, idx, want_grad=False):
+        vf = self._value_function
+        net = vf.net
+        v = net.forward(batch.obs_dev, M, row_idx=idx)
+        dout = net.dout_view(M) if want_grad else None
+        loss = torch.empty(1, dtype=torch.float32, device=net.device)
+        call('ga_gaussian_nll_loss_f32', dptr(v), v.stride(0), dptr(returns),
+             dptr(idx), dptr(net.params[0:1]), M, dptr(dout), dptr(loss),
+             dptr(net._slabs) if want_grad else None, net.n_flat,
+             int(net._splits) if want_grad else 0,
+             dptr(reduction_workspace(net.device)), stream_ptr())
+        return loss, v, dout
+
+    def _kl_sum(self, mean_old, s_old, mean_new, s_new, M):
+        out = torch.zeros(1, dtype=torch.float64, device=mean_old.device)
+        call('ga_gaussian_kl_f32', dptr(mean_old), dptr(mean_new),
+             mean_old.stride(0), M, self.policy.net.out_dim, float(s_old),
+             float(s_new), dptr(out), dptr(reduction_workspace(out.device)),
+             stream_ptr())
+        return out
+
+    def _allreduce(self, tensor, op='sum'):
+        if self._comm is not None:
+            self._comm.all_reduce(tensor, op)
+
+    def _padded_cells(self, lengths):
+        """N * P of the reference's padded tensors (pad_batch_array widening)."""
+        P = self.max_episode_length
+        longest = int(lengths.max())
+        P = longest if P is None else max(int(P), longest)
+        return len(lengths) * P, P
+
+    # -- one iteration (vpg.py:136-206) -----------------------------------------
+    def _train_once(self, itr, eps):
+        batch = self._to_device_batch(eps)
+        pol, vf = self.policy, self._value_function
+        dev = pol.device
+        S = batch.n_samples
+        lengths = batch.lengths
+        n_cells, P = self._padded_cells(lengths)
+        n_pad = n_cells - S
+        pol.net._workspace(S)
+        vf.net._workspace(S)
+        zero_obs = torch.zeros(1, batch.obs_dev.shape[1], device=dev)
+
+        # baselines on every valid step and on the all-zero observation the
+        # reference feeds through the padding (vpg.py:147,155-156; Q2)
+        values = torch.empty(S, 1, dtype=torch.float32, device=dev)
+        vf.net.forward(batch.obs_dev, S, out=values)
+        v0 = float(vf.net.forward(zero_obs, 1)[0, 0].item())
+
+        bonus = 0.0
+        if self._maximum_entropy:  # vpg.py:158-160, padded cells included
+            bonus = self._policy_ent_coeff * self._entropy_value()
+        adv, returns = gae_scan(
+            batch.rewards_dev, values.view(-1), discount=self._discount,
+            gae_lambda=self._gae_lambda, max_episode_length=P,
+            offsets=batch.ep_off_dev, max_len=int(lengths.max()), v0=v0,
+            bonus_const=bonus)
+        self._normalise_advantages(adv)
+
+        # ---- diagnostics before the update (vpg.py:168-173) -----------------
+        s_old = self._clamped(self._old_policy.params)
+        old_ll = torch.empty(S, dtype=torch.float32, device=dev)
+        _, mean_old, _ = self._policy_loss_pass(
+            batch, adv, None, S, None, params=self._old_policy.params,
+            ll_out=old_ll)
+        mean_old = mean_old.clone()
+        saved = pol.net.params
+        pol.net.params = self._old_policy.params
+        mean_old_pad = pol.net.forward(zero_obs, 1).clone()
+        pol.net.params = saved
+        loss_before, mean_new, _ = self._policy_loss_pass(
+            batch, adv, old_ll, S, None)
+        kl_before = self._mean_kl(mean_old, mean_old_pad, s_old, mean_new,
+                                  zero_obs, S, n_pad, n_cells)
+        vf_before, _, _ = self._value_loss_pass(batch, returns, S, None)
+
+        self._train(batch, adv, returns, old_ll)
+
+        # ---- diagnostics after the update (vpg.py:178-184) -------------------
+        loss_after, mean_new, _ = self._policy_loss_pass(
+            batch, adv, old_ll, S, None)
+        kl_after = self._mean_kl(mean_old, mean_old_pad, s_old, mean_new,
+                                 zero_obs, S, n_pad, n_cells)
+        vf_after, _, _ = self._value_loss_pass(batch, returns, S, None)
+        entropy = self._entropy_value()
+
+        scalars = torch.stack([loss_before[0], loss_after[0], vf_before[0],
+                               vf_after[0]]).to(torch.float64)
+        scalars = torch.cat([scalars, kl_before, kl_after])
+        if self._comm is not None:
+            self._allreduce(scalars, 'sum')
+            scalars = scalars / self._comm.world_size
+        pl_b, pl_a, vl_b, vl_a, kl_b, kl_a = scalars.cpu().tolist()
+        tab = logger.tabular
+        with tab.prefix(self.policy.name):
+            tab.record('/LossBefore', pl_b)
+            tab.record('/LossAfter', pl_a)
+            tab.record('/dLoss', pl_b - pl_a)
+            tab.record('/KLBefore', kl_b)
+            tab.record('/KL', kl_a)
+            tab.record('/Entropy', entropy)
+        with tab.prefix(self._value_function.name):
+            tab.record('/LossBefore', vl_b)
+            tab.record('/LossAfter', vl_a)
+            tab.record('/dLoss', vl_b - vl_a)
+        self.last_tabular = {
+            'policy/LossBefore': pl_b, 'policy/LossAfter': pl_a,
+            'policy/dLoss': pl_b - pl_a, 'policy/KLBefore': kl_b,
+            'policy/KL': kl_a, 'policy/Entropy': entropy,
+            'vf/LossBefore': vl_b, 'vf/LossAfter': vl_a,
+            'vf/dLoss': vl_b - vl_a,
+        }
+        self.last_tensors = {'advantages': adv, 'returns': returns,
+                             'values': values.view(-1), 'v0': v0}
+
+        self._old_policy.sync(self.policy)  # vpg.py:201
+        undiscounted = self._log_performance(itr, batch, returns)
+        return np.mean(undiscounted)
+
+    def _clamped(self, params):
+        s = float(params[0].item())
+        pol = self.policy
+        if pol._min_log_std is not None:
+            s = max(s, pol._min_log_std)
+        if pol._max_log_std is not None:
+            s = min(s, pol._max_log_std)
+        return s
+
+    def _mean_kl(self, mean_old, mean_old_pad, s_old, mean_new, zero_obs, S,
+                 n_pad, n_cells):
+        """``vpg.py:381-406`` over the padded (N, P) grid (Q9): valid rows from
+        the device sum, padded rows (all identical) in closed form."""
+        s_new = self.policy.clamped_log_std()
+        total = self._kl_sum(mean_old, s_old, mean_new, s_new, S)
+        if n_pad > 0:
+            new_pad = self.policy.net.forward(zero_obs, 1).clone()
+            total = total + n_pad * self._kl_sum(mean_old_pad, s_old, new_pad,
+                                                 s_new, 1)
+        if self._comm is not None:
+            cells = torch.tensor([float(n_cells)], dtype=torch.float64,
+                                 device=total.device)
+            self._allreduce(total, 'sum')
+            self._allreduce(cells, 'sum')
+            # every rank divides by the global cell count; the later scalar
+            # average over ranks is undone by multiplying with world_size
+            return total / cells * self._comm.world_size
+        return total / n_cells
+
+    def _normalise_advantages(self, adv):
+        """``vpg.py:371-377`` (global moments when the batch is sharded)."""
+        hook = None
+        if self._comm is not None:
+            hook = self._allreduce
+        center_advantages(adv, center=self._center_adv,
+                          positive=self._positive_adv, allreduce=hook)
+
+    def _compute_advantage(self, rewards, valids, baselines):
+        """``vpg.py:349-379`` on padded ``(N, P)`` device tensors -> packed."""
+        rewards = torch.as_tensor(rewards).to(self.policy.device,
+                                              torch.float32).contiguous()
+        baselines = torch.as_tensor(baselines).to(self.policy.device,
+                                                  torch.float32).contiguous()
+        adv, _ = gae_scan(rewards, baselines, discount=self._discount,
+                          gae_lambda=self._gae_lambda,
+                          max_episode_length=rewards.shape[1])
+        flat = torch.cat([adv[i, :int(v)] for i, v in enumerate(valids)])
+        self._normalise_advantages(flat)
+        return flat
+
+    # -- the update (vpg.py:230-293) -------------------------------------------
+    def _train(self, batch, adv, returns, old_ll):
+        S = batch.n_samples
+        for idx in self._policy_optimizer.minibatch_indices(S):
+            self._train_policy(batch, adv, old_ll, idx)
+        for idx in self._vf_optimizer.minibatch_indices(S):
+            self._train_value_function(batch, returns, idx)
+
+    def _train_policy(self, batch, adv, old_ll, idx):
+        M = batch.n_samples if idx is None else int(idx.numel())
+        net = self.policy.net
+        loss, _, dout = self._policy_loss_pass(batch, adv, old_ll, M, idx,
+                                               want_grad=True)
+        net.backward(batch.obs_dev, M, dout, row_idx=idx)
+        self._policy_optimizer.step()
+        return loss
+
+    def _train_value_function(self, batch, returns, idx):
+        M = batch.n_samples if idx is None else int(idx.numel())
+        net = self._value_function.net
+        loss, _, dout = self._value_loss_pass(batch, returns, M, idx,
+                                              want_grad=True)
+        net.backward(batch.obs_dev, M, dout, row_idx=idx)
+        self._vf_optimizer.step()
+        return loss
+
+    # -- log_performance (_functions.py:233-275) --------------------------------
+    def _log_performance(self, itr, batch, returns):
+        dev = returns.device
+        off = batch.ep_off_dev
+        N = len(batch.lengths)
+        sums = torch.empty(N, dtype=torch.float64, device=dev)
+        call('ga_episode_sums_f32', dptr(batch.rewards_dev), dptr(off), N,
+             dptr(sums), stream_ptr())
+        first = returns[off[:-1]].to(torch.float64)
+        last_st = batch.step_types_dev[off[1:] - 1]
+        host = torch.cat([sums, first,
+                          (last_st == int(StepType.TERMINAL)).to(
+                              torch.float64)]).cpu().numpy()
+        undiscounted, discounted, term = host[:N], host[N:2 * N], host[2 * N:]
+        tab = logger.tabular
+        with tab.prefix('Evaluation/'):
+            tab.record('Iteration', itr)
+            tab.record('NumEpisodes', N)
+            tab.record('AverageDiscountedReturn', np.mean(discounted))
+            tab.record('AverageReturn', np.mean(undiscounted))
+            tab.record('StdReturn', np.std(undiscounted))
+            tab.record('MaxReturn', np.max(undiscounted))
+            tab.record('MinReturn', np.min(undiscounted))
+            tab.record('TerminationRate', np.mean(term))
+        self.last_performance = {
+            'NumEpisodes': N,
+            'AverageDiscountedReturn': float(np.mean(discounted)),
+            'AverageReturn': float(np.mean(undiscounted)),
+            'StdReturn': float(np.std(undiscounted)),
+            'MaxReturn': float(np.max(undiscounted)),
+            'MinReturn': float(np.min(undiscounted)),
+            'TerminationRate': float(np.mean(term)),
+        }
+        return list(undiscounted)
+
+    def train(self, trainer):
+        """``vpg.py:208-228``."""
+        last_return = None
+        for _ in trainer.step_epochs():
+            for _ in range(self._n_samples):
+                eps = trainer.obtain_episodes(trainer.step_itr)
+                last_return = self._train_once(trainer.step_itr, eps)
+                trainer.step_itr += 1
+        return last_return
+
+    # -- snapshots: the sampler's workers are rebuilt on load ---------------------
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state['_old_policy'] = self._old_policy.params.cpu().numpy()
+        state.pop('last_tensors', None)
+        state['_comm'] = None
+        return state
+
+    def __setstate__(self, state):
+        old = state.pop('_old_policy')
+        self.__dict__.update(state)
+        self._old_policy = _OldPolicy(self.policy)
+        self._old_policy.params.copy_(torch.from_numpy(old))
+
+
+class PPO(VPG):
+    """Proximal Policy Optimization (``torch/algos/ppo.py:8-132``)."""
+
+    def __init__(self,
+                 env_spec,
+                 policy,
+                 value_function,
+                 sampler,
+                 policy_optimizer=None,
+                 vf_optimizer=None,
+                 lr_clip_range=2e-1,
+                 num_train_per_epoch=1,
+                 discount=0.99,
+                 gae_lambda=0.97,
+                 center_adv=True,
+                 positive_adv=False,
+                 policy_ent_coeff=0.0,
+                 use_softplus_entropy=False,
+                 stop_entropy_gradient=False,
+                 entropy_method='no_entropy'):
+        if policy_optimizer is None:
+            policy_optimizer = OptimizerWrapper(
+                (torch.optim.Adam, dict(lr=2.5e-4)), policy,
+                max_optimization_epochs=10, minibatch_size=64)
+        if vf_optimizer is None:
+            vf_optimizer = OptimizerWrapper(
+                (torch.optim.Adam, dict(lr=2.5e-4)), value_function,
+                max_optimization_epochs=10, minibatch_size=64)
+        super().__init__(env_spec=env_spec, policy=policy,
+                         value_function=value_function, sampler=sampler,
+                         policy_optimizer=policy_optimizer,
+                         vf_optimizer=vf_optimizer,
+                         num_train_per_epoch=num_train_per_epoch,
+                         discount=discount, gae_lambda=gae_lambda,
+                         center_adv=center_adv, positive_adv=positive_adv,
+                         policy_ent_coeff=policy_ent_coeff,
+                         use_softplus_entropy=use_softplus_entropy,
+                         stop_entropy_gradient=stop_entropy_gradient,
+                         entropy_method=entropy_method)
+        self._lr_clip_range = lr_clip_range
+        self._algo_id = 0  # clipped surrogate in the loss kernel
+
+
+__all__ = ['VPG', 'PPO']

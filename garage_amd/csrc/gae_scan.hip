@@ -87,6 +87,9 @@ __global__ __launch_bounds__(256) void gae_scan_kernel(ScanParams p) {
       len = p.T;
     }
   }
+  // 16-B accesses need the row to start on a 4-float boundary (always true for
+  // the padded layout, true for packed batches of fixed-length episodes).
+  const bool vec_row = (start & 3) == 0;
   const int C = 4 * lpr;
   int nchunks = (int)((len + C - 1) / C);
   int maxchunks = nchunks;
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(256) void gae_scan_kernel(ScanParams p) {
     float b[4] = {0.f, 0.f, 0.f, 0.f};
     int tl[4] = {0, 0, 0, 0};
     const bool full = active && (i0 + 3 < len);
-    if (VEC && full) {
+    if (VEC && vec_row && full) {
       const float4 r4 = *reinterpret_cast<const float4*>(p.rew + start + i0);
       const float4 v4 = *reinterpret_cast<const float4*>(p.val + start + i0);
       r[0] = r4.x; r[1] = r4.y; r[2] = r4.z; r[3] = r4.w;
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(256) void gae_scan_kernel(ScanParams p) {
       oa[j] = (float)ya;
       og[j] = (float)yg;
     }
-    if (VEC && full) {
+    if (VEC && vec_row && full) {
       *reinterpret_cast<float4*>(p.adv + start + i0) =
           make_float4(oa[0], oa[1], oa[2], oa[3]);
       *reinterpret_cast<float4*>(p.ret + start + i0) =
@@ -268,7 +271,7 @@ extern "C" int ga_gae_scan_f32(const float* rewards, const float* values,
   const int64_t waves = ga_ceil_div(n_rows, rows_per_wave);
   const int64_t blocks = ga_ceil_div(waves, 4);
   GA_REQUIRE(blocks < (1ll << 31), "ga_gae_scan_f32: grid too large");
-  const bool vec = !offsets && (ld % 4 == 0) && ga_aligned16(rewards) &&
+  const bool vec = (offsets || ld % 4 == 0) && ga_aligned16(rewards) &&
                    ga_aligned16(values) && ga_aligned16(adv) && ga_aligned16(ret) &&
                    (!bonus || ga_aligned16(bonus)) &&
                    (!tail || (reinterpret_cast<uintptr_t>(tail) & 7u) == 0);

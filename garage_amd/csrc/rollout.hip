@@ -368,6 +368,40 @@ __global__ __launch_bounds__(256) void episode_sums_kernel(const float* rewards,
   sums[e] = acc;
 }
 
+
+// ---- keyed pseudo-random permutation of [0, n) --------------------------------
+// BatchDataset (np/optimizers/minibatch_dataset.py:4-35) shuffles ids on the host
+// with the global numpy RNG; the throughput mode replaces that by a 4-round
+// Feistel network over 2h bits with cycle walking: out[i] = PRP_key(i), computed
+// independently per element (no sort, no host round trip).
+__device__ __forceinline__ uint32_t feistel_f(uint32_t x, uint32_t k) {
+  x ^= k;
+  x *= 0x9E3779B1u; x ^= x >> 15;
+  x *= 0x85EBCA77u; x ^= x >> 13;
+  x *= 0xC2B2AE3Du; x ^= x >> 16;
+  return x;
+}
+
+__global__ __launch_bounds__(256) void feistel_perm_kernel(int64_t n, int half_bits,
+                                                           uint32_t k0, uint32_t k1,
+                                                           int32_t* out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t mask = (1u << half_bits) - 1u;
+  uint32_t x = (uint32_t)i;
+  do {
+    uint32_t L = x >> half_bits, R = x & mask;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t t = L ^ (feistel_f(R, k0 + 0x9E3779B9u * r + (k1 ^ r)) & mask);
+      L = R;
+      R = t;
+    }
+    x = (L << half_bits) | R;
+  } while ((int64_t)x >= n);
+  out[i] = (int32_t)x;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -570,5 +604,17 @@ extern "C" int ga_episode_sums_f32(const float* rewards, const int64_t* ep_off,
   hipLaunchKernelGGL(episode_sums_kernel, dim3((unsigned)ga_ceil_div(n_eps, 256)),
                      dim3(256), 0, stream, rewards, ep_off, n_eps, sums);
   GA_CHECK_LAUNCH("episode_sums");
+  return GA_OK;
+}
+
+extern "C" int ga_permutation_i32(int64_t n, uint64_t key, int32_t* out,
+                                  hipStream_t stream) {
+  GA_REQUIRE(out && n > 0 && n < (1ll << 30), "ga_permutation_i32: bad arguments");
+  int half_bits = 1;
+  while ((1ll << (2 * half_bits)) < n) ++half_bits;
+  hipLaunchKernelGGL(feistel_perm_kernel, dim3((unsigned)ga_ceil_div(n, 256)),
+                     dim3(256), 0, stream, n, half_bits,
+                     (uint32_t)(key & 0xffffffffu), (uint32_t)(key >> 32), out);
+  GA_CHECK_LAUNCH("feistel_perm");
   return GA_OK;
 }

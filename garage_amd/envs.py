@@ -1,0 +1,213 @@
+"""Batched environments behind the GPU sampler.
+
+garage steps one ``Environment`` object per env in a Python loop
+(``sampler/vec_worker.py:185-197``; contract ``_environment.py:237-276``).  Here
+an environment *batch* is one object that advances all ``n_envs`` members with
+a single call and keeps its state in HBM:
+
+    reset_all()            -> ``obs`` (n, ldo) holds every first observation
+    step_all(actions)      -> ``reward`` (n,), ``step_type`` (n,) uint8 and
+                              ``next_obs`` (n, ldo) (the true next observation,
+                              terminal ones included)
+    reset_where(done)      -> members with ``done != 0`` start a new episode;
+                              their first observation overwrites ``next_obs``
+
+``SyntheticVecEnv`` is the benchmark workload of BASELINE.json (HIP kernels,
+Philox-keyed).  ``HostVecEnv`` adapts a list of ordinary per-env objects (any
+``garage.Environment``-like with ``reset``/``step``) so existing CPU simulators
+still feed the device-resident update path.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from garage_amd import _lib
+from garage_amd._dtypes import Box, Discrete, EnvSpec, StepType, is_discrete
+from garage_amd._lib import call, dptr, stream_ptr
+from garage_amd.engine import require_gpu, round4
+
+
+class VecEnv:
+    """Base class / protocol of a device-batched environment."""
+
+    n_envs = 0
+    spec = None
+
+    @property
+    def obs_dim(self):
+        return self.spec.observation_space.flat_dim
+
+    @property
+    def act_width(self):
+        """Columns of the action matrix handed to :meth:`step_all`."""
+        if is_discrete(self.spec.action_space):
+            return 1
+        return self.spec.action_space.flat_dim
+
+    def _alloc(self, device):
+        n, ldo = self.n_envs, round4(self.obs_dim)
+        self.device = device
+        self.obs = torch.zeros(n, ldo, dtype=torch.float32, device=device)
+        self.next_obs = torch.zeros(n, ldo, dtype=torch.float32, device=device)
+        self.reward = torch.zeros(n, dtype=torch.float32, device=device)
+        self.step_type = torch.zeros(n, dtype=torch.uint8, device=device)
+
+    def advance(self):
+        """Make ``next_obs`` the current observation (buffer swap)."""
+        self.obs, self.next_obs = self.next_obs, self.obs
+
+    def reset_all(self):
+        raise NotImplementedError
+
+    def step_all(self, actions):
+        raise NotImplementedError
+
+    def reset_where(self, done):
+        raise NotImplementedError
+
+    def close(self):
+        pass
+
+
+class SyntheticVecEnv(VecEnv):
+    """``n_envs`` synthetic environments stepped by one HIP kernel.
+
+    Observation ``t`` of episode ``e`` of env ``i``: ``obs_dim`` unit-variance
+    uniforms from Philox4x32-10 keyed ``(seed; env_id0 + i, e, t)``; reward: a
+    Philox value plus ``0.1 * <clip(a), obs>`` (continuous) or ``0.1 * obs[a]``
+    (discrete); episode length ``L ~ U{min_len..max_episode_length}``, ending
+    TIMEOUT when ``L == max_episode_length`` else TERMINAL.  ``oracle/envs.py``
+    holds the bit-identical per-env CPU twin used by the parity tests.
+    """
+
+    def __init__(self, n_envs, obs_dim, act_dim, max_episode_length, *,
+                 min_len=None, seed=0, discrete=False, env_id0=0, device=None):
+        self.n_envs = int(n_envs)
+        self._obs_dim = int(obs_dim)
+        self._act_dim = int(act_dim)
+        self.discrete = bool(discrete)
+        self.max_episode_length = int(max_episode_length)
+        self.min_len = (self.max_episode_length
+                        if min_len is None else int(min_len))
+        self.seed = int(seed)
+        self.env_id0 = int(env_id0)
+        act_space = (Discrete(act_dim) if discrete else Box(
+            -np.inf, np.inf, (act_dim, )))
+        self.spec = EnvSpec(Box(-np.inf, np.inf, (obs_dim, )), act_space,
+                            max_episode_length=self.max_episode_length)
+        self._init_device(device)
+
+    def _init_device(self, device):
+        device = device or require_gpu()
+        self._alloc(device)
+        n = self.n_envs
+        self._episode = torch.full((n, ), -1, dtype=torch.int32, device=device)
+        self._t = torch.zeros(n, dtype=torch.int32, device=device)
+        self._len = torch.zeros(n, dtype=torch.int32, device=device)
+        e = _lib.SynthEnv()
+        e.n, e.env_id0 = n, self.env_id0
+        e.obs_dim, e.act_dim = self._obs_dim, self._act_dim
+        e.discrete = int(self.discrete)
+        e.min_len, e.max_len = self.min_len, self.max_episode_length
+        e.seed = self.seed
+        e.episode = self._episode.data_ptr()
+        e.t = self._t.data_ptr()
+        e.len = self._len.data_ptr()
+        self._c = e
+
+    def reset_all(self):
+        call('ga_synth_env_reset', C.byref(self._c), None, dptr(self.obs),
+             self.obs.stride(0), stream_ptr())
+
+    def step_all(self, actions):
+        call('ga_synth_env_step', C.byref(self._c), dptr(actions),
+             actions.stride(0), dptr(self.obs), dptr(self.next_obs),
+             self.obs.stride(0), dptr(self.reward), dptr(self.step_type),
+             stream_ptr())
+
+    def reset_where(self, done):
+        call('ga_synth_env_reset', C.byref(self._c), dptr(done),
+             dptr(self.next_obs), self.next_obs.stride(0), stream_ptr())
+
+    # -- snapshot support (trainer.py:263-293 pickles algo + env) -----------
+    def __getstate__(self):
+        state = {
+            k: v for k, v in self.__dict__.items()
+            if not torch.is_tensor(v) and k not in ('_c', 'device')
+        }
+        state['_saved'] = {
+            k: getattr(self, k).cpu().numpy()
+            for k in ('_episode', '_t', '_len', 'obs')
+        }
+        return state
+
+    def __setstate__(self, state):
+        saved = state.pop('_saved')
+        self.__dict__.update(state)
+        self._init_device(None)
+        for k, v in saved.items():
+            getattr(self, k).copy_(torch.from_numpy(v))
+
+
+class HostVecEnv(VecEnv):
+    """Adapter: a list of per-env CPU objects behind the batched protocol.
+
+    Each member follows garage's ``Environment`` contract
+    (``_environment.py:237-276``): ``reset() -> (obs, episode_info)`` and
+    ``step(action) -> EnvStep`` with ``.reward``, ``.observation``,
+    ``.step_type``.  Stepping stays a host loop (that is what those simulators
+    are); observations / rewards cross PCIe once per step through pinned
+    staging buffers, and everything downstream stays on the device.
+    """
+
+    def __init__(self, envs, spec=None, device=None):
+        self.envs = list(envs)
+        self.n_envs = len(self.envs)
+        self.spec = spec if spec is not None else self.envs[0].spec
+        self._alloc(device or require_gpu())
+        n, ldo = self.n_envs, self.obs.shape[1]
+        self._h_obs = torch.zeros(n, ldo, dtype=torch.float32).pin_memory()
+        self._h_rew = torch.zeros(n, dtype=torch.float32).pin_memory()
+        self._h_st = torch.zeros(n, dtype=torch.uint8).pin_memory()
+        self.discrete = is_discrete(self.spec.action_space)
+
+    def _put_obs(self, i, obs):
+        flat = np.asarray(obs, dtype=np.float32).reshape(-1)
+        self._h_obs[i, :flat.shape[0]] = torch.from_numpy(flat)
+
+    def reset_all(self):
+        for i, env in enumerate(self.envs):
+            self._put_obs(i, env.reset()[0])
+        self.obs.copy_(self._h_obs)
+
+    def step_all(self, actions):
+        acts = actions.cpu().numpy()
+        O = self.obs_dim
+        for i, env in enumerate(self.envs):
+            a = int(acts[i, 0]) if self.discrete else acts[i, :self.act_width]
+            es = env.step(a)
+            self._put_obs(i, es.observation)
+            self._h_rew[i] = float(es.reward)
+            self._h_st[i] = int(es.step_type)
+        del O
+        self.next_obs.copy_(self._h_obs)
+        self.reward.copy_(self._h_rew)
+        self.step_type.copy_(self._h_st)
+
+    def reset_where(self, done):
+        mask = done.cpu().numpy()
+        idx = np.nonzero(mask)[0]
+        if idx.size == 0:
+            return
+        self._h_obs.copy_(self.next_obs)  # keep rows that are not reset
+        for i in idx:
+            self._put_obs(int(i), self.envs[int(i)].reset()[0])
+        self.next_obs.copy_(self._h_obs)
+
+    def close(self):
+        for env in self.envs:
+            env.close()
+
+
+__all__ = ['VecEnv', 'SyntheticVecEnv', 'HostVecEnv', 'StepType']

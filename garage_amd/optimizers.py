@@ -1,0 +1,118 @@
+"""``OptimizerWrapper`` with a fused device Adam and minibatch id streams.
+
+Mirrors ``garage.torch.optimizers.OptimizerWrapper``
+(``torch/optimizers/optimizer_wrapper.py:6-63``), ``make_optimizer``
+(``_functions.py:25-65``) and ``BatchDataset``
+(``np/optimizers/minibatch_dataset.py:4-35``).
+"""
+import numpy as np
+import torch
+
+from garage_amd._lib import call, dptr, stream_ptr
+
+
+def _parse_optimizer(optimizer):
+    """``make_optimizer``: a type, or ``(type, kwargs)``."""
+    kwargs = {}
+    if isinstance(optimizer, tuple):
+        opt_type, kwargs = optimizer
+        kwargs = dict(kwargs)
+    else:
+        opt_type = optimizer
+    name = getattr(opt_type, '__name__', str(opt_type))
+    if name != 'Adam':
+        raise NotImplementedError(
+            'garage_amd fuses torch.optim.Adam; got {}'.format(name))
+    if kwargs.get('weight_decay', 0) or kwargs.get('amsgrad', False):
+        raise NotImplementedError('weight_decay / amsgrad are not supported')
+    return dict(lr=kwargs.get('lr', 1e-3), betas=kwargs.get('betas',
+                                                            (0.9, 0.999)),
+                eps=kwargs.get('eps', 1e-8))
+
+
+class OptimizerWrapper:
+    """Adam over one module's flat parameter buffer + minibatch iteration.
+
+    Args:
+        optimizer: ``torch.optim.Adam`` or ``(torch.optim.Adam, {'lr': ...})``.
+        module: a ``garage_amd`` policy / value function (has ``.net``).
+        max_optimization_epochs (int): passes over the data per update.
+        minibatch_size (int or None): ``None`` = one full batch, no shuffle.
+        permutation (str): ``'numpy'`` draws the ids exactly like the reference
+            (global ``np.random.shuffle`` on the host, cumulative, one extra
+            shuffle per pass: SURVEY.md Q8) and ships them to the device;
+            ``'device'`` evaluates a keyed Feistel permutation in a HIP kernel
+            (no host work; a different but equally valid shuffle).
+        seed (int): key of the ``'device'`` permutations.
+    """
+
+    def __init__(self, optimizer, module, max_optimization_epochs=1,
+                 minibatch_size=None, permutation='numpy', seed=0):
+        self._hyper = _parse_optimizer(optimizer)
+        self._module = module
+        self._max_optimization_epochs = max_optimization_epochs
+        self._minibatch_size = minibatch_size
+        if permutation not in ('numpy', 'device'):
+            raise ValueError("permutation must be 'numpy' or 'device'")
+        self._permutation = permutation
+        self._seed = int(seed)
+        self._draws = 0
+        self.grad_hook = None  # multi-GPU: called on the flat grads
+
+    @property
+    def net(self):
+        return self._module.net
+
+    def minibatch_indices(self, n):
+        """Yield one device int32 id tensor per minibatch (``None``: all rows).
+
+        Same number, sizes and -- in ``'numpy'`` mode -- contents as the
+        minibatches ``get_minibatch`` of the reference yields for ``n`` rows.
+        """
+        mb = self._minibatch_size
+        if mb is None:
+            for _ in range(self._max_optimization_epochs):
+                yield None
+            return
+        dev = self.net.device
+        nb = -(-n // mb)
+        if self._permutation == 'numpy':
+            ids = np.arange(n, dtype=np.int32)
+            np.random.shuffle(ids)  # BatchDataset.__init__ -> update()
+            for _ in range(self._max_optimization_epochs):
+                perm = torch.from_numpy(ids.copy()).to(dev)
+                for k in range(nb):
+                    yield perm[k * mb:(k + 1) * mb]
+                np.random.shuffle(ids)  # after each full pass
+        else:
+            for _ in range(self._max_optimization_epochs):
+                perm = torch.empty(n, dtype=torch.int32, device=dev)
+                self._draws += 1
+                key = (self._seed * 0x9E3779B97F4A7C15 +
+                       self._draws * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+                call('ga_permutation_i32', n, key, dptr(perm), stream_ptr())
+                for k in range(nb):
+                    yield perm[k * mb:(k + 1) * mb]
+
+    def get_minibatch(self, *inputs):
+        """Reference-shaped generator: lists of gathered tensors."""
+        n = inputs[0].shape[0]
+        for idx in self.minibatch_indices(n):
+            if idx is None:
+                yield list(inputs)
+            else:
+                yield [d[idx.long()] for d in inputs]
+
+    def zero_grad(self):
+        self.net.grads.zero_()
+
+    def step(self, **closure):
+        """Reduce the gradient slabs, (all-reduce,) Adam."""
+        del closure
+        self.net.reduce_grads()
+        if not getattr(self._module, '_learn_std', True):
+            self.net.grads[0:1].zero_()
+        if self.grad_hook is not None:
+            self.grad_hook(self.net.grads)
+        self.net.adam_step(self._hyper['lr'], self._hyper['betas'],
+                           self._hyper['eps'])

@@ -1,0 +1,361 @@
+"""Gaussian MLP policy and value function on flat HBM parameter buffers.
+
+API-compatible with ``garage.torch.policies.GaussianMLPPolicy``
+(``torch/policies/gaussian_mlp_policy.py:9-102``, ``stochastic_policy.py:11-104``,
+``torch/policies/policy.py:9-79``) and
+``garage.torch.value_functions.GaussianMLPValueFunction``
+(``torch/value_functions/gaussian_mlp_value_function.py:9-112``): same
+constructor keywords, ``state_dict`` key names and shapes, ``get_actions`` /
+``get_param_values`` / ``set_param_values`` / ``forward`` / ``compute_loss``.
+The arithmetic runs in the HIP kernels of ``garage_amd/csrc``.
+"""
+import ctypes as C
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+from torch import nn
+from torch.distributions import Independent, Normal
+
+from garage_amd import _lib
+from garage_amd._dtypes import is_discrete
+from garage_amd._lib import call, dptr, stream_ptr
+from garage_amd.engine import (FlatMLP, pad_rows, reduction_workspace,
+                               require_gpu, round4)
+
+
+def _check_supported(hidden_nonlinearity, output_nonlinearity,
+                     std_parameterization, layer_normalization):
+    if hidden_nonlinearity not in (torch.tanh, 'tanh', nn.Tanh):
+        raise NotImplementedError(
+            'garage_amd kernels implement tanh hidden layers (the '
+            'GaussianMLP* default); got {!r}'.format(hidden_nonlinearity))
+    if output_nonlinearity is not None:
+        raise NotImplementedError('output_nonlinearity must be None')
+    if std_parameterization != 'exp':
+        raise NotImplementedError("only std_parameterization='exp'")
+    if layer_normalization:
+        raise NotImplementedError('layer_normalization is not supported')
+
+
+def _reference_init(mlp, hidden_w_init, hidden_b_init, output_w_init,
+                    output_b_init):
+    """Initialise exactly as the reference does, consuming the same torch RNG.
+
+    ``MultiHeadedMLPModule.__init__`` (multi_headed_mlp_module.py:70-101)
+    builds an ``nn.Linear`` (which draws its own default init) and then applies
+    the weight / bias initialisers; doing the same on the CPU and copying the
+    result means ``set_seed(s)`` + construction yields the reference's
+    parameters bit for bit.
+    """
+    nl = len(mlp.dims) - 1
+    for l in range(nl):
+        lin = nn.Linear(mlp.dims[l], mlp.dims[l + 1])
+        if l < nl - 1:
+            hidden_w_init(lin.weight)
+            hidden_b_init(lin.bias)
+        else:
+            output_w_init(lin.weight)
+            output_b_init(lin.bias)
+        mlp.weight(l).copy_(lin.weight.detach())
+        mlp.bias(l).copy_(lin.bias.detach())
+
+
+class _GaussianMLP:
+    """Shared machinery of the policy and the value function."""
+
+    _prefix = '_module.'
+
+    def _build(self, in_dim, out_dim, hidden_sizes, hidden_w_init,
+               hidden_b_init, output_w_init, output_b_init, learn_std,
+               init_std, min_std, max_std, device):
+        self.device = device or require_gpu()
+        self.net = FlatMLP(in_dim, out_dim, hidden_sizes, self.device)
+        _reference_init(self.net, hidden_w_init, hidden_b_init, output_w_init,
+                        output_b_init)
+        self._learn_std = bool(learn_std)
+        self.net.params[0] = math.log(init_std)
+        self._min_log_std = None if min_std is None else float(
+            torch.Tensor([min_std]).log())
+        self._max_log_std = None if max_std is None else float(
+            torch.Tensor([max_std]).log())
+
+    # -- std handling ---------------------------------------------------------
+    def _std_args(self):
+        """(has_min, min, has_max, max) as the kernels take them."""
+        return (int(self._min_log_std is not None),
+                float(self._min_log_std or 0.0),
+                int(self._max_log_std is not None),
+                float(self._max_log_std or 0.0))
+
+    def clamped_log_std(self):
+        """Host value of the (clamped) scalar log-std: one tiny D2H copy."""
+        s = float(self.net.params[0].item())
+        if self._min_log_std is not None:
+            s = max(s, self._min_log_std)
+        if self._max_log_std is not None:
+            s = min(s, self._max_log_std)
+        return s
+
+    # -- torch.nn.Module-like surface -----------------------------------------
+    def _std_key(self):
+        return '_init_std' if self._learn_std else 'init_std'
+
+    def state_dict(self):
+        sd = OrderedDict()
+        for key, view in self.net.named_views():
+            if key == '_init_std':
+                sd[self._prefix + self._std_key()] = view.detach().cpu().clone()
+                if self._min_log_std is not None:
+                    sd[self._prefix + 'min_std_param'] = torch.tensor(
+                        [self._min_log_std])
+                if self._max_log_std is not None:
+                    sd[self._prefix + 'max_std_param'] = torch.tensor(
+                        [self._max_log_std])
+            else:
+                sd[self._prefix + key] = view.detach().cpu().clone()
+        return sd
+
+    def load_state_dict(self, sd):
+        for key, view in self.net.named_views():
+            name = self._prefix + (self._std_key()
+                                   if key == '_init_std' else key)
+            src = torch.as_tensor(np.asarray(sd[name]) if not torch.is_tensor(
+                sd[name]) else sd[name])
+            view.copy_(src.to(self.device, torch.float32).reshape(view.shape))
+        for attr, key in (('_min_log_std', 'min_std_param'),
+                          ('_max_log_std', 'max_std_param')):
+            if self._prefix + key in sd:
+                setattr(self, attr, float(sd[self._prefix + key]))
+
+    def parameters(self):
+        """Views of the trainable tensors, in the reference's order."""
+        views = self.net.named_views()
+        if not self._learn_std:
+            views = views[1:]
+        return [v for _, v in views]
+
+    def named_parameters(self):
+        out = []
+        for key, view in self.net.named_views():
+            if key == '_init_std' and not self._learn_std:
+                continue
+            out.append((self._prefix + key, view))
+        return out
+
+    def get_param_values(self):
+        return self.state_dict()
+
+    def set_param_values(self, state_dict):
+        self.load_state_dict(state_dict)
+
+    def copy_params_from(self, other):
+        """Device-to-device parameter copy (``_old_policy`` sync)."""
+        self.net.params.copy_(other.net.params)
+
+    def _as_device_obs(self, observations):
+        """Accept numpy / torch / list observations, return padded (B, ldo)."""
+        if torch.is_tensor(observations) and observations.is_cuda and \
+                observations.dim() == 2 and \
+                observations.shape[1] == round4(self.net.in_dim) and \
+                observations.dtype == torch.float32:
+            return observations
+        if isinstance(observations, (list, tuple)):
+            observations = np.stack([np.asarray(o) for o in observations])
+        if torch.is_tensor(observations):
+            observations = observations.detach().cpu().numpy()
+        flat = np.asarray(observations, dtype=np.float32)
+        flat = flat.reshape(flat.shape[0], -1)
+        return pad_rows(flat)
+
+    # -- pickling (Trainer snapshots cloudpickle the algo, trainer.py:263-293)
+    def __getstate__(self):
+        state = {k: v for k, v in self.__dict__.items()
+                 if k not in ('net', 'device')}
+        state['_hidden_sizes'] = self.net.hidden_sizes
+        state['_dims'] = (self.net.in_dim, self.net.out_dim)
+        for k in ('params', 'exp_avg', 'exp_avg_sq'):
+            state['_net_' + k] = getattr(self.net, k).cpu().numpy()
+        state['_net_steps'] = self.net.adam_steps
+        return state
+
+    def __setstate__(self, state):
+        hidden = state.pop('_hidden_sizes')
+        in_dim, out_dim = state.pop('_dims')
+        bufs = {k: state.pop('_net_' + k)
+                for k in ('params', 'exp_avg', 'exp_avg_sq')}
+        steps = state.pop('_net_steps')
+        self.__dict__.update(state)
+        self.device = require_gpu()
+        self.net = FlatMLP(in_dim, out_dim, hidden, self.device)
+        for k, v in bufs.items():
+            getattr(self.net, k).copy_(torch.from_numpy(v))
+        self.net.adam_steps = steps
+
+
+class GaussianMLPPolicy(_GaussianMLP):
+    """``garage.torch.policies.GaussianMLPPolicy`` on HIP kernels."""
+
+    def __init__(self,
+                 env_spec,
+                 hidden_sizes=(32, 32),
+                 hidden_nonlinearity=torch.tanh,
+                 hidden_w_init=nn.init.xavier_uniform_,
+                 hidden_b_init=nn.init.zeros_,
+                 output_nonlinearity=None,
+                 output_w_init=nn.init.xavier_uniform_,
+                 output_b_init=nn.init.zeros_,
+                 learn_std=True,
+                 init_std=1.0,
+                 min_std=1e-6,
+                 max_std=None,
+                 std_parameterization='exp',
+                 layer_normalization=False,
+                 name='GaussianMLPPolicy',
+                 device=None):
+        _check_supported(hidden_nonlinearity, output_nonlinearity,
+                         std_parameterization, layer_normalization)
+        if is_discrete(env_spec.action_space):
+            raise ValueError('GaussianMLPPolicy needs a continuous action '
+                             'space')
+        self._env_spec = env_spec
+        self._name = name
+        self._obs_dim = env_spec.observation_space.flat_dim
+        self._action_dim = env_spec.action_space.flat_dim
+        self._build(self._obs_dim, self._action_dim, hidden_sizes,
+                    hidden_w_init, hidden_b_init, output_w_init, output_b_init,
+                    learn_std, init_std, min_std, max_std, device)
+        # derived from torch's seed without consuming the global stream, so the
+        # objects constructed after this one still match the reference's init
+        self._sample_seed = int(torch.initial_seed() & 0x7FFFFFFF)
+        self._sample_calls = 0
+
+    kind = 'gaussian'
+
+    @property
+    def name(self):
+        return self._name
+
+    @property
+    def env_spec(self):
+        return self._env_spec
+
+    @property
+    def observation_space(self):
+        return self._env_spec.observation_space
+
+    @property
+    def action_space(self):
+        return self._env_spec.action_space
+
+    def reset(self, do_resets=None):
+        """Stateless policy: nothing to reset (``np/policies/policy.py:40``)."""
+
+    def mean(self, obs_dev, M=None, row_idx=None):
+        """Policy means ``(M, round4(A))`` for padded device observations."""
+        M = obs_dev.shape[0] if M is None else M
+        return self.net.forward(obs_dev, M, row_idx=row_idx)
+
+    def forward(self, observations):
+        """``(Independent(Normal(mean, std), 1), dict(mean=, log_std=))``.
+
+        ``gaussian_mlp_policy.py:89-102``; the mean comes from the HIP MLP, the
+        distribution object is built on the device for callers that want
+        ``log_prob`` / ``entropy`` (diagnostics, user code).
+        """
+        lead = None
+        if torch.is_tensor(observations) and observations.dim() > 2:
+            lead = observations.shape[:-1]
+            observations = observations.reshape(-1, observations.shape[-1])
+        obs = self._as_device_obs(observations)
+        mean = self.mean(obs)[:, :self._action_dim].clone()
+        log_std = torch.full_like(mean, self.clamped_log_std())
+        if lead is not None:
+            mean = mean.reshape(tuple(lead) + (self._action_dim, ))
+            log_std = log_std.reshape(mean.shape)
+        dist = Independent(Normal(mean, log_std.exp()), 1)
+        return dist, dict(mean=mean, log_std=log_std)
+
+    __call__ = forward
+
+    def get_actions(self, observations):
+        """``stochastic_policy.py:46-89``: numpy in, numpy out."""
+        obs = self._as_device_obs(observations)
+        n = obs.shape[0]
+        mean = self.mean(obs)
+        s = self.clamped_log_std()
+        self._sample_calls += 1
+        gen = torch.Generator(device=self.device)
+        gen.manual_seed(self._sample_seed + self._sample_calls)
+        noise = torch.randn(n, self._action_dim, device=self.device,
+                            generator=gen)
+        m = mean[:, :self._action_dim]
+        actions = m + math.exp(s) * noise
+        return actions.cpu().numpy(), dict(
+            mean=m.cpu().numpy(),
+            log_std=np.full((n, self._action_dim), s, dtype=np.float32))
+
+    def get_action(self, observation):
+        a, info = self.get_actions(np.asarray(observation)[None])
+        return a[0], {k: v[0] for k, v in info.items()}
+
+
+class GaussianMLPValueFunction(_GaussianMLP):
+    """``garage.torch.value_functions.GaussianMLPValueFunction`` on HIP kernels."""
+
+    _prefix = 'module.'
+
+    def __init__(self,
+                 env_spec,
+                 hidden_sizes=(32, 32),
+                 hidden_nonlinearity=torch.tanh,
+                 hidden_w_init=nn.init.xavier_uniform_,
+                 hidden_b_init=nn.init.zeros_,
+                 output_nonlinearity=None,
+                 output_w_init=nn.init.xavier_uniform_,
+                 output_b_init=nn.init.zeros_,
+                 learn_std=True,
+                 init_std=1.0,
+                 layer_normalization=False,
+                 name='GaussianMLPValueFunction',
+                 device=None):
+        _check_supported(hidden_nonlinearity, output_nonlinearity, 'exp',
+                         layer_normalization)
+        self._env_spec = env_spec
+        self.name = name
+        self._build(env_spec.observation_space.flat_dim, 1, hidden_sizes,
+                    hidden_w_init, hidden_b_init, output_w_init, output_b_init,
+                    learn_std, init_std, None, None, device)
+
+    def values(self, obs_dev, M=None, row_idx=None):
+        """``(M, 4)`` device tensor, the value in column 0."""
+        M = obs_dev.shape[0] if M is None else M
+        return self.net.forward(obs_dev, M, row_idx=row_idx)
+
+    def forward(self, obs):
+        """``gaussian_mlp_value_function.py:100-112``: ``(..., O) -> (...)``."""
+        lead = None
+        if torch.is_tensor(obs) and obs.dim() > 2:
+            lead = obs.shape[:-1]
+            obs = obs.reshape(-1, obs.shape[-1])
+        v = self.values(self._as_device_obs(obs))[:, 0].clone()
+        return v if lead is None else v.reshape(tuple(lead))
+
+    __call__ = forward
+
+    def compute_loss(self, obs, returns):
+        """Gaussian NLL of ``returns`` (``gaussian_mlp_value_function.py:81-98``)."""
+        x = self._as_device_obs(obs)
+        M = x.shape[0]
+        v = self.values(x)
+        ret = torch.as_tensor(returns).to(self.device,
+                                          torch.float32).reshape(-1)
+        out = torch.zeros(1, dtype=torch.float32, device=self.device)
+        call('ga_gaussian_nll_loss_f32', dptr(v), v.stride(0), dptr(ret), None,
+             dptr(self.net.log_std), M, None, dptr(out), None, 0, 0,
+             dptr(reduction_workspace(self.device)), stream_ptr())
+        return out[0]
+
+
+__all__ = ['GaussianMLPPolicy', 'GaussianMLPValueFunction']

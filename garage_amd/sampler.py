@@ -1,0 +1,467 @@
+"""GPU sampler and worker with garage's Sampler / Worker plugin surface.
+
+Replaces ``LocalSampler`` + ``VecWorker`` (``sampler/local_sampler.py:13-232``,
+``sampler/vec_worker.py:12-228``, ``sampler/worker_factory.py:24-116``,
+``sampler/_functions.py:6-40``).  The per-env Python loop becomes a handful of
+kernel launches per step over env-major ``(n_envs, Tcap)`` rollout buffers in
+HBM; episode bookkeeping (lengths, completion order, step types, the reset of
+finished envs, the discard of in-flight episodes at each ``obtain_samples``)
+follows the reference exactly and is verified bit for bit against it.
+"""
+import copy
+import ctypes as C
+
+import numpy as np
+import torch
+
+from garage_amd import _lib
+from garage_amd._dtypes import DeviceEpisodeBatch, EpisodeBatch, is_discrete
+from garage_amd._lib import call, dptr, stream_ptr
+from garage_amd.engine import require_gpu, round4
+from garage_amd.envs import HostVecEnv, VecEnv
+
+
+def _identity(value):
+    return value
+
+
+class WorkerFactory:
+    """``sampler/worker_factory.py:24-116`` (picklable worker constructor)."""
+
+    def __init__(self, *, max_episode_length, is_tf_worker=False, seed=None,
+                 n_workers=1, worker_class=None, worker_args=None):
+        if is_tf_worker:
+            raise NotImplementedError('TensorFlow workers are out of scope')
+        self.n_workers = n_workers
+        self._seed = seed
+        self._max_episode_length = max_episode_length
+        self._worker_class = worker_class or GpuVecWorker
+        self._worker_args = {} if worker_args is None else worker_args
+
+    def prepare_worker_messages(self, objs, preprocess=_identity):
+        if isinstance(objs, list):
+            if len(objs) != self.n_workers:
+                raise ValueError(
+                    'Length of list doesn\'t match number of workers')
+            return [preprocess(obj) for obj in objs]
+        return [preprocess(objs) for _ in range(self.n_workers)]
+
+    def __call__(self, worker_number):
+        if worker_number >= self.n_workers:
+            raise ValueError('Worker number is too big')
+        return self._worker_class(worker_number=worker_number,
+                                  seed=self._seed,
+                                  max_episode_length=self._max_episode_length,
+                                  **self._worker_args)
+
+
+def _copy_env(env):
+    """``copy.deepcopy`` for per-env objects; device batches are shared."""
+    return env if isinstance(env, VecEnv) else copy.deepcopy(env)
+
+
+class GpuVecWorker:
+    """``VecWorker`` whose ``n_envs`` environments live on the GPU.
+
+    ``update_env`` accepts a :class:`~garage_amd.envs.VecEnv` (used as is), a
+    list of exactly ``n_envs`` per-env objects or a single per-env object that
+    is deep-copied ``n_envs`` times (``vec_worker.py:75-105``) -- the latter two
+    are wrapped in :class:`~garage_amd.envs.HostVecEnv`.
+    """
+
+    DEFAULT_N_ENVS = 8
+
+    def __init__(self, *, seed, max_episode_length, worker_number,
+                 n_envs=DEFAULT_N_ENVS, noise_fn=None, store_agent_infos=True):
+        self._seed = seed
+        self._max_episode_length = max_episode_length
+        self._worker_number = worker_number
+        self._n_envs = n_envs
+        self._noise_fn = noise_fn  # test hook: step -> (n, A) noise tensor
+        self._store_infos = store_agent_infos
+        self.agent = None
+        self.env = None
+        self._needs_agent_reset = True
+        self._needs_env_reset = True
+        self._ep_t = None
+        self._global_step = 0
+        self._pending = []  # API-compat path: completed episode batches
+        self.device = require_gpu()
+        if seed is not None:
+            # default_worker.py:50-53: seed the *global* RNGs per worker
+            import random
+            s = seed + worker_number
+            random.seed(s)
+            np.random.seed(s)
+            torch.manual_seed(s)
+
+    # -- updates --------------------------------------------------------------
+    def update_agent(self, agent_update):
+        """``default_worker.py:55-69`` + ``vec_worker.py:61-73``."""
+        if isinstance(agent_update, (dict, tuple, np.ndarray)):
+            self.agent.set_param_values(agent_update)
+        elif agent_update is not None:
+            self.agent = agent_update
+        self._needs_agent_reset = True
+
+    def update_env(self, env_update):
+        if env_update is None:
+            return
+        if isinstance(env_update, VecEnv):
+            if env_update.n_envs != self._n_envs:
+                raise ValueError('If separate environments are passed for '
+                                 'each worker, there must be exactly n_envs '
+                                 '({}) environments, but received {} '
+                                 'environments.'.format(
+                                     self._n_envs, env_update.n_envs))
+            new_env = env_update
+        elif isinstance(env_update, list):
+            if len(env_update) != self._n_envs:
+                raise ValueError('If separate environments are passed for '
+                                 'each worker, there must be exactly n_envs '
+                                 '({}) environments, but received {} '
+                                 'environments.'.format(
+                                     self._n_envs, len(env_update)))
+            new_env = HostVecEnv(env_update)
+        elif hasattr(env_update, 'step') and hasattr(env_update, 'reset'):
+            new_env = HostVecEnv(
+                [copy.deepcopy(env_update) for _ in range(self._n_envs)])
+        elif callable(env_update):  # EnvUpdate (sampler/env_update.py:5-159)
+            new_env = env_update(self.env)
+        else:
+            raise TypeError('Unknown environment update type.')
+        if self.env is not None and self.env is not new_env:
+            self.env.close()
+        self.env = new_env
+        self._needs_env_reset = True
+
+    # -- rollout buffers ------------------------------------------------------
+    def _alloc_buffers(self, num_samples):
+        env, n = self.env, self._n_envs
+        P = int(self._max_episode_length)
+        # the last step t* satisfies t* <= ceil(num_samples / n) + P - 2
+        tcap = -(-int(num_samples) // n) + P - 1
+        tcap = round4(max(tcap, 1))
+        if tcap > 65535 * 4:
+            raise ValueError('rollout too long for one obtain_samples call')
+        dev = self.device
+        ldo = round4(env.obs_dim)
+        lda = round4(env.act_width)
+        ldh = round4(self.agent.net.out_dim)
+        f32 = torch.float32
+        b = {
+            'Tcap': tcap,
+            'obs': torch.empty(n, tcap, ldo, dtype=f32, device=dev),
+            'act': torch.empty(n, tcap, lda, dtype=f32, device=dev),
+            'head': (torch.empty(n, tcap, ldh, dtype=f32, device=dev)
+                     if self._store_infos else None),
+            'lastobs': torch.empty(n, tcap, ldo, dtype=f32, device=dev),
+            'rew': torch.empty(n, tcap, dtype=f32, device=dev),
+            'st': torch.empty(n, tcap, dtype=torch.uint8, device=dev),
+            'tail': torch.zeros(n, tcap, dtype=torch.uint16, device=dev),
+            'step_eps': torch.zeros(tcap, dtype=torch.int32, device=dev),
+            'step_samples': torch.zeros(tcap, dtype=torch.int32, device=dev),
+            'action': torch.zeros(n, lda, dtype=f32, device=dev),
+            'done': torch.zeros(n, dtype=torch.uint8, device=dev),
+        }
+        if ldo != env.obs_dim:
+            b['obs'].zero_()      # padding columns feed the GEMMs: keep them 0
+            b['lastobs'].zero_()
+        if lda != env.act_width:
+            b['act'].zero_()
+        return b
+
+    def _start(self):
+        """``vec_worker.py:107-137``: reset on agent / env update."""
+        if not (self._needs_agent_reset or self._needs_env_reset):
+            return
+        self.agent.reset([True] * self._n_envs)
+        if self._needs_env_reset or self._ep_t is None:
+            self.env.reset_all()
+            self._ep_t = torch.zeros(self._n_envs, dtype=torch.int32,
+                                     device=self.device)
+        else:
+            # only environments with progress are reset (vec_worker.py:122-126)
+            progress = (self._ep_t > 0).to(torch.uint8)
+            self.env.next_obs.copy_(self.env.obs)
+            self.env.reset_where(progress)
+            self.env.advance()
+            self._ep_t.zero_()
+        self._needs_agent_reset = False
+        self._needs_env_reset = False
+
+    def _step(self, b, col):
+        """One vectorised step into column ``col`` of the rollout buffers."""
+        env, pol, n = self.env, self.agent, self._n_envs
+        head = pol.net.forward(env.obs, n)
+        a = _lib.HeadArgs()
+        a.n, a.env_id0 = n, getattr(env, 'env_id0', 0)
+        a.kind = 0 if pol.kind == 'gaussian' else 1
+        a.A = pol.net.out_dim
+        a.head, a.ldh = head.data_ptr(), head.stride(0)
+        if pol.kind == 'gaussian':
+            a.log_std = pol.net.log_std.data_ptr()
+            a.has_min, a.min_log_std, a.has_max, a.max_log_std = \
+                pol._std_args()
+        else:
+            a.double_softmax = int(pol.double_softmax)
+        noise = self._noise_fn(self._global_step) if self._noise_fn else None
+        if noise is not None:
+            a.noise, a.ldn = noise.data_ptr(), noise.stride(0)
+        a.seed = (self._seed or 0) + 7919 * (self._worker_number + 1)
+        a.step = self._global_step & 0xFFFFFFFF
+        a.obs, a.ldo, a.obs_dim = (env.obs.data_ptr(), env.obs.stride(0),
+                                   env.obs_dim)
+        a.col, a.Tcap = col, b['Tcap']
+        a.action, a.lda = b['action'].data_ptr(), b['action'].stride(0)
+        a.obs_buf, a.act_buf = b['obs'].data_ptr(), b['act'].data_ptr()
+        a.head_buf = b['head'].data_ptr() if b['head'] is not None else None
+        s = stream_ptr()
+        call('ga_policy_head_sample', C.byref(a), s)
+        env.step_all(b['action'])
+        r = _lib.RecordArgs()
+        r.n, r.col, r.Tcap = n, col, b['Tcap']
+        r.max_episode_length = int(self._max_episode_length)
+        r.reward, r.step_type = env.reward.data_ptr(), env.step_type.data_ptr()
+        r.next_obs, r.ldo, r.obs_dim = (env.next_obs.data_ptr(),
+                                        env.next_obs.stride(0), env.obs_dim)
+        r.ep_t = self._ep_t.data_ptr()
+        r.rew_buf, r.st_buf = b['rew'].data_ptr(), b['st'].data_ptr()
+        r.tail_buf, r.lastobs_buf = (b['tail'].data_ptr(),
+                                     b['lastobs'].data_ptr())
+        r.done = b['done'].data_ptr()
+        r.step_eps = b['step_eps'].data_ptr()
+        r.step_samples = b['step_samples'].data_ptr()
+        call('ga_record_step', C.byref(r), s)
+        env.reset_where(b['done'])
+        env.advance()
+        self._global_step += 1
+        self.agent.reset(None)
+
+    def rollout_samples(self, num_samples):
+        """Everything ``LocalSampler.obtain_samples`` collects from one worker.
+
+        Steps until the episodes completed so far hold ``>= num_samples``
+        transitions, exactly like the ``while True: worker.rollout()`` loop of
+        ``local_sampler.py:157-166`` (in-flight episodes at that point are
+        dropped by the next call's reset).
+        """
+        self._start()
+        n = self._n_envs
+        b = self._alloc_buffers(num_samples)
+        col = 0
+        while True:
+            self._step(b, col)
+            col += 1
+            if col * n >= num_samples:  # cannot be reached any earlier
+                done_samples = int(b['step_samples'][:col].sum().item())
+                if done_samples >= num_samples:
+                    break
+            if col >= b['Tcap']:
+                raise RuntimeError('rollout buffer exhausted: an environment '
+                                   'ran past max_episode_length')
+        return self._pack(b, col)
+
+    def _pack(self, b, n_steps, first_step=0):
+        """Episodes that ended in columns ``[first_step, n_steps)`` -> batch."""
+        dev, n, tcap = self.device, self._n_envs, b['Tcap']
+        step_eps = b['step_eps'][:n_steps].cpu().numpy().astype(np.int64)
+        step_eps[:first_step] = 0
+        ep_base = np.concatenate([[0], np.cumsum(step_eps)[:-1]])
+        n_eps = int(step_eps.sum())
+        s = stream_ptr()
+        ep_env = torch.empty(n_eps, dtype=torch.int32, device=dev)
+        ep_end = torch.empty_like(ep_env)
+        ep_len = torch.empty_like(ep_env)
+        base_dev = torch.from_numpy(ep_base.astype(np.int32)).to(dev)
+        tail = b['tail']
+        if first_step:
+            tail = tail.clone()
+            tail[:, :first_step] = 0
+        call('ga_pack_episodes', dptr(tail), n, tcap, n_steps, dptr(base_dev),
+             dptr(ep_env), dptr(ep_end), dptr(ep_len), s)
+        lengths = ep_len.cpu().numpy().astype(np.int64)
+        off = np.concatenate([[0], np.cumsum(lengths)])
+        S = int(off[-1])
+        off_dev = torch.from_numpy(off).to(dev)
+        src = torch.empty(S, dtype=torch.int32, device=dev)
+        call('ga_pack_src_index', dptr(ep_env), dptr(ep_end), dptr(ep_len),
+             dptr(off_dev), n_eps, tcap, dptr(src), s)
+        ep_cell = (ep_env.long() * tcap + ep_end.long()).to(torch.int32)
+
+        def rows(buf, idx, count):
+            w = buf.shape[-1]
+            out = torch.empty(count, w, dtype=torch.float32, device=dev)
+            call('ga_gather_rows_f32', dptr(buf), w, dptr(idx), count, w,
+                 dptr(out), w, s)
+            return out
+
+        obs = rows(b['obs'], src, S)
+        act = rows(b['act'], src, S)
+        head = rows(b['head'], src, S) if b['head'] is not None else None
+        last = rows(b['lastobs'], ep_cell, n_eps)
+        rew = torch.empty(S, dtype=torch.float32, device=dev)
+        call('ga_gather_f32', dptr(b['rew']), dptr(src), S, dptr(rew), s)
+        st = torch.empty(S, dtype=torch.uint8, device=dev)
+        call('ga_gather_u8', dptr(b['st']), dptr(src), S, dptr(st), s)
+        pol = self.agent
+        gaussian = pol.kind == 'gaussian'
+        return DeviceEpisodeBatch(
+            self.env.spec, lengths=lengths, obs_dev=obs, last_obs_dev=last,
+            actions_dev=act, rewards_dev=rew, step_types_dev=st,
+            ep_off_dev=off_dev, head_dev=head,
+            head_name='mean' if gaussian else 'prob',
+            log_std=pol.clamped_log_std() if gaussian else None,
+            discrete=is_discrete(self.env.spec.action_space))
+
+    # -- reference-shaped API (one rollout() = until >=1 episode completes) ---
+    def start_episode(self):
+        self._start()
+
+    def rollout(self):
+        """``default_worker.py:176-186`` semantics, one device sync per step."""
+        self._start()
+        P = int(self._max_episode_length)
+        if getattr(self, '_api_buf', None) is None:
+            self._api_buf = self._alloc_buffers(self._n_envs * P)
+            self._api_col = 0
+            self._api_first = 0
+        b = self._api_buf
+        while True:
+            if self._api_col >= b['Tcap']:
+                raise RuntimeError('rollout buffer exhausted')
+            self._step(b, self._api_col)
+            self._api_col += 1
+            if int(b['step_eps'][self._api_col - 1].item()) > 0:
+                break
+        batch = self._pack(b, self._api_col, first_step=self._api_col - 1)
+        if self._api_col + P >= b['Tcap']:
+            self._rebase_api_buffer()
+        return batch
+
+    def _rebase_api_buffer(self):
+        """Move the in-flight tails of the API buffer back to column 0."""
+        old, col = self._api_buf, self._api_col
+        P = int(self._max_episode_length)
+        new = self._alloc_buffers(self._n_envs * P)
+        keep = min(col, P)
+        for k in ('obs', 'act', 'head', 'lastobs', 'rew', 'st'):
+            if old[k] is not None:
+                new[k][:, :keep] = old[k][:, col - keep:col]
+        self._api_buf, self._api_col = new, keep
+
+    def step_episode(self):
+        raise NotImplementedError(
+            'GpuVecWorker exposes rollout() / rollout_samples(); per-step '
+            'host control would serialise the device')
+
+    def collect_episode(self):
+        raise NotImplementedError('use rollout()')
+
+    def shutdown(self):
+        if self.env is not None:
+            self.env.close()
+
+    def __getstate__(self):
+        """Workers are not picklable (``sampler/worker.py:79-87``)."""
+        raise ValueError('Workers are not pickleable. '
+                         'Please pickle the WorkerFactory instead.')
+
+
+class GpuVecSampler:
+    """``LocalSampler`` (``sampler/local_sampler.py:13-232``) for GPU workers.
+
+    Same constructor keywords, ``from_worker_factory``, ``obtain_samples``,
+    ``obtain_exact_episodes``, ``shutdown_worker``, ``total_env_steps`` and
+    pickling behaviour; ``envs`` may be a :class:`~garage_amd.envs.VecEnv`.
+    Returns :class:`~garage_amd._dtypes.DeviceEpisodeBatch`.
+    """
+
+    def __init__(self, agents, envs, *, worker_factory=None,
+                 max_episode_length=None, is_tf_worker=False, seed=None,
+                 n_workers=1, worker_class=GpuVecWorker, worker_args=None):
+        if worker_factory is None and max_episode_length is None:
+            raise TypeError('Must construct a sampler from WorkerFactory or'
+                            'parameters (at least max_episode_length)')
+        if isinstance(worker_factory, WorkerFactory):
+            self._factory = worker_factory
+        else:
+            self._factory = WorkerFactory(
+                max_episode_length=max_episode_length,
+                is_tf_worker=is_tf_worker, seed=seed, n_workers=n_workers,
+                worker_class=worker_class, worker_args=worker_args)
+        self._agents = self._factory.prepare_worker_messages(agents)
+        self._envs = self._factory.prepare_worker_messages(
+            envs, preprocess=_copy_env)
+        self._build_workers()
+        self.total_env_steps = 0
+
+    def _build_workers(self):
+        self._workers = [
+            self._factory(i) for i in range(self._factory.n_workers)
+        ]
+        for worker, agent, env in zip(self._workers, self._agents, self._envs):
+            worker.update_agent(agent)
+            worker.update_env(env)
+
+    @classmethod
+    def from_worker_factory(cls, worker_factory, agents, envs):
+        return cls(agents, envs, worker_factory=worker_factory)
+
+    def start_worker(self):
+        """No-op, as in ``sampler/sampler.py``."""
+
+    def _update_workers(self, agent_update, env_update):
+        agent_updates = self._factory.prepare_worker_messages(agent_update)
+        env_updates = self._factory.prepare_worker_messages(
+            env_update, preprocess=_copy_env)
+        for worker, a, e in zip(self._workers, agent_updates, env_updates):
+            worker.update_agent(a)
+            worker.update_env(e)
+
+    def obtain_samples(self, itr, num_samples, agent_update, env_update=None):
+        """``local_sampler.py:134-166``."""
+        del itr
+        self._update_workers(agent_update, env_update)
+        if len(self._workers) == 1:
+            samples = self._workers[0].rollout_samples(num_samples)
+        else:
+            batches, done = [], 0
+            while done < num_samples:
+                for worker in self._workers:
+                    batch = worker.rollout()
+                    done += len(batch.actions)
+                    batches.append(batch.to_host())
+                    if done >= num_samples:
+                        break
+            samples = EpisodeBatch.concatenate(*batches)
+        self.total_env_steps += int(sum(samples.lengths))
+        return samples
+
+    def obtain_exact_episodes(self, n_eps_per_worker, agent_update,
+                              env_update=None):
+        """``local_sampler.py:168-200`` (worker order)."""
+        self._update_workers(agent_update, env_update)
+        batches = []
+        for worker in self._workers:
+            for _ in range(n_eps_per_worker):
+                batches.append(worker.rollout().to_host())
+        samples = EpisodeBatch.concatenate(*batches)
+        self.total_env_steps += int(sum(samples.lengths))
+        return samples
+
+    def shutdown_worker(self):
+        for worker in self._workers:
+            worker.shutdown()
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state['_workers'] = None  # local_sampler.py:207-217
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        self._build_workers()
+
+
+__all__ = ['WorkerFactory', 'GpuVecWorker', 'GpuVecSampler']

@@ -196,6 +196,11 @@ int ga_gather_f32(const float* src, const int32_t* idx, int64_t n, float* dst,
                   ga_stream_t stream);
 int ga_gather_u8(const uint8_t* src, const int32_t* idx, int64_t n, uint8_t* dst,
                  ga_stream_t stream);
+/* Minibatch id permutation of BatchDataset
+ * (np/optimizers/minibatch_dataset.py:4-35), throughput mode: a keyed Feistel
+ * permutation of [0, n) evaluated on the device (the parity mode ships the host
+ * np.random.shuffle ids instead). */
+int ga_permutation_i32(int64_t n, uint64_t key, int32_t* out, ga_stream_t stream);
 /* undiscounted return per episode (log_performance, _functions.py:233-275) */
 int ga_episode_sums_f32(const float* rewards, const int64_t* ep_off, int64_t n_eps,
                         double* sums, ga_stream_t stream);

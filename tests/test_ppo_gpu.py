@@ -1,0 +1,312 @@
+"""End-to-end parity on the GPU: sampler bookkeeping and PPO/VPG iterations
+against goldens captured from the real reference and against the oracle."""
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+LOG_KEYS = {
+    'policy/LossBefore': 'GaussianMLPPolicy/LossBefore',
+    'policy/LossAfter': 'GaussianMLPPolicy/LossAfter',
+    'policy/dLoss': 'GaussianMLPPolicy/dLoss',
+    'policy/KLBefore': 'GaussianMLPPolicy/KLBefore',
+    'policy/KL': 'GaussianMLPPolicy/KL',
+    'policy/Entropy': 'GaussianMLPPolicy/Entropy',
+    'vf/LossBefore': 'GaussianMLPValueFunction/LossBefore',
+    'vf/LossAfter': 'GaussianMLPValueFunction/LossAfter',
+    'vf/dLoss': 'GaussianMLPValueFunction/dLoss',
+}
+
+TRAIN_CASES = {
+    'ppo': dict(),
+    'ppo_pos': dict(positive_adv=True),
+    'ppo_reg': dict(entropy_method='regularized', policy_ent_coeff=0.02),
+    'ppo_max': dict(entropy_method='max', policy_ent_coeff=0.05,
+                    center_adv=False, stop_entropy_gradient=True,
+                    use_softplus_entropy=True),
+    'vpg': dict(),
+    'ppo_full': dict(),
+}
+
+
+def _sd(g, prefix):
+    out = OrderedDict()
+    for k in g.files:
+        if k.startswith(prefix):
+            out[k[len(prefix):]] = torch.from_numpy(g[k].copy())
+    return out
+
+
+def _spec(O, A, P):
+    from garage_amd._dtypes import Box, EnvSpec
+    return EnvSpec(Box(-np.inf, np.inf, (O, )), Box(-np.inf, np.inf, (A, )),
+                   max_episode_length=P)
+
+
+def _host_batch(spec, g, pre, O):
+    from garage_amd._dtypes import EpisodeBatch, StepType
+    lens = g[pre + 'lengths']
+    st = np.asarray([StepType(int(s)) for s in g[pre + 'step_types']],
+                    dtype=object)
+    return EpisodeBatch(env_spec=spec, episode_infos={},
+                        observations=g[pre + 'observations'],
+                        last_observations=np.zeros((len(lens), O), np.float32),
+                        actions=g[pre + 'actions'], rewards=g[pre + 'rewards'],
+                        env_infos={}, agent_infos={}, step_types=st,
+                        lengths=lens)
+
+
+@pytest.mark.parametrize('tag', sorted(TRAIN_CASES))
+def test_train_once_matches_real_reference(golden, tag):
+    """Two consecutive ``_train_once`` calls vs the real garage PPO / VPG
+    (tests/golden/train_once.npz): 9 logged scalars, evaluation statistics,
+    post-update parameters and Adam moments."""
+    from garage_amd.algos import PPO, VPG
+    from garage_amd.optimizers import OptimizerWrapper
+    from garage_amd.policies import GaussianMLPPolicy, GaussianMLPValueFunction
+    g = golden('train_once')
+    O, A, P, E, mb = [int(v) for v in g[tag + '_cfg']]
+    mb = None if mb < 0 else mb
+    spec = _spec(O, A, P)
+    pol = GaussianMLPPolicy(spec, hidden_sizes=(8, 8))
+    vf = GaussianMLPValueFunction(spec, hidden_sizes=(8, 8))
+    pol.load_state_dict(_sd(g, tag + '_pol0:'))
+    vf.load_state_dict(_sd(g, tag + '_vf0:'))
+    cls = VPG if tag == 'vpg' else PPO
+    algo = cls(env_spec=spec, policy=pol, value_function=vf, sampler=None,
+               policy_optimizer=OptimizerWrapper(
+                   (torch.optim.Adam, dict(lr=2.5e-4)), pol,
+                   max_optimization_epochs=E, minibatch_size=mb),
+               vf_optimizer=OptimizerWrapper(
+                   (torch.optim.Adam, dict(lr=2.5e-4)), vf,
+                   max_optimization_epochs=E, minibatch_size=mb),
+               **TRAIN_CASES[tag])
+    for it in range(2):
+        pre = '%s_it%d_' % (tag, it)
+        batch = _host_batch(spec, g, pre, O)
+        np.random.seed(int(g[pre + 'np_seed']))
+        avg = algo._train_once(it, batch)
+        for mine, theirs in LOG_KEYS.items():
+            want = float(g[pre + 'log:' + theirs])
+            assert np.isclose(algo.last_tabular[mine], want, atol=1e-5,
+                              rtol=1e-5), (mine, it, algo.last_tabular[mine],
+                                           want)
+        assert np.isclose(avg, float(g[pre + 'avg_return']))
+        for k, v in algo.last_performance.items():
+            assert np.isclose(v, float(g[pre + 'log:Evaluation/' + k])), k
+        for k, v in pol.state_dict().items():
+            assert np.allclose(v.numpy(), g[pre + 'pol:' + k], atol=2e-6), k
+        for k, v in vf.state_dict().items():
+            assert np.allclose(v.numpy(), g[pre + 'vf:' + k], atol=2e-6), k
+        for name, net in (('pol', pol.net), ('vf', vf.net)):
+            views_m = net.named_views(net.exp_avg)
+            views_v = net.named_views(net.exp_avg_sq)
+            for j, ((_, m), (_, v)) in enumerate(zip(views_m, views_v)):
+                gm = g['%sadam_%s_%d_m' % (pre, name, j)]
+                gv = g['%sadam_%s_%d_v' % (pre, name, j)]
+                assert np.allclose(m.cpu().numpy().reshape(gm.shape), gm,
+                                   atol=1e-6)
+                assert np.allclose(v.cpu().numpy().reshape(gv.shape), gv,
+                                   atol=1e-8)
+            assert net.adam_steps == int(g['%sadam_%s_0_step' % (pre, name)])
+
+
+def _scripted_policy(spec):
+    """action = [sum(obs), step]: a linear 'MLP' + teacher-forced noise."""
+    from garage_amd.policies import GaussianMLPPolicy
+    pol = GaussianMLPPolicy(spec, hidden_sizes=(), init_std=1.0)
+    pol.net.weight(0).copy_(torch.tensor([[1., 1., 1.], [0., 0., 0.]]))
+    pol.net.bias(0).zero_()
+    return pol
+
+
+def test_sampler_bookkeeping_matches_real_vecworker(golden):
+    """lengths / order / step types / rewards / actions / last_observations
+    equal the real ``LocalSampler(VecWorker)`` (tests/golden/sampler.npz);
+    observations equal what ``DefaultWorker`` semantics give (Q10)."""
+    from garage_amd.sampler import GpuVecSampler, GpuVecWorker
+    from oracle import envs as oenvs
+    from oracle import sampler as osamp
+    g = golden('sampler')
+    P, n = [int(v) for v in g['cfg']]
+    cyc = g['cycles']
+    spec = _spec(3, 2, P)
+
+    class Env(oenvs.CountingEnv):
+
+        def __init__(self, i):
+            super().__init__(i, cyc[i], P)
+            self.spec = spec
+
+    pol = _scripted_policy(spec)
+    dev = pol.device
+
+    def noise_fn(step):
+        z = torch.zeros(n, 4, device=dev)
+        z[:, 1] = float(step)
+        return z
+
+    sampler = GpuVecSampler(pol, [[Env(i) for i in range(n)]],
+                            max_episode_length=P, n_workers=1,
+                            worker_class=GpuVecWorker,
+                            worker_args=dict(n_envs=n, noise_fn=noise_fn))
+    # the oracle's VecWorker with DefaultWorker observations (alias bug off)
+    class Scripted:
+        calls = 0
+
+        def reset(self, do_resets=None):
+            pass
+
+        def get_actions(self, obs):
+            obs = np.asarray(obs, dtype=np.float32)
+            a = np.zeros((obs.shape[0], 2), np.float32)
+            a[:, 0] = obs.sum(axis=1)
+            a[:, 1] = self.calls
+            self.calls += 1
+            return a, {}
+
+    ref = osamp.OracleLocalSampler(
+        Scripted(), [[oenvs.CountingEnv(i, cyc[i], P) for i in range(n)]],
+        max_episode_length=P, n_workers=1, worker_class=osamp.OracleVecWorker,
+        worker_args=dict(n_envs=n))
+    for prefix, num in (('vec_', 30), ('vec2_', 17)):
+        eps = sampler.obtain_samples(0, num, None)
+        want = ref.obtain_samples(0, num, None)
+        assert np.array_equal(eps.lengths, g[prefix + 'lengths'])
+        assert eps.lengths.dtype == np.dtype('l')
+        assert np.array_equal([int(s) for s in eps.step_types],
+                              g[prefix + 'step_types'])
+        assert np.array_equal(eps.rewards, g[prefix + 'rewards'])
+        assert eps.rewards.dtype == np.float64
+        assert np.array_equal(eps.actions, g[prefix + 'actions'])
+        assert np.array_equal(eps.last_observations,
+                              g[prefix + 'last_observations'])
+        assert np.array_equal(eps.observations, want.observations)
+        eps.to_host()  # passes the reference's EpisodeBatch validation
+    assert sampler.total_env_steps == int(g['vec_total_env_steps'])
+
+
+@pytest.mark.parametrize('ragged', [False, True])
+def test_synthetic_rollout_matches_cpu_twin(ragged):
+    """SyntheticVecEnv + GpuVecWorker vs the per-env CPU twin stepped by the
+    oracle's VecWorker, teacher-forced with the same noise."""
+    from garage_amd.envs import SyntheticVecEnv
+    from garage_amd.policies import GaussianMLPPolicy
+    from garage_amd.sampler import GpuVecSampler, GpuVecWorker
+    from oracle import envs as oenvs
+    from oracle import networks as nets
+    from oracle import sampler as osamp
+    n, O, A, P = 37, 5, 3, 12
+    min_len = 3 if ragged else None
+    torch.manual_seed(3)
+    env = SyntheticVecEnv(n, O, A, P, min_len=min_len, seed=123)
+    pol = GaussianMLPPolicy(env.spec, hidden_sizes=(16, 16))
+    dev = pol.device
+    noise = torch.randn(64, n, 4)
+
+    def noise_fn(step):
+        return noise[step].to(dev)
+
+    sampler = GpuVecSampler(pol, env, max_episode_length=P, n_workers=1,
+                            worker_class=GpuVecWorker,
+                            worker_args=dict(n_envs=n, noise_fn=noise_fn))
+    params = pol.state_dict()
+
+    class CpuPolicy:
+        calls = 0
+
+        def reset(self, do_resets=None):
+            pass
+
+        def get_actions(self, obs):
+            with torch.no_grad():
+                dist, info = nets.policy_forward(
+                    params, torch.from_numpy(np.asarray(obs, np.float32)))
+            a = dist.mean + dist.stddev * noise[self.calls][:, :A]
+            self.calls += 1
+            return a.numpy(), {'mean': info['mean'].numpy()}
+
+    ref = osamp.OracleLocalSampler(
+        CpuPolicy(),
+        [[oenvs.SyntheticEnv(i, O, A, P, min_len=min_len, seed=123)
+          for i in range(n)]], max_episode_length=P, n_workers=1,
+        worker_class=osamp.OracleVecWorker, worker_args=dict(n_envs=n))
+    for num in (n * P, 150):
+        eps = sampler.obtain_samples(0, num, None)
+        want = ref.obtain_samples(0, num, None)
+        assert np.array_equal(eps.lengths, want.lengths)
+        assert np.array_equal([int(s) for s in eps.step_types],
+                              [int(s) for s in want.step_types])
+        assert np.array_equal(eps.observations, want.observations)  # bit exact
+        assert np.array_equal(eps.last_observations, want.last_observations)
+        assert np.allclose(eps.actions, want.actions, atol=1e-5)
+        assert np.allclose(eps.rewards, want.rewards, atol=1e-5)
+        assert np.allclose(eps.agent_infos['mean'], want.agent_infos['mean'],
+                           atol=1e-5)
+    assert sampler.total_env_steps == ref.total_env_steps
+
+
+def test_full_iteration_vs_oracle():
+    """GPU sampler -> PPO._train_once vs the oracle PPO on the same batch
+    (ragged episodes, Adam over several minibatches, numpy permutations)."""
+    from garage_amd.algos import PPO
+    from garage_amd.envs import SyntheticVecEnv
+    from garage_amd.optimizers import OptimizerWrapper
+    from garage_amd.policies import GaussianMLPPolicy, GaussianMLPValueFunction
+    from garage_amd.sampler import GpuVecSampler, GpuVecWorker
+    from oracle import batch as ob
+    from oracle.ppo import OraclePPO
+    n, O, A, P = 64, 17, 6, 32
+    torch.manual_seed(5)
+    env = SyntheticVecEnv(n, O, A, P, min_len=5, seed=7)
+    pol = GaussianMLPPolicy(env.spec, hidden_sizes=(32, 32))
+    vf = GaussianMLPValueFunction(env.spec, hidden_sizes=(32, 32))
+    with torch.no_grad():
+        vf.net.params.add_(torch.randn_like(vf.net.params) * 0.05)
+        for l in range(3):  # keep the layout contract: padded columns stay 0
+            w = vf.net.params[vf.net.w_off[l]:vf.net.b_off[l]].view(
+                vf.net.dims[l + 1], -1)
+            w[:, vf.net.dims[l]:] = 0
+    sampler = GpuVecSampler(pol, env, max_episode_length=P, n_workers=1,
+                            worker_class=GpuVecWorker,
+                            worker_args=dict(n_envs=n))
+    E, mb = 3, 200
+    algo = PPO(env_spec=env.spec, policy=pol, value_function=vf,
+               sampler=sampler,
+               policy_optimizer=OptimizerWrapper(
+                   (torch.optim.Adam, dict(lr=2.5e-4)), pol,
+                   max_optimization_epochs=E, minibatch_size=mb),
+               vf_optimizer=OptimizerWrapper(
+                   (torch.optim.Adam, dict(lr=2.5e-4)), vf,
+                   max_optimization_epochs=E, minibatch_size=mb))
+    oracle = OraclePPO(pol.state_dict(), vf.state_dict(), max_episode_length=P,
+                       max_optimization_epochs=E, minibatch_size=mb)
+    for it in range(2):
+        eps = sampler.obtain_samples(it, n * P, pol.get_param_values())
+        host = ob.OracleEpisodeBatch(
+            observations=eps.observations,
+            last_observations=eps.last_observations, actions=eps.actions,
+            rewards=eps.rewards, step_types=eps.step_types,
+            lengths=eps.lengths, max_episode_length=P)
+        np.random.seed(50 + it)
+        want = oracle.train_once(host)
+        np.random.seed(50 + it)
+        algo._train_once(it, eps)
+        got = algo.last_tabular
+        for k in LOG_KEYS:
+            assert np.isclose(got[k], want[k], atol=1e-5, rtol=1e-5), (k, it)
+        t = algo.last_tensors
+        assert np.allclose(t['returns'].cpu().numpy(), want['returns_flat'],
+                           rtol=1e-5, atol=1e-5)
+        assert np.allclose(t['advantages'].cpu().numpy(),
+                           want['advantages_flat'], rtol=1e-4, atol=1e-5)
+        wp, wv = oracle.state()
+        for k, v in pol.state_dict().items():
+            assert np.allclose(v.numpy(), wp[k], atol=1e-5), k
+        for k, v in vf.state_dict().items():
+            assert np.allclose(v.numpy(), wv[k], atol=1e-5), k
+        for k, v in algo.last_performance.items():
+            assert np.isclose(v, want['performance'][k]), k
