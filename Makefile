@@ -7,16 +7,20 @@ ARCH  ?= gfx950
 CSRC  := garage_amd/csrc
 OUT   := garage_amd/_C
 SRCS  := $(CSRC)/gae_scan.hip $(CSRC)/gemm.hip $(CSRC)/losses.hip $(CSRC)/rollout.hip
-OBJS  := $(patsubst $(CSRC)/%.hip,$(OUT)/%.o,$(SRCS)) $(OUT)/errors.o
+OBJS  := $(patsubst $(CSRC)/%.hip,$(OUT)/%.o,$(SRCS)) $(OUT)/errors.o $(OUT)/prof.o
 FLAGS := --offload-arch=$(ARCH) -O3 -fPIC -std=c++17 -Wall -Wno-unused-function
 
 all: $(OUT)/libgarage_amd.so
 
-$(OUT)/%.o: $(CSRC)/%.hip $(CSRC)/common.h
+$(OUT)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/prof.h
 	@mkdir -p $(OUT)
 	$(HIPCC) $(FLAGS) -c $< -o $@
 
 $(OUT)/errors.o: $(CSRC)/errors.cpp
+	@mkdir -p $(OUT)
+	$(HIPCC) $(FLAGS) -x hip -c $< -o $@
+
+$(OUT)/prof.o: $(CSRC)/prof.cpp $(CSRC)/prof.h
 	@mkdir -p $(OUT)
 	$(HIPCC) $(FLAGS) -x hip -c $< -o $@
 

@@ -1,0 +1,285 @@
+#!/usr/bin/env python
+"""Headline benchmark: env-steps/s of one PPO iteration (rollout + update).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one PPO iteration: a rollout of ``n_envs x T`` synthetic env steps
+through ``GpuVecSampler`` followed by one ``PPO._train_once`` (value baselines,
+GAE scan, advantage centring, E epochs x 32 minibatches of policy updates, then
+the same for the value function, diagnostics, old-policy sync) -- all of it in
+the timed region.  Weak scaling: every rank owns ``n_envs`` environments.
+Prints ONE JSON line (rank 0) with ``roofline`` (dominant kernel, HIP-event
+timed), ``roofline_gae_scan`` and ``cpu_baseline``.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # BASELINE.json configs[2]: the configuration the metric is quoted on
+    'c3': dict(name='HalfCheetah-shape synthetic', obs_dim=17, act_dim=6,
+               n_envs=4096, T=256, hidden=(256, 256), min_len=None),
+    'c2': dict(name='CartPole-shape synthetic (continuous head)', obs_dim=4,
+               act_dim=2, n_envs=4096, T=128, hidden=(64, 64), min_len=None),
+    'c5': dict(name='Humanoid-shape synthetic, ragged', obs_dim=376,
+               act_dim=17, n_envs=8192, T=256, hidden=(512, 512, 512),
+               min_len=32),
+}
+HYPER = dict(discount=0.99, gae_lambda=0.97, lr_clip_range=0.2, lr=2.5e-4,
+             epochs=10, minibatches_per_epoch=32)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
+
+KIND_NAMES = [
+    'gemm_f32_kernel<128,128,2,2,true,true> (forward)',
+    'gemm_f32_kernel<128,128,2,2,true,false> (data grad)',
+    'gemm_f32_kernel<128,128,2,2,false,false> (weight grad)',
+    'gemm_f32_kernel<256,32,4,1,true,true> (forward, narrow)',
+    'gemm_f32_kernel<256,32,4,1,true,false> (data grad, narrow)',
+    'gemm_f32_kernel<256,32,4,1,false,false> (weight grad, narrow)',
+    'gae_scan_kernel',
+]
+
+
+def build_engine(cfg, comm, seed=1):
+    from garage_amd.algos import PPO
+    from garage_amd.distributed import shard_algo
+    from garage_amd.envs import SyntheticVecEnv
+    from garage_amd.optimizers import OptimizerWrapper
+    from garage_amd.policies import GaussianMLPPolicy, GaussianMLPValueFunction
+    from garage_amd.sampler import GpuVecSampler, GpuVecWorker
+    rank = comm.rank if comm is not None else 0
+    n, T = cfg['n_envs'], cfg['T']
+    torch.manual_seed(seed)
+    env = SyntheticVecEnv(n, cfg['obs_dim'], cfg['act_dim'], T,
+                          min_len=cfg['min_len'], seed=seed, env_id0=rank * n)
+    pol = GaussianMLPPolicy(env.spec, hidden_sizes=cfg['hidden'])
+    vf = GaussianMLPValueFunction(env.spec, hidden_sizes=cfg['hidden'])
+    sampler = GpuVecSampler(pol, env, max_episode_length=T, n_workers=1,
+                            worker_class=GpuVecWorker, seed=seed + rank,
+                            worker_args=dict(n_envs=n,
+                                             store_agent_infos=False))
+    S = n * T
+    mb = S // HYPER['minibatches_per_epoch']
+    opt = (torch.optim.Adam, dict(lr=HYPER['lr']))
+    algo = PPO(env_spec=env.spec, policy=pol, value_function=vf,
+               sampler=sampler,
+               policy_optimizer=OptimizerWrapper(
+                   opt, pol, max_optimization_epochs=HYPER['epochs'],
+                   minibatch_size=mb, permutation='device',
+                   seed=2 * seed + 1000 * rank),
+               vf_optimizer=OptimizerWrapper(
+                   opt, vf, max_optimization_epochs=HYPER['epochs'],
+                   minibatch_size=mb, permutation='device',
+                   seed=2 * seed + 1 + 1000 * rank),
+               lr_clip_range=HYPER['lr_clip_range'],
+               discount=HYPER['discount'], gae_lambda=HYPER['gae_lambda'])
+    shard_algo(algo, comm)
+    return algo, sampler, pol, S
+
+
+def one_iteration(algo, sampler, pol, S, itr):
+    eps = sampler.obtain_samples(itr, S, None)
+    algo._train_once(itr, eps)
+
+
+def roofline_pass(algo, sampler, pol, S, itr):
+    """One extra, instrumented iteration: every GEMM / scan launch is bracketed
+    by HIP events on its stream (garage_amd/csrc/prof.cpp)."""
+    from garage_amd import _lib
+    lib = _lib.load()
+    lib.ga_prof_enable(1)
+    one_iteration(algo, sampler, pol, S, itr)
+    torch.cuda.synchronize()
+    lib.ga_prof_enable(0)
+    n_kinds = len(KIND_NAMES)
+    out = (C.c_double * (3 * n_kinds))()
+    lib.ga_prof_collect(out, n_kinds)
+    rows = []
+    for k in range(n_kinds):
+        ms, work, cnt = out[3 * k], out[3 * k + 1], out[3 * k + 2]
+        rows.append(dict(kernel=KIND_NAMES[k], total_ms=ms, work=work,
+                         launches=int(cnt)))
+    return rows
+
+
+def cpu_baseline(cfg, n_envs, seed=1):
+    """The oracle (CPU restatement of garage's LocalSampler/VecWorker rollout +
+    torch-CPU PPO) timed on a bounded sample of the same workload."""
+    from oracle import envs as oenvs
+    from oracle import networks as nets
+    from oracle import sampler as osamp
+    from oracle.ppo import OraclePPO
+    O, A, T = cfg['obs_dim'], cfg['act_dim'], cfg['T']
+    rng = np.random.RandomState(seed)
+    polp = nets.init_gaussian_mlp(rng, nets.POLICY_PREFIX, O, A, cfg['hidden'],
+                                  min_std=1e-6)
+    vfp = nets.init_gaussian_mlp(rng, nets.VALUE_PREFIX, O, 1, cfg['hidden'])
+    S = n_envs * T
+    mb = S // HYPER['minibatches_per_epoch']
+    algo = OraclePPO(polp, vfp, max_episode_length=T,
+                     max_optimization_epochs=HYPER['epochs'],
+                     minibatch_size=mb, policy_lr=HYPER['lr'],
+                     vf_lr=HYPER['lr'], discount=HYPER['discount'],
+                     gae_lambda=HYPER['gae_lambda'],
+                     lr_clip_range=HYPER['lr_clip_range'])
+
+    class Agent:
+
+        def reset(self, do_resets=None):
+            pass
+
+        def get_actions(self, obs):
+            with torch.no_grad():
+                dist, info = nets.policy_forward(
+                    algo.policy, torch.from_numpy(np.asarray(obs, np.float32)))
+                return dist.sample().numpy(), {
+                    k: v.numpy() for k, v in info.items()
+                }
+
+    envs = [oenvs.SyntheticEnv(i, O, A, T, min_len=cfg['min_len'], seed=seed)
+            for i in range(n_envs)]
+    sampler = osamp.OracleLocalSampler(
+        Agent(), [envs], max_episode_length=T, n_workers=1,
+        worker_class=osamp.OracleVecWorker, worker_args=dict(n_envs=n_envs))
+    np.random.seed(seed)
+    t0 = time.perf_counter()
+    batch = sampler.obtain_samples(0, S, None)
+    t1 = time.perf_counter()
+    algo.train_once(batch)
+    t2 = time.perf_counter()
+    steps = int(batch.lengths.sum())
+    return dict(value=steps / (t2 - t0), unit='env-steps/s',
+                cores=torch.get_num_threads(), kind='port',
+                sample='{} envs x T={} ({} steps), same PPO hyper-parameters '
+                '(E={}, {} minibatches/epoch); rollout {:.2f} s + update '
+                '{:.2f} s; host has {} logical CPUs'.format(
+                    n_envs, T, steps, HYPER['epochs'],
+                    HYPER['minibatches_per_epoch'], t1 - t0, t2 - t1,
+                    os.cpu_count()))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--config', default='c3', choices=sorted(CONFIGS))
+    ap.add_argument('--cpu-envs', type=int, default=256,
+                    help='envs of the bounded CPU-baseline sample (0: skip)')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    from garage_amd.distributed import init_from_env
+    comm = init_from_env()
+    world = comm.world_size if comm is not None else 1
+    rank = comm.rank if comm is not None else 0
+    if world != args.gpus and rank == 0:
+        print('warning: --gpus {} but WORLD_SIZE {}'.format(args.gpus, world),
+              file=sys.stderr)
+    cfg = CONFIGS[args.config]
+    algo, sampler, pol, S = build_engine(cfg, comm)
+
+    def sync():
+        if comm is not None:
+            comm.barrier()
+        torch.cuda.synchronize()
+
+    itr = 0
+    for _ in range(args.warmup):
+        one_iteration(algo, sampler, pol, S, itr)
+        itr += 1
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_iteration(algo, sampler, pol, S, itr)
+        itr += 1
+    sync()
+    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64,
+                           device='cuda')
+    if comm is not None:
+        comm.all_reduce(elapsed, 'max')
+    elapsed = float(elapsed.item())
+
+    rows = None
+    if not args.no_roofline:
+        rows = roofline_pass(algo, sampler, pol, S, itr)
+    if rank != 0:
+        return
+    ms_per_step = elapsed / args.steps * 1e3
+    value = S * world * args.steps / elapsed
+    line = {
+        'metric': 'env-steps/sec (whole node) PPO 4096 envs',
+        'value': value,
+        'unit': 'env-steps/s',
+        'n_gpus': world,
+        'steps': args.steps,
+        'warmup': args.warmup,
+        'ms_per_step': ms_per_step,
+        'higher_is_better': True,
+        'scaling': 'weak',
+        'vs_baseline': None,
+        'dtype': 'f32',
+        'data': 'synthetic',
+        'config': {
+            'workload': '{}: obs {} act {} Gaussian, {} envs/GPU x T={}, '
+                        'MLP{} policy + value, PPO E={} x {} minibatches, '
+                        'gamma {} lambda {} clip {} Adam lr {}, device '
+                        'minibatch permutation'.format(
+                            cfg['name'], cfg['obs_dim'], cfg['act_dim'],
+                            cfg['n_envs'], cfg['T'], cfg['hidden'],
+                            HYPER['epochs'], HYPER['minibatches_per_epoch'],
+                            HYPER['discount'], HYPER['gae_lambda'],
+                            HYPER['lr_clip_range'], HYPER['lr']),
+            'config_id': args.config,
+            'parallelism': 'dp{}'.format(world),
+        },
+    }
+    if rows is not None:
+        gemms = [r for r in rows[:6] if r['launches'] > 0]
+        dom = max(gemms, key=lambda r: r['total_ms'])
+        tflops = dom['work'] / (dom['total_ms'] * 1e-3) / 1e12
+        line['roofline'] = {
+            'kernel': dom['kernel'], 'bound': 'mfma', 'achieved': tflops,
+            'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': tflops / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
+            'launches_per_iteration': dom['launches'],
+            'avg_launch_us': dom['total_ms'] * 1e3 / dom['launches'],
+            'share_of_iteration': dom['total_ms'] / ms_per_step,
+        }
+        scan = rows[6]
+        if scan['launches'] > 0:
+            gbs = scan['work'] / (scan['total_ms'] * 1e-3) / 1e9
+            line['roofline_gae_scan'] = {
+                'kernel': scan['kernel'], 'bound': 'hbm', 'achieved': gbs,
+                'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                'frac': gbs / PEAK_HBM_GBS, 'traffic': None,
+                'avg_launch_us': scan['total_ms'] * 1e3 / scan['launches'],
+                'bytes_per_launch': scan['work'] / scan['launches'],
+            }
+        line['kernels'] = [
+            dict(kernel=r['kernel'], launches=r['launches'],
+                 total_ms=round(r['total_ms'], 3),
+                 avg_us=round(r['total_ms'] * 1e3 / max(1, r['launches']), 2))
+            for r in rows if r['launches'] > 0
+        ]
+    if args.cpu_envs > 0 and world == 1:
+        line['cpu_baseline'] = cpu_baseline(cfg, args.cpu_envs)
+    print(json.dumps(line))
+
+
+if __name__ == '__main__':
+    main()

@@ -95,6 +95,8 @@ SIGNATURES = {
     'ga_gather_u8': (c_int, [ptr, ptr, c_i64, ptr, ptr]),
     'ga_permutation_i32': (c_int, [c_i64, c_u64, ptr, ptr]),
     'ga_episode_sums_f32': (c_int, [ptr, ptr, c_i64, ptr, ptr]),
+    'ga_prof_enable': (c_int, [c_int]),
+    'ga_prof_collect': (c_int, [C.POINTER(c_f64), c_int]),
 }
 
 

@@ -23,6 +23,7 @@
 //
 // Algorithmic HBM bytes: 16 per step (r, V in; A, G out) (+2 for the tail flag).
 #include "common.h"
+#include "prof.h"
 
 namespace {
 
@@ -248,6 +249,7 @@ extern "C" int ga_gae_scan_f32(const float* rewards, const float* values,
   } else {
     GA_REQUIRE(max_len >= 0, "ga_gae_scan_f32: max_len required with offsets");
   }
+  const int64_t prof_steps = T;  // packed mode: callers pass the total step count in T
   if (n_rows == 0 || max_len == 0) return GA_OK;
 
   int lpr = 1;
@@ -275,12 +277,17 @@ extern "C" int ga_gae_scan_f32(const float* rewards, const float* values,
                    ga_aligned16(values) && ga_aligned16(adv) && ga_aligned16(ret) &&
                    (!bonus || ga_aligned16(bonus)) &&
                    (!tail || (reinterpret_cast<uintptr_t>(tail) & 7u) == 0);
+  // algorithmic bytes: 16 per step (r, V in; A, G out)
+  const double steps = offsets ? 0.0 : (double)n_rows * (double)T;
+  const int slot = ga_prof_begin(GA_PROF_GAE_SCAN,
+                                 16.0 * (offsets ? (double)prof_steps : steps), stream);
   if (vec)
     hipLaunchKernelGGL(gae_scan_kernel<true>, dim3((unsigned)blocks), dim3(256), 0,
                        stream, p);
   else
     hipLaunchKernelGGL(gae_scan_kernel<false>, dim3((unsigned)blocks), dim3(256),
                        0, stream, p);
+  ga_prof_end(slot, stream);
   GA_CHECK_LAUNCH("ga_gae_scan_f32");
   return GA_OK;
 }

@@ -19,6 +19,7 @@
 // MFMA A operand of lane l is tile[2*kk + (l >> 5)][row0 + (l & 31)] and B is
 // read the same way, one ds_read_b32 each.
 #include "common.h"
+#include "prof.h"
 
 namespace {
 
@@ -237,16 +238,23 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
 
 template <bool A_KC, bool B_KC>
 int launch_gemm(const GemmParams& p, int splits, hipStream_t stream) {
+  const int mode = (A_KC && B_KC) ? 0 : (A_KC ? 1 : 2);
+  // algorithmic flops: 2 M N K (the padding of ragged tiles is not counted)
+  const double flops = 2.0 * (double)p.M * (double)p.N * (double)p.K;
   if (p.N <= 32) {
     dim3 grid((unsigned)ga_ceil_div(p.M, 256), (unsigned)ga_ceil_div(p.N, 32),
               (unsigned)splits);
+    const int slot = ga_prof_begin(GA_PROF_GEMM_NT_256 + mode, flops, stream);
     hipLaunchKernelGGL((gemm_f32_kernel<256, 32, 4, 1, A_KC, B_KC>), grid,
                        dim3(256), 0, stream, p);
+    ga_prof_end(slot, stream);
   } else {
     dim3 grid((unsigned)ga_ceil_div(p.M, 128), (unsigned)ga_ceil_div(p.N, 128),
               (unsigned)splits);
+    const int slot = ga_prof_begin(GA_PROF_GEMM_NT_128 + mode, flops, stream);
     hipLaunchKernelGGL((gemm_f32_kernel<128, 128, 2, 2, A_KC, B_KC>), grid,
                        dim3(256), 0, stream, p);
+    ga_prof_end(slot, stream);
   }
   GA_CHECK_LAUNCH("gemm_f32");
   return GA_OK;

@@ -1,0 +1,73 @@
+// Optional per-launch timing with HIP events (used by bench.py's roofline leg).
+// Disabled by default: ga_prof_begin() is then a single branch.  Events are
+// recorded on the stream the kernel is launched on, so the elapsed time is the
+// kernel's duration on the device (plus ~1-2 us of event overhead).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <vector>
+
+#include "prof.h"
+
+namespace {
+struct Sample {
+  hipEvent_t start, stop;
+  int kind;
+  double work;
+};
+bool g_on = false;
+std::vector<Sample> g_samples;
+std::vector<hipEvent_t> g_pool;
+constexpr size_t kMaxSamples = 200000;
+
+hipEvent_t get_event() {
+  if (!g_pool.empty()) {
+    hipEvent_t e = g_pool.back();
+    g_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  (void)hipEventCreate(&e);
+  return e;
+}
+}  // namespace
+
+int ga_prof_begin(int kind, double work, hipStream_t stream) {
+  if (!g_on || g_samples.size() >= kMaxSamples) return -1;
+  Sample s;
+  s.start = get_event();
+  s.stop = get_event();
+  s.kind = kind;
+  s.work = work;
+  (void)hipEventRecord(s.start, stream);
+  g_samples.push_back(s);
+  return (int)g_samples.size() - 1;
+}
+
+void ga_prof_end(int slot, hipStream_t stream) {
+  if (slot < 0) return;
+  (void)hipEventRecord(g_samples[slot].stop, stream);
+}
+
+extern "C" int ga_prof_enable(int on) {
+  g_on = on != 0;
+  return 0;
+}
+
+// out[kind * 3 + {0,1,2}] = {total milliseconds, total work, launches}
+extern "C" int ga_prof_collect(double* out_host, int n_kinds) {
+  for (int i = 0; i < n_kinds * 3; ++i) out_host[i] = 0.0;
+  for (auto& s : g_samples) {
+    (void)hipEventSynchronize(s.stop);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, s.start, s.stop);
+    if (s.kind >= 0 && s.kind < n_kinds) {
+      out_host[s.kind * 3 + 0] += (double)ms;
+      out_host[s.kind * 3 + 1] += s.work;
+      out_host[s.kind * 3 + 2] += 1.0;
+    }
+    g_pool.push_back(s.start);
+    g_pool.push_back(s.stop);
+  }
+  g_samples.clear();
+  return 0;
+}

@@ -206,7 +206,7 @@ def gae_scan(rewards, values, *, discount, gae_lambda, max_episode_length,
     """
     if offsets is not None:
         n_rows = offsets.numel() - 1
-        T, ld = 0, 0
+        T, ld = rewards.numel(), 0  # packed: T carries the total step count
         if max_len is None:
             raise ValueError('max_len is required with offsets')
     else:

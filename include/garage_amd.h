@@ -205,6 +205,16 @@ int ga_permutation_i32(int64_t n, uint64_t key, int32_t* out, ga_stream_t stream
 int ga_episode_sums_f32(const float* rewards, const int64_t* ep_off, int64_t n_eps,
                         double* sums, ga_stream_t stream);
 
+/* ---- measurement ----------------------------------------------------------
+ * Optional HIP-event timing of every GEMM / scan launch on its own stream
+ * (bench.py's roofline leg; no reference counterpart).  kinds: 0..2 =
+ * gemm_f32_kernel<128,128,..> forward / data-grad / weight-grad, 3..5 = the
+ * <256,32,..> variants, 6 = gae_scan_kernel.  ga_prof_collect synchronises and
+ * fills out_host[kind*3 + {0,1,2}] = {total ms, total flops or bytes, launches}
+ * (a HOST pointer). */
+int ga_prof_enable(int on);
+int ga_prof_collect(double* out_host, int n_kinds);
+
 #ifdef __cplusplus
 }
 #endif
