@@ -40,6 +40,7 @@ CONFIGS = {
 HYPER = dict(discount=0.99, gae_lambda=0.97, lr_clip_range=0.2, lr=2.5e-4,
              epochs=10, minibatches_per_epoch=32)
 
+CPU_THREADS = int(os.environ.get('GARAGE_AMD_CPU_THREADS', '16'))
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
 
@@ -47,9 +48,9 @@ KIND_NAMES = [
     'gemm_f32_kernel<128,128,2,2,true,true> (forward)',
     'gemm_f32_kernel<128,128,2,2,true,false> (data grad)',
     'gemm_f32_kernel<128,128,2,2,false,false> (weight grad)',
-    'gemm_f32_kernel<256,32,4,1,true,true> (forward, narrow)',
-    'gemm_f32_kernel<256,32,4,1,true,false> (data grad, narrow)',
-    'gemm_f32_kernel<256,32,4,1,false,false> (weight grad, narrow)',
+    'gemm_f32_kernel<128,32,4,1,true,true> (forward, narrow)',
+    'gemm_f32_kernel<128,32,4,1,true,false> (data grad, narrow)',
+    'gemm_f32_kernel<128,32,4,1,false,false> (weight grad, narrow)',
     'gae_scan_kernel',
 ]
 
@@ -124,6 +125,9 @@ def cpu_baseline(cfg, n_envs, seed=1):
     from oracle import sampler as osamp
     from oracle.ppo import OraclePPO
     O, A, T = cfg['obs_dim'], cfg['act_dim'], cfg['T']
+    # a one-GPU box owns a 16-CPU share of the host; torch's default (one
+    # thread per logical CPU of the whole machine) oversubscribes it badly
+    torch.set_num_threads(max(1, min(CPU_THREADS, os.cpu_count() or 1)))
     rng = np.random.RandomState(seed)
     polp = nets.init_gaussian_mlp(rng, nets.POLICY_PREFIX, O, A, cfg['hidden'],
                                   min_std=1e-6)

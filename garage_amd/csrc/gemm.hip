@@ -242,10 +242,12 @@ int launch_gemm(const GemmParams& p, int splits, hipStream_t stream) {
   // algorithmic flops: 2 M N K (the padding of ragged tiles is not counted)
   const double flops = 2.0 * (double)p.M * (double)p.N * (double)p.K;
   if (p.N <= 32) {
-    dim3 grid((unsigned)ga_ceil_div(p.M, 256), (unsigned)ga_ceil_div(p.N, 32),
+    // narrow outputs are HBM bound on the wide operand: 128-row tiles give
+    // M/128 workgroups (256 at the C3 minibatch) to pull it through
+    dim3 grid((unsigned)ga_ceil_div(p.M, 128), (unsigned)ga_ceil_div(p.N, 32),
               (unsigned)splits);
     const int slot = ga_prof_begin(GA_PROF_GEMM_NT_256 + mode, flops, stream);
-    hipLaunchKernelGGL((gemm_f32_kernel<256, 32, 4, 1, A_KC, B_KC>), grid,
+    hipLaunchKernelGGL((gemm_f32_kernel<128, 32, 4, 1, A_KC, B_KC>), grid,
                        dim3(256), 0, stream, p);
     ga_prof_end(slot, stream);
   } else {
@@ -333,9 +335,11 @@ extern "C" int64_t ga_mlp_backward_splits(const ga_mlp_desc* d, int64_t M) {
   (void)d;
   // Rows of the batch each weight-gradient workgroup reduces before writing a
   // slab: large enough to amortise the slab write, small enough to fill 256 CUs.
-  int64_t s = ga_ceil_div(M, 1024);
+  // 256 rows per slab: the widest layer (256x256 -> 2x2 tiles) then launches
+  // 4 * M/256 workgroups, i.e. 512 at the C3 minibatch of 32768 rows.
+  int64_t s = ga_ceil_div(M, 256);
   if (s < 1) s = 1;
-  if (s > 64) s = 64;
+  if (s > 128) s = 128;
   return s;
 }
 

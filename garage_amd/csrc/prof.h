@@ -6,9 +6,9 @@ enum GaProfKind {
   GA_PROF_GEMM_NT_128 = 0,  // gemm_f32_kernel<128,128,2,2,true,true>   forward
   GA_PROF_GEMM_NN_128 = 1,  // gemm_f32_kernel<128,128,2,2,true,false>  data grad
   GA_PROF_GEMM_TN_128 = 2,  // gemm_f32_kernel<128,128,2,2,false,false> weight grad
-  GA_PROF_GEMM_NT_256 = 3,  // gemm_f32_kernel<256,32,4,1,true,true>
-  GA_PROF_GEMM_NN_256 = 4,  // gemm_f32_kernel<256,32,4,1,true,false>
-  GA_PROF_GEMM_TN_256 = 5,  // gemm_f32_kernel<256,32,4,1,false,false>
+  GA_PROF_GEMM_NT_256 = 3,  // gemm_f32_kernel<128,32,4,1,true,true>
+  GA_PROF_GEMM_NN_256 = 4,  // gemm_f32_kernel<128,32,4,1,true,false>
+  GA_PROF_GEMM_TN_256 = 5,  // gemm_f32_kernel<128,32,4,1,false,false>
   GA_PROF_GAE_SCAN = 6,     // gae_scan_kernel<*>
   GA_PROF_KINDS = 7
 };
