@@ -229,11 +229,21 @@ class VPG:
         bonus = 0.0
         if self._maximum_entropy:  # vpg.py:158-160, padded cells included
             bonus = self._policy_ent_coeff * self._entropy_value()
-        adv, returns = gae_scan(
-            batch.rewards_dev, values.view(-1), discount=self._discount,
-            gae_lambda=self._gae_lambda, max_episode_length=P,
-            offsets=batch.ep_off_dev, max_len=int(lengths.max()), v0=v0,
-            bonus_const=bonus)
+        longest = int(lengths.max())
+        if int(lengths.min()) == longest:
+            # equal-length episodes: the packed batch IS an (N, L) matrix, no
+            # offsets to chase (one dependent load less per wave)
+            adv, returns = gae_scan(
+                batch.rewards_dev.view(-1, longest), values.view(-1, longest),
+                discount=self._discount, gae_lambda=self._gae_lambda,
+                max_episode_length=P, v0=v0, bonus_const=bonus)
+            adv, returns = adv.view(-1), returns.view(-1)
+        else:
+            adv, returns = gae_scan(
+                batch.rewards_dev, values.view(-1), discount=self._discount,
+                gae_lambda=self._gae_lambda, max_episode_length=P,
+                offsets=batch.ep_off_dev, max_len=longest, v0=v0,
+                bonus_const=bonus)
         self._normalise_advantages(adv)
 
         # ---- diagnostics before the update (vpg.py:168-173) -----------------

@@ -63,13 +63,17 @@ __device__ double padded_tail_carry(const ScanParams& p, int L, double* boot) {
   }
   *boot = p.v0;
   const double pad_delta = p.bonus_const + (p.gamma - 1.0) * p.v0;
-  const double cm1 = pow(p.c, (double)(m - 1));
+  double cm1 = 1.0, base = p.c;  // c^(m-1) by squaring: cheap in registers
+  for (int e = m - 1; e > 0; e >>= 1) {
+    if (e & 1) cm1 *= base;
+    base *= base;
+  }
   const double geo = (p.c == 1.0) ? (double)(m - 1) : (1.0 - cm1) / (1.0 - p.c);
   return pad_delta * geo + cm1 * (p.bonus_const - p.v0);
 }
 
 template <bool VEC>
-__global__ __launch_bounds__(256) void gae_scan_kernel(ScanParams p) {
+__global__ __launch_bounds__(256, 4) void gae_scan_kernel(ScanParams p) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lpr = p.lpr;
@@ -142,37 +146,38 @@ __global__ __launch_bounds__(256) void gae_scan_kernel(ScanParams p) {
     if (sub == lpr - 1) vright = vnext_chunk;
 
     // Per-step affine maps  y_t = x_t + d_t * y_{t+1}.
-    double xa[4], da[4], xg[4], dg[4];
+    // Per-step affine maps  y_t = x_t + d_t * y_{t+1}; d_t is one of three
+    // values, so only the offsets are kept in (fp64) registers.
+    double xa[4];
+    int kind[4];  // 0: beyond the row (identity), 1: episode end, 2: ordinary
 #pragma unroll
     for (int j = 3; j >= 0; --j) {
       const bool valid = active && (i0 + j < len);
       const double vn = (j == 3) ? vright : (double)v[j + 1];
-      const double rj = (double)r[j];
-      const double rb = rj + p.bonus_const + (double)b[j];
+      const double rb = (double)r[j] + p.bonus_const + (double)b[j];
       if (!valid) {
-        xa[j] = 0.0; da[j] = 1.0; xg[j] = 0.0; dg[j] = 1.0;
+        xa[j] = 0.0;
+        kind[j] = 0;
       } else if (tl[j] > 0) {
         double boot;
         const double c0 = padded_tail_carry(p, tl[j], &boot);
         xa[j] = rb + p.gamma * boot - (double)v[j] + p.c * c0;
-        da[j] = 0.0;
-        xg[j] = rj;
-        dg[j] = 0.0;
+        kind[j] = 1;
       } else {
         xa[j] = rb + p.gamma * vn - (double)v[j];
-        da[j] = p.c;
-        xg[j] = rj;
-        dg[j] = p.gamma_ret;
+        kind[j] = 2;
       }
     }
     // Compose the lane's four maps (right to left).
     Pair A = {1.0, 0.0}, G = {1.0, 0.0};
 #pragma unroll
     for (int j = 3; j >= 0; --j) {
-      A.x = xa[j] + da[j] * A.x;
-      A.d = da[j] * A.d;
-      G.x = xg[j] + dg[j] * G.x;
-      G.d = dg[j] * G.d;
+      const double da = kind[j] == 2 ? p.c : (kind[j] == 1 ? 0.0 : 1.0);
+      const double dg = kind[j] == 2 ? p.gamma_ret : (kind[j] == 1 ? 0.0 : 1.0);
+      A.x = xa[j] + da * A.x;
+      A.d = da * A.d;
+      G.x = (double)r[j] + dg * G.x;
+      G.d = dg * G.d;
     }
     // Inclusive suffix scan over the row group.
     for (int o = 1; o < lpr; o <<= 1) {
@@ -196,8 +201,10 @@ __global__ __launch_bounds__(256) void gae_scan_kernel(ScanParams p) {
     float oa[4], og[4];
 #pragma unroll
     for (int j = 3; j >= 0; --j) {
-      ya = xa[j] + da[j] * ya;
-      yg = xg[j] + dg[j] * yg;
+      const double da = kind[j] == 2 ? p.c : (kind[j] == 1 ? 0.0 : 1.0);
+      const double dg = kind[j] == 2 ? p.gamma_ret : (kind[j] == 1 ? 0.0 : 1.0);
+      ya = xa[j] + da * ya;
+      yg = (double)r[j] + dg * yg;
       oa[j] = (float)ya;
       og[j] = (float)yg;
     }

@@ -246,15 +246,45 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* slabs,
                                                            int64_t n_splits,
                                                            int64_t stride, int64_t n,
                                                            float* out, float scale) {
-  const int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-  if (i4 >= n) return;  // n is a multiple of 4 (flat buffers are padded)
+  // 64 float4 columns x 4 slab groups per block: 4x the workgroups of a
+  // column-per-thread layout and 4 independent 16-B loads in flight per thread;
+  // the groups are combined through LDS in a fixed order (deterministic).
+  __shared__ float4 part[4][64];
+  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int64_t i4 = ((int64_t)blockIdx.x * 64 + col) * 4;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int64_t s = 0; s < n_splits; ++s) {
-    const float4 v = *reinterpret_cast<const float4*>(slabs + s * stride + i4);
-    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  if (i4 < n) {  // n is a multiple of 4 (flat buffers are padded)
+    int64_t s = grp;
+    for (; s + 12 < n_splits; s += 16) {
+      const float4 v0 = *reinterpret_cast<const float4*>(slabs + s * stride + i4);
+      const float4 v1 =
+          *reinterpret_cast<const float4*>(slabs + (s + 4) * stride + i4);
+      const float4 v2 =
+          *reinterpret_cast<const float4*>(slabs + (s + 8) * stride + i4);
+      const float4 v3 =
+          *reinterpret_cast<const float4*>(slabs + (s + 12) * stride + i4);
+      acc.x += (v0.x + v1.x) + (v2.x + v3.x);
+      acc.y += (v0.y + v1.y) + (v2.y + v3.y);
+      acc.z += (v0.z + v1.z) + (v2.z + v3.z);
+      acc.w += (v0.w + v1.w) + (v2.w + v3.w);
+    }
+    for (; s < n_splits; s += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(slabs + s * stride + i4);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
   }
-  acc.x *= scale; acc.y *= scale; acc.z *= scale; acc.w *= scale;
-  *reinterpret_cast<float4*>(out + i4) = acc;
+  part[grp][col] = acc;
+  __syncthreads();
+  if (grp == 0 && i4 < n) {
+    const float4 a = part[0][col], b = part[1][col], c = part[2][col],
+                 d = part[3][col];
+    float4 r;
+    r.x = ((a.x + b.x) + (c.x + d.x)) * scale;
+    r.y = ((a.y + b.y) + (c.y + d.y)) * scale;
+    r.z = ((a.z + b.z) + (c.z + d.z)) * scale;
+    r.w = ((a.w + b.w) + (c.w + d.w)) * scale;
+    *reinterpret_cast<float4*>(out + i4) = r;
+  }
 }
 
 struct AdamParams {
@@ -447,7 +477,7 @@ extern "C" int ga_reduce_slabs_f32(const float* slabs, int64_t n_splits,
              "ga_reduce_slabs_f32: n and stride must be multiples of 4");
   GA_REQUIRE(ga_aligned16(slabs) && ga_aligned16(out),
              "ga_reduce_slabs_f32: 16-B alignment required");
-  const int64_t nb = ga_ceil_div(n / 4, 256);
+  const int64_t nb = ga_ceil_div(n / 4, 64);
   hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)nb), dim3(256), 0, stream,
                      slabs, n_splits, slab_stride, n, out, scale);
   GA_CHECK_LAUNCH("reduce_slabs");
