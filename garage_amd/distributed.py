@@ -54,9 +54,13 @@ def init_from_env(backend=None):
         return None
     local_rank = int(os.environ.get('LOCAL_RANK', os.environ.get('RANK', '0')))
     if backend is None:
-        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
-    if backend == 'nccl':
-        torch.cuda.set_device(local_rank)
+        backend = os.environ.get(
+            'GARAGE_AMD_BACKEND',
+            'nccl' if torch.cuda.is_available() else 'gloo')
+    if torch.cuda.is_available():
+        # one rank per GPU; with fewer GPUs than ranks (a gloo rehearsal on a
+        # one-GPU box) ranks share devices round-robin
+        torch.cuda.set_device(local_rank % torch.cuda.device_count())
     if not dist.is_initialized():
         dist.init_process_group(backend=backend)
     return Comm()
