@@ -6,8 +6,9 @@ HIPCC ?= /opt/rocm/bin/hipcc
 ARCH  ?= gfx950
 CSRC  := garage_amd/csrc
 OUT   := garage_amd/_C
-SRCS  := $(CSRC)/gae_scan.hip $(CSRC)/gemm.hip $(CSRC)/losses.hip $(CSRC)/rollout.hip
-OBJS  := $(patsubst $(CSRC)/%.hip,$(OUT)/%.o,$(SRCS)) $(OUT)/errors.o $(OUT)/prof.o
+HIPS  := gae_scan gemm losses rollout
+CPPS  := errors prof update comm
+OBJS  := $(patsubst %,$(OUT)/%.o,$(HIPS) $(CPPS))
 FLAGS := --offload-arch=$(ARCH) -O3 -fPIC -std=c++17 -Wall -Wno-unused-function
 
 all: $(OUT)/libgarage_amd.so
@@ -16,16 +17,12 @@ $(OUT)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/prof.h
 	@mkdir -p $(OUT)
 	$(HIPCC) $(FLAGS) -c $< -o $@
 
-$(OUT)/errors.o: $(CSRC)/errors.cpp
-	@mkdir -p $(OUT)
-	$(HIPCC) $(FLAGS) -x hip -c $< -o $@
-
-$(OUT)/prof.o: $(CSRC)/prof.cpp $(CSRC)/prof.h
+$(OUT)/%.o: $(CSRC)/%.cpp $(CSRC)/prof.h include/garage_amd.h
 	@mkdir -p $(OUT)
 	$(HIPCC) $(FLAGS) -x hip -c $< -o $@
 
 $(OUT)/libgarage_amd.so: $(OBJS)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(OBJS) -o $@
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(OBJS) -ldl -o $@
 
 clean:
 	rm -rf $(OUT)/*.o $(OUT)/*.so

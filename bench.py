@@ -45,9 +45,9 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
 
 KIND_NAMES = [
-    'gemm_f32_kernel<128,128,2,2,true,true> (forward)',
-    'gemm_f32_kernel<128,128,2,2,true,false> (data grad)',
-    'gemm_f32_kernel<128,128,2,2,false,false> (weight grad)',
+    'gemm_f32_kernel<128,128,2,4,true,true> (forward)',
+    'gemm_f32_kernel<128,128,2,4,true,false> (data grad)',
+    'gemm_f32_kernel<128,128,2,4,false,false> (weight grad)',
     'gemm_f32_kernel<128,32,4,1,true,true> (forward, narrow)',
     'gemm_f32_kernel<128,32,4,1,true,false> (data grad, narrow)',
     'gemm_f32_kernel<128,32,4,1,false,false> (weight grad, narrow)',

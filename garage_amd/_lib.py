@@ -50,6 +50,24 @@ class RecordArgs(C.Structure):
                 ('done', ptr), ('step_eps', ptr), ('step_samples', ptr)]
 
 
+class UpdateArgs(C.Structure):
+    """``ga_update_args``."""
+    _fields_ = [('desc', C.POINTER(MlpDesc)), ('params', ptr), ('grads', ptr),
+                ('exp_avg', ptr), ('exp_avg_sq', ptr), ('n_flat', c_i64),
+                ('acts', ptr), ('dacts', ptr), ('out', ptr), ('dout', ptr),
+                ('ldo', c_i64), ('slabs', ptr), ('max_splits', c_i64),
+                ('step0', c_i64), ('lr', c_f64), ('beta1', c_f64),
+                ('beta2', c_f64), ('eps', c_f64), ('learn_std', c_i32),
+                ('X', ptr), ('ldx', c_i64), ('S', c_i64), ('perm', ptr),
+                ('mb', c_i64), ('kind', c_i32), ('actions', ptr),
+                ('lda', c_i64), ('old_ll', ptr), ('adv', ptr),
+                ('returns', ptr), ('has_min', c_i32), ('min_log_std', c_f32),
+                ('has_max', c_i32), ('max_log_std', c_f32), ('algo', c_i32),
+                ('clip', c_f32), ('ent_coeff', c_f32), ('ent_flags', c_i32),
+                ('losses', ptr), ('loss_scratch', ptr), ('workspace', ptr),
+                ('comm', ptr), ('world', c_i32)]
+
+
 # name -> (restype, argtypes); mirrors include/garage_amd.h one to one.
 SIGNATURES = {
     'ga_abi_version': (c_int, []),
@@ -95,6 +113,11 @@ SIGNATURES = {
     'ga_gather_u8': (c_int, [ptr, ptr, c_i64, ptr, ptr]),
     'ga_permutation_i32': (c_int, [c_i64, c_u64, ptr, ptr]),
     'ga_episode_sums_f32': (c_int, [ptr, ptr, c_i64, ptr, ptr]),
+    'ga_update_epoch': (c_int, [C.POINTER(UpdateArgs), ptr]),
+    'ga_comm_unique_id': (c_int, [ptr]),
+    'ga_comm_init_rank': (ptr, [ptr, c_int, c_int]),
+    'ga_comm_allreduce_sum_f32': (c_int, [ptr, ptr, c_i64, ptr]),
+    'ga_comm_destroy': (c_int, [ptr]),
     'ga_prof_enable': (c_int, [c_int]),
     'ga_prof_collect': (c_int, [C.POINTER(c_f64), c_int]),
 }

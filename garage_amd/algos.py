@@ -359,10 +359,81 @@ class VPG:
     # -- the update (vpg.py:230-293) -------------------------------------------
     def _train(self, batch, adv, returns, old_ll):
         S = batch.n_samples
+        if self._native_update_ok():
+            self._train_native(self._policy_optimizer, self.policy, 0, batch,
+                               adv, returns, old_ll)
+            self._train_native(self._vf_optimizer, self._value_function, 1,
+                               batch, adv, returns, old_ll)
+            return
         for idx in self._policy_optimizer.minibatch_indices(S):
             self._train_policy(batch, adv, old_ll, idx)
         for idx in self._vf_optimizer.minibatch_indices(S):
             self._train_value_function(batch, returns, idx)
+
+    def _native_update_ok(self):
+        """The C++ epoch loop (``ga_update_epoch``) replaces the Python loop
+        unless a subclass hooks the per-minibatch methods or the ranks exchange
+        gradients through a backend the library cannot call (gloo)."""
+        cls = type(self)
+        if (cls._train_policy is not VPG._train_policy
+                or cls._train_value_function is not VPG._train_value_function):
+            return False
+        for opt in (self._policy_optimizer, self._vf_optimizer):
+            if opt.grad_hook is not None and getattr(opt, 'native_comm',
+                                                     None) is None:
+                return False
+        return True
+
+    def _train_native(self, opt, module, kind, batch, adv, returns, old_ll):
+        from garage_amd import _lib
+        import ctypes as C
+        net = module.net
+        S = batch.n_samples
+        mb = opt._minibatch_size
+        net._workspace(S if mb is None else min(S, mb))
+        dev = net.device
+        a = _lib.UpdateArgs()
+        a.desc = C.pointer(net._desc)
+        a.params, a.grads = net.params.data_ptr(), net.grads.data_ptr()
+        a.exp_avg = net.exp_avg.data_ptr()
+        a.exp_avg_sq = net.exp_avg_sq.data_ptr()
+        a.n_flat = net.n_flat
+        a.acts, a.dacts = net._acts.data_ptr(), net._dacts.data_ptr()
+        a.out, a.dout = net._out.data_ptr(), net._dout.data_ptr()
+        a.ldo = net.ld_out
+        a.slabs, a.max_splits = net._slabs.data_ptr(), int(net._splits)
+        h = opt._hyper
+        a.lr, a.beta1, a.beta2, a.eps = (float(h['lr']), float(h['betas'][0]),
+                                         float(h['betas'][1]), float(h['eps']))
+        a.learn_std = int(getattr(module, '_learn_std', True))
+        a.X, a.ldx, a.S = (batch.obs_dev.data_ptr(), batch.obs_dev.stride(0),
+                           S)
+        a.mb = 0 if mb is None else int(mb)
+        a.kind = kind
+        if kind == 0:
+            a.actions = batch.actions_dev.data_ptr()
+            a.lda = batch.actions_dev.stride(0)
+            a.old_ll, a.adv = old_ll.data_ptr(), adv.data_ptr()
+            a.has_min, a.min_log_std, a.has_max, a.max_log_std = \
+                module._std_args()
+            a.algo = self._algo_id
+            a.clip = float(self._lr_clip_range)
+            a.ent_coeff = float(self._policy_ent_coeff)
+            a.ent_flags = self._ent_flags()
+        else:
+            a.returns = returns.data_ptr()
+        scratch = torch.empty(1, dtype=torch.float32, device=dev)
+        a.loss_scratch = scratch.data_ptr()
+        a.workspace = reduction_workspace(dev).data_ptr()
+        comm = getattr(opt, 'native_comm', None)
+        if comm is not None:
+            a.comm, a.world = comm.handle, comm.world_size
+        n_mb = 1 if mb is None else -(-S // mb)
+        for perm in opt.epoch_permutations(S):
+            a.perm = None if perm is None else perm.data_ptr()
+            a.step0 = net.adam_steps
+            call('ga_update_epoch', C.byref(a), stream_ptr())
+            net.adam_steps += n_mb
 
     def _train_policy(self, batch, adv, old_ll, idx):
         M = batch.n_samples if idx is None else int(idx.numel())

@@ -68,9 +68,9 @@ struct GemmParams {
 // a load inside a data-dependent branch makes hipcc wait vmcnt(0) right behind
 // it, which serialises the whole tile fetch in front of the MFMAs.  The gathered
 // line numbers (`idx`) are fetched one tile ahead for the same reason.
-template <int BR, bool KC>
+template <int BR, bool KC, int NT>
 struct TileLoader {
-  static constexpr int NV = BR * BK / 4 / 256;  // float4 per thread
+  static constexpr int NV = BR * BK / 4 / NT;  // float4 per thread
   static constexpr int VPL = BR / 4;            // vectors per line (KC = false)
   float4 regs[NV];
   int32_t cur[NV];  // memory line (after the optional gather) of each vector
@@ -83,7 +83,7 @@ struct TileLoader {
     int want[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int f = tid + 256 * i;
+      const int f = tid + NT * i;
       want[i] = KC ? min(r0 + (f >> 3), R - 1) : min(kbeg + f / VPL, kend - 1);
       want[i] = max(want[i], 0);
     }
@@ -104,11 +104,11 @@ struct TileLoader {
     if (idx) {
 #pragma unroll
       for (int i = 0; i < NV; ++i)
-        nxt[i] = idx[max(min(k0 + (tid + 256 * i) / VPL, kend - 1), 0)];
+        nxt[i] = idx[max(min(k0 + (tid + NT * i) / VPL, kend - 1), 0)];
     } else {
 #pragma unroll
       for (int i = 0; i < NV; ++i)
-        nxt[i] = max(min(k0 + (tid + 256 * i) / VPL, kend - 1), 0);
+        nxt[i] = max(min(k0 + (tid + NT * i) / VPL, kend - 1), 0);
     }
   }
 
@@ -125,7 +125,7 @@ struct TileLoader {
     const int last = max(((span + 3) & ~3) - 4, 0);  // last in-bounds vector
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int f = tid + 256 * i;
+      const int f = tid + NT * i;
       const int c = KC ? (k0 + 4 * (f & 7)) : (r0 + 4 * (f % VPL));
       regs[i] = *reinterpret_cast<const float4*>(base + (int64_t)cur[i] * ld +
                                                  min(c, last));
@@ -138,7 +138,7 @@ struct TileLoader {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int f = tid + 256 * i;
+      const int f = tid + NT * i;
       float4 v = regs[i];
       if (KC) {
         const int r = f >> 3;
@@ -166,7 +166,9 @@ struct TileLoader {
 };
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KC, bool B_KC>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_f32_kernel(
+    GemmParams p) {
+  constexpr int NT = 64 * WAVES_M * WAVES_N;  // threads per workgroup
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int TM = WM / 32, TN = WN / 32;
   // row-contiguous operands: [BK][BR + PAD]; k-contiguous ones: [BR][BK + PAD]
@@ -201,8 +203,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
       p.colsum != nullptr &&
       (p.colsum_of_b ? (blockIdx.x == 0) : (blockIdx.y == 0));
 
-  TileLoader<BM, A_KC> la;
-  TileLoader<BN, B_KC> lb;
+  TileLoader<BM, A_KC, NT> la;
+  TileLoader<BN, B_KC, NT> lb;
   const int a_span = A_KC ? p.K : p.M;  // valid floats along the contiguous axis
   const int b_span = B_KC ? p.K : p.N;
   const int nk = (kend - kbeg + BK - 1) / BK;
@@ -342,8 +344,10 @@ int launch_gemm(const GemmParams& p, int splits, hipStream_t stream) {
     dim3 grid((unsigned)ga_ceil_div(p.M, 128), (unsigned)ga_ceil_div(p.N, 128),
               (unsigned)splits);
     const int slot = ga_prof_begin(GA_PROF_GEMM_NT_128 + mode, flops, stream);
-    hipLaunchKernelGGL((gemm_f32_kernel<128, 128, 2, 2, A_KC, B_KC>), grid,
-                       dim3(256), 0, stream, p);
+    // 8 waves (64x32 each): two workgroups per CU put 4 waves on every SIMD, so
+    // the matrix pipe has work while other waves sit at the barrier / vmcnt
+    hipLaunchKernelGGL((gemm_f32_kernel<128, 128, 2, 4, A_KC, B_KC>), grid,
+                       dim3(512), 0, stream, p);
     ga_prof_end(slot, stream);
   }
   GA_CHECK_LAUNCH("gemm_f32");

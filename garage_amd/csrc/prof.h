@@ -3,9 +3,9 @@
 #include <hip/hip_runtime.h>
 
 enum GaProfKind {
-  GA_PROF_GEMM_NT_128 = 0,  // gemm_f32_kernel<128,128,2,2,true,true>   forward
-  GA_PROF_GEMM_NN_128 = 1,  // gemm_f32_kernel<128,128,2,2,true,false>  data grad
-  GA_PROF_GEMM_TN_128 = 2,  // gemm_f32_kernel<128,128,2,2,false,false> weight grad
+  GA_PROF_GEMM_NT_128 = 0,  // gemm_f32_kernel<128,128,2,4,true,true>   forward
+  GA_PROF_GEMM_NN_128 = 1,  // gemm_f32_kernel<128,128,2,4,true,false>  data grad
+  GA_PROF_GEMM_TN_128 = 2,  // gemm_f32_kernel<128,128,2,4,false,false> weight grad
   GA_PROF_GEMM_NT_256 = 3,  // gemm_f32_kernel<128,32,4,1,true,true>
   GA_PROF_GEMM_NN_256 = 4,  // gemm_f32_kernel<128,32,4,1,true,false>
   GA_PROF_GEMM_TN_256 = 5,  // gemm_f32_kernel<128,32,4,1,false,false>

@@ -66,6 +66,30 @@ def init_from_env(backend=None):
     return Comm()
 
 
+class NativeComm:
+    """RCCL communicator owned by ``libgarage_amd`` (``ga_comm_*``), so the C++
+    epoch loop can all-reduce gradients without returning to Python.  The
+    128-byte unique id is created on rank 0 and broadcast with torch."""
+
+    def __init__(self, comm):
+        import ctypes as C
+
+        from garage_amd import _lib
+        lib = _lib.load()
+        raw = (C.c_ubyte * 128)()
+        if comm.rank == 0:
+            if lib.ga_comm_unique_id(raw) != 0:
+                raise RuntimeError(lib.ga_last_error().decode())
+        t = torch.tensor(list(raw), dtype=torch.uint8, device='cuda')
+        comm.broadcast(t, src=0)
+        raw = (C.c_ubyte * 128)(*t.cpu().tolist())
+        self.handle = lib.ga_comm_init_rank(raw, comm.rank, comm.world_size)
+        if not self.handle:
+            raise RuntimeError(lib.ga_last_error().decode())
+        self.world_size = comm.world_size
+        self.rank = comm.rank
+
+
 def combine_moments(stats, comm):
     """Global (sum, count) / squared deviations / min from per-rank stats.
 
@@ -86,11 +110,15 @@ def shard_algo(algo, comm):
     if comm is None:
         return algo
     algo._comm = comm
+    native = None
+    if dist.get_backend(comm.group) == 'nccl':
+        native = NativeComm(comm)  # RCCL inside the C++ epoch loop
     for module, opt in ((algo.policy, algo._policy_optimizer),
                         (algo._value_function, algo._vf_optimizer)):
         comm.broadcast(module.net.params)
         comm.broadcast(module.net.exp_avg)
         comm.broadcast(module.net.exp_avg_sq)
         opt.grad_hook = comm.all_reduce_mean
+        opt.native_comm = native
     algo._old_policy.sync(algo.policy)
     return algo

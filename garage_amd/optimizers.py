@@ -58,31 +58,36 @@ class OptimizerWrapper:
         self._seed = int(seed)
         self._draws = 0
         self.grad_hook = None  # multi-GPU: called on the flat grads
+        self.native_comm = None  # RCCL handle for the C++ epoch loop
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state['grad_hook'] = None  # process-group objects do not pickle
+        state['native_comm'] = None
+        return state
 
     @property
     def net(self):
         return self._module.net
 
-    def minibatch_indices(self, n):
-        """Yield one device int32 id tensor per minibatch (``None``: all rows).
+    def epoch_permutations(self, n):
+        """Yield, per optimisation pass, the device int32 id order of that pass
+        (``None`` when ``minibatch_size is None``: one full batch, no shuffle).
 
-        Same number, sizes and -- in ``'numpy'`` mode -- contents as the
-        minibatches ``get_minibatch`` of the reference yields for ``n`` rows.
+        ``'numpy'`` mode consumes the global numpy RNG exactly like
+        ``BatchDataset``: one shuffle at construction, one after every pass,
+        applied cumulatively to the same id array.
         """
-        mb = self._minibatch_size
-        if mb is None:
+        if self._minibatch_size is None:
             for _ in range(self._max_optimization_epochs):
                 yield None
             return
         dev = self.net.device
-        nb = -(-n // mb)
         if self._permutation == 'numpy':
             ids = np.arange(n, dtype=np.int32)
             np.random.shuffle(ids)  # BatchDataset.__init__ -> update()
             for _ in range(self._max_optimization_epochs):
-                perm = torch.from_numpy(ids.copy()).to(dev)
-                for k in range(nb):
-                    yield perm[k * mb:(k + 1) * mb]
+                yield torch.from_numpy(ids.copy()).to(dev)
                 np.random.shuffle(ids)  # after each full pass
         else:
             for _ in range(self._max_optimization_epochs):
@@ -91,8 +96,21 @@ class OptimizerWrapper:
                 key = (self._seed * 0x9E3779B97F4A7C15 +
                        self._draws * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
                 call('ga_permutation_i32', n, key, dptr(perm), stream_ptr())
-                for k in range(nb):
-                    yield perm[k * mb:(k + 1) * mb]
+                yield perm
+
+    def minibatch_indices(self, n):
+        """Yield one device int32 id tensor per minibatch (``None``: all rows).
+
+        Same number, sizes and -- in ``'numpy'`` mode -- contents as the
+        minibatches ``get_minibatch`` of the reference yields for ``n`` rows.
+        """
+        mb = self._minibatch_size
+        for perm in self.epoch_permutations(n):
+            if perm is None:
+                yield None
+                continue
+            for k in range(-(-n // mb)):
+                yield perm[k * mb:(k + 1) * mb]
 
     def get_minibatch(self, *inputs):
         """Reference-shaped generator: lists of gathered tensors."""

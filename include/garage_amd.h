@@ -205,6 +205,44 @@ int ga_permutation_i32(int64_t n, uint64_t key, int32_t* out, ga_stream_t stream
 int ga_episode_sums_f32(const float* rewards, const int64_t* ep_off, int64_t n_eps,
                         double* sums, ga_stream_t stream);
 
+/* ---- one optimisation pass, enqueued natively --------------------------------
+ * All minibatches of one epoch of VPG._train (torch/algos/vpg.py:230-293) for
+ * one network: forward, fused loss + gradient seed, backward, slab reduction,
+ * optional RCCL all-reduce(mean) of the flat gradient, Adam.  Same kernels and
+ * order as driving the entry points above one by one; exists because ~14
+ * launches per minibatch through ctypes starve the GPU. */
+typedef struct {
+  const ga_mlp_desc* desc;
+  float* params; float* grads; float* exp_avg; float* exp_avg_sq; int64_t n_flat;
+  float* acts; float* dacts; float* out; float* dout; int64_t ldo;
+  float* slabs; int64_t max_splits;
+  int64_t step0;           /* Adam steps already taken */
+  double lr, beta1, beta2, eps;
+  int32_t learn_std;       /* 0: the log-std slot is not trained */
+  const float* X; int64_t ldx; int64_t S;
+  const int32_t* perm;     /* S minibatch ids of this pass, NULL = one full batch */
+  int64_t mb;
+  int32_t kind;            /* 0 policy (PPO/VPG objective), 1 value (Gaussian NLL) */
+  const float* actions; int64_t lda; const float* old_ll; const float* adv;
+  const float* returns;
+  int32_t has_min; float min_log_std; int32_t has_max; float max_log_std;
+  int32_t algo; float clip; float ent_coeff; int32_t ent_flags;
+  float* losses;           /* optional [n_minibatches] per-step losses */
+  float* loss_scratch;     /* 1 float, used when losses == NULL */
+  double* workspace;
+  void* comm; int32_t world; /* RCCL communicator from ga_comm_init_rank, or NULL */
+} ga_update_args;
+int ga_update_epoch(const ga_update_args* args, ga_stream_t stream);
+
+/* RCCL communicator for the data-parallel gradient all-reduce (new: the
+ * reference has no collective on this path).
+ * ga_comm_unique_id fills 128 bytes on rank 0 (HOST pointer) to be broadcast by
+ * the caller; ga_comm_init_rank returns an opaque handle. */
+int ga_comm_unique_id(void* id128_host);
+void* ga_comm_init_rank(const void* id128_host, int rank, int world);
+int ga_comm_allreduce_sum_f32(void* comm, float* buf, int64_t n, ga_stream_t stream);
+int ga_comm_destroy(void* comm);
+
 /* ---- measurement ----------------------------------------------------------
  * Optional HIP-event timing of every GEMM / scan launch on its own stream
  * (bench.py's roofline leg; no reference counterpart).  kinds: 0..2 =
