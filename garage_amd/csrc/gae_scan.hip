@@ -23,6 +23,8 @@
 //
 // Algorithmic HBM bytes: 16 per step (r, V in; A, G out) (+2 for the tail flag).
 #include "common.h"
+#include <hip/hip_ext.h>
+
 #include "prof.h"
 
 namespace {
@@ -286,15 +288,15 @@ extern "C" int ga_gae_scan_f32(const float* rewards, const float* values,
                    (!tail || (reinterpret_cast<uintptr_t>(tail) & 7u) == 0);
   // algorithmic bytes: 16 per step (r, V in; A, G out)
   const double steps = offsets ? 0.0 : (double)n_rows * (double)T;
-  const int slot = ga_prof_begin(GA_PROF_GAE_SCAN,
-                                 16.0 * (offsets ? (double)prof_steps : steps), stream);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  ga_prof_events(GA_PROF_GAE_SCAN, 16.0 * (offsets ? (double)prof_steps : steps),
+                 &e0, &e1);
   if (vec)
-    hipLaunchKernelGGL(gae_scan_kernel<true>, dim3((unsigned)blocks), dim3(256), 0,
-                       stream, p);
+    hipExtLaunchKernelGGL(gae_scan_kernel<true>, dim3((unsigned)blocks), dim3(256),
+                          0, stream, e0, e1, 0, p);
   else
-    hipLaunchKernelGGL(gae_scan_kernel<false>, dim3((unsigned)blocks), dim3(256),
-                       0, stream, p);
-  ga_prof_end(slot, stream);
+    hipExtLaunchKernelGGL(gae_scan_kernel<false>, dim3((unsigned)blocks), dim3(256),
+                          0, stream, e0, e1, 0, p);
   GA_CHECK_LAUNCH("ga_gae_scan_f32");
   return GA_OK;
 }

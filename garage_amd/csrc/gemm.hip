@@ -19,6 +19,8 @@
 // MFMA A operand of lane l is tile[2*kk + (l >> 5)][row0 + (l & 31)] and B is
 // read the same way, one ds_read_b32 each.
 #include "common.h"
+#include <hip/hip_ext.h>
+
 #include "prof.h"
 
 namespace {
@@ -331,24 +333,23 @@ int launch_gemm(const GemmParams& p, int splits, hipStream_t stream) {
   const int mode = (A_KC && B_KC) ? 0 : (A_KC ? 1 : 2);
   // algorithmic flops: 2 M N K (the padding of ragged tiles is not counted)
   const double flops = 2.0 * (double)p.M * (double)p.N * (double)p.K;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
   if (p.N <= 32) {
     // narrow outputs are HBM bound on the wide operand: 128-row tiles give
     // M/128 workgroups (256 at the C3 minibatch) to pull it through
     dim3 grid((unsigned)ga_ceil_div(p.M, 128), (unsigned)ga_ceil_div(p.N, 32),
               (unsigned)splits);
-    const int slot = ga_prof_begin(GA_PROF_GEMM_NT_256 + mode, flops, stream);
-    hipLaunchKernelGGL((gemm_f32_kernel<128, 32, 4, 1, A_KC, B_KC>), grid,
-                       dim3(256), 0, stream, p);
-    ga_prof_end(slot, stream);
+    ga_prof_events(GA_PROF_GEMM_NT_256 + mode, flops, &e0, &e1);
+    hipExtLaunchKernelGGL((gemm_f32_kernel<128, 32, 4, 1, A_KC, B_KC>), grid,
+                          dim3(256), 0, stream, e0, e1, 0, p);
   } else {
     dim3 grid((unsigned)ga_ceil_div(p.M, 128), (unsigned)ga_ceil_div(p.N, 128),
               (unsigned)splits);
-    const int slot = ga_prof_begin(GA_PROF_GEMM_NT_128 + mode, flops, stream);
+    ga_prof_events(GA_PROF_GEMM_NT_128 + mode, flops, &e0, &e1);
     // 8 waves (64x32 each): two workgroups per CU put 4 waves on every SIMD, so
     // the matrix pipe has work while other waves sit at the barrier / vmcnt
-    hipLaunchKernelGGL((gemm_f32_kernel<128, 128, 2, 4, A_KC, B_KC>), grid,
-                       dim3(512), 0, stream, p);
-    ga_prof_end(slot, stream);
+    hipExtLaunchKernelGGL((gemm_f32_kernel<128, 128, 2, 4, A_KC, B_KC>), grid,
+                          dim3(512), 0, stream, e0, e1, 0, p);
   }
   GA_CHECK_LAUNCH("gemm_f32");
   return GA_OK;

@@ -1,7 +1,7 @@
 // Optional per-launch timing with HIP events (used by bench.py's roofline leg).
-// Disabled by default: ga_prof_begin() is then a single branch.  Events are
-// recorded on the stream the kernel is launched on, so the elapsed time is the
-// kernel's duration on the device (plus ~1-2 us of event overhead).
+// Disabled by default.  The events are attached to the kernel dispatch itself
+// (hipExtLaunchKernelGGL), on the stream the kernel is launched on, so the
+// elapsed time is the kernel's own duration on the device.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <vector>
@@ -31,21 +31,18 @@ hipEvent_t get_event() {
 }
 }  // namespace
 
-int ga_prof_begin(int kind, double work, hipStream_t stream) {
-  if (!g_on || g_samples.size() >= kMaxSamples) return -1;
+void ga_prof_events(int kind, double work, hipEvent_t* start, hipEvent_t* stop) {
+  *start = nullptr;
+  *stop = nullptr;
+  if (!g_on || g_samples.size() >= kMaxSamples) return;
   Sample s;
   s.start = get_event();
   s.stop = get_event();
   s.kind = kind;
   s.work = work;
-  (void)hipEventRecord(s.start, stream);
   g_samples.push_back(s);
-  return (int)g_samples.size() - 1;
-}
-
-void ga_prof_end(int slot, hipStream_t stream) {
-  if (slot < 0) return;
-  (void)hipEventRecord(g_samples[slot].stop, stream);
+  *start = s.start;
+  *stop = s.stop;
 }
 
 extern "C" int ga_prof_enable(int on) {

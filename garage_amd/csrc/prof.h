@@ -13,5 +13,8 @@ enum GaProfKind {
   GA_PROF_KINDS = 7
 };
 
-int ga_prof_begin(int kind, double work, hipStream_t stream);
-void ga_prof_end(int slot, hipStream_t stream);
+// When profiling is on, hands out a (start, stop) event pair to attach to ONE
+// kernel dispatch with hipExtLaunchKernelGGL: the elapsed time is then the
+// kernel's own duration (what rocprofv3 reports), with no launch gaps in it.
+// When off, both stay null and the launch is an ordinary one.
+void ga_prof_events(int kind, double work, hipEvent_t* start, hipEvent_t* stop);
