@@ -31,8 +31,9 @@ CONFIGS = {
     # BASELINE.json configs[2]: the configuration the metric is quoted on
     'c3': dict(name='HalfCheetah-shape synthetic', obs_dim=17, act_dim=6,
                n_envs=4096, T=256, hidden=(256, 256), min_len=None),
-    'c2': dict(name='CartPole-shape synthetic (continuous head)', obs_dim=4,
-               act_dim=2, n_envs=4096, T=128, hidden=(64, 64), min_len=None),
+    'c2': dict(name='CartPole-shape synthetic, discrete-2 categorical head',
+               obs_dim=4, act_dim=2, n_envs=4096, T=128, hidden=(64, 64),
+               min_len=None, discrete=True),
     'c5': dict(name='Humanoid-shape synthetic, ragged', obs_dim=376,
                act_dim=17, n_envs=8192, T=256, hidden=(512, 512, 512),
                min_len=32),
@@ -60,14 +61,18 @@ def build_engine(cfg, comm, seed=1):
     from garage_amd.distributed import shard_algo
     from garage_amd.envs import SyntheticVecEnv
     from garage_amd.optimizers import OptimizerWrapper
-    from garage_amd.policies import GaussianMLPPolicy, GaussianMLPValueFunction
+    from garage_amd.policies import (CategoricalMLPPolicy, GaussianMLPPolicy,
+                                     GaussianMLPValueFunction)
     from garage_amd.sampler import GpuVecSampler, GpuVecWorker
     rank = comm.rank if comm is not None else 0
     n, T = cfg['n_envs'], cfg['T']
     torch.manual_seed(seed)
     env = SyntheticVecEnv(n, cfg['obs_dim'], cfg['act_dim'], T,
-                          min_len=cfg['min_len'], seed=seed, env_id0=rank * n)
-    pol = GaussianMLPPolicy(env.spec, hidden_sizes=cfg['hidden'])
+                          min_len=cfg['min_len'], seed=seed, env_id0=rank * n,
+                          discrete=cfg.get('discrete', False))
+    policy_cls = (CategoricalMLPPolicy
+                  if cfg.get('discrete') else GaussianMLPPolicy)
+    pol = policy_cls(env.spec, hidden_sizes=cfg['hidden'])
     vf = GaussianMLPValueFunction(env.spec, hidden_sizes=cfg['hidden'])
     sampler = GpuVecSampler(pol, env, max_episode_length=T, n_workers=1,
                             worker_class=GpuVecWorker, seed=seed + rank,
@@ -239,7 +244,7 @@ def main():
         'dtype': 'f32',
         'data': 'synthetic',
         'config': {
-            'workload': '{}: obs {} act {} Gaussian, {} envs/GPU x T={}, '
+            'workload': '{}: obs {} act {}, {} envs/GPU x T={}, '
                         'MLP{} policy + value, PPO E={} x {} minibatches, '
                         'gamma {} lambda {} clip {} Adam lr {}, device '
                         'minibatch permutation'.format(

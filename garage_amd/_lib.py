@@ -65,7 +65,7 @@ class UpdateArgs(C.Structure):
                 ('has_max', c_i32), ('max_log_std', c_f32), ('algo', c_i32),
                 ('clip', c_f32), ('ent_coeff', c_f32), ('ent_flags', c_i32),
                 ('losses', ptr), ('loss_scratch', ptr), ('workspace', ptr),
-                ('comm', ptr), ('world', c_i32)]
+                ('comm', ptr), ('world', c_i32), ('double_softmax', c_i32)]
 
 
 # name -> (restype, argtypes); mirrors include/garage_amd.h one to one.
@@ -89,6 +89,13 @@ SIGNATURES = {
                                          c_i64, c_int, c_int, c_f32, c_f32,
                                          c_int, ptr, ptr, ptr, ptr, c_i64,
                                          c_i64, ptr, ptr]),
+    'ga_ppo_categorical_loss_f32': (c_int, [ptr, c_i64, ptr, c_i64, ptr, ptr,
+                                            ptr, c_i64, c_int, c_int, c_int,
+                                            c_f32, c_f32, c_int, ptr, ptr, ptr,
+                                            ptr, ptr, ptr, c_i64, c_i64, ptr,
+                                            ptr]),
+    'ga_categorical_kl_f32': (c_int, [ptr, ptr, c_i64, c_i64, c_int, c_int,
+                                      ptr, ptr, ptr]),
     'ga_gaussian_nll_loss_f32': (c_int, [ptr, c_i64, ptr, ptr, ptr, c_i64, ptr,
                                          ptr, ptr, c_i64, c_i64, ptr, ptr]),
     'ga_gaussian_kl_f32': (c_int, [ptr, ptr, c_i64, c_i64, c_int, c_f32, c_f32,

@@ -160,6 +160,178 @@ __global__ void ppo_gaussian_finalize_kernel(PpoFinalizeParams p) {
   }
 }
 
+// ---- categorical policy head ---------------------------------------------------
+// The reference has no torch CategoricalMLPPolicy; its torch categorical (CNN)
+// policies feed softmax(net(x)) to Categorical(logits=...)
+// (torch/policies/categorical_cnn_policy.py:138-139).
+// double_softmax = 1 keeps that convention, 0 treats the MLP output as logits.
+struct CatLossParams {
+  const float* scores;   // [M, lds] MLP outputs of the minibatch rows
+  int64_t lds;
+  const float* actions;  // [*, lda] column 0 holds the class id (as float)
+  int64_t lda;
+  const float* old_ll;
+  const float* adv;
+  const int32_t* idx;
+  int64_t M;
+  int A;
+  int double_softmax;
+  int algo;
+  float clip;
+  float ent_coeff;
+  int ent_regularized, ent_softplus, ent_stop_grad;
+  float* dscores;        // optional [M, lds]: dLoss/dscores (already / M)
+  float* ll_out;         // optional [M]
+  float* ent_out;        // optional [M]: per-row entropy (after softplus if set)
+  double* partials;      // [gridDim.x][2]: sum objective, sum entropy
+};
+
+// Final log-probabilities lp[j] of the row, its entropy, and (for the
+// gradient) the softmax p of the raw scores.  A is small (number of actions).
+__device__ __forceinline__ void cat_row(const float* sc, int A, int dbl, float* lse_out,
+                                        float* mx_out, float* den_out) {
+  float mx = sc[0];
+  for (int j = 1; j < A; ++j) mx = fmaxf(mx, sc[j]);
+  float den = 0.f;
+  for (int j = 0; j < A; ++j) den += expf(sc[j] - mx);
+  *mx_out = mx;
+  *den_out = den;
+  if (!dbl) {
+    *lse_out = mx + logf(den);  // lp[j] = sc[j] - lse
+  } else {
+    // logits' = p in [0,1]: logsumexp without a shift is safe
+    float s2 = 0.f;
+    for (int j = 0; j < A; ++j) s2 += expf(expf(sc[j] - mx) / den);
+    *lse_out = logf(s2);        // lp[j] = p[j] - lse
+  }
+}
+
+__global__ __launch_bounds__(256) void ppo_categorical_loss_kernel(CatLossParams p) {
+  __shared__ double red[4];
+  const float invM = 1.f / (float)p.M;
+  double obj_sum = 0.0, ent_sum = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < p.M;
+       i += (int64_t)gridDim.x * 256) {
+    const int64_t src = p.idx ? (int64_t)p.idx[i] : i;
+    const float* sc = p.scores + i * p.lds;
+    const int a = (int)p.actions[src * p.lda];
+    float lse, mx, den;
+    cat_row(sc, p.A, p.double_softmax, &lse, &mx, &den);
+    // log-prob of the taken action and the entropy H = -sum q lp
+    float ll = 0.f, H = 0.f;
+    for (int j = 0; j < p.A; ++j) {
+      const float pj = expf(sc[j] - mx) / den;
+      const float lp = (p.double_softmax ? pj : sc[j]) - lse;
+      const float q = expf(lp);
+      H -= q * lp;
+      if (j == a) ll = lp;
+    }
+    float Hs = H, dHs = 1.f;  // softplus(H) and its derivative
+    if (p.ent_softplus) {
+      dHs = sigmoidf(H);
+      Hs = softplusf(H);
+    }
+    if (p.ll_out) p.ll_out[i] = ll;
+    if (p.ent_out) p.ent_out[i] = Hs;
+    const float adv = p.adv[src];
+    float obj, g;
+    if (p.algo == 1) {
+      obj = ll * adv;
+      g = adv;
+    } else {
+      const float ratio = expf(ll - p.old_ll[src]);
+      const float lo = 1.f - p.clip, hi = 1.f + p.clip;
+      const float rc = fminf(fmaxf(ratio, lo), hi);
+      const float s1 = ratio * adv, s2 = rc * adv;
+      obj = fminf(s1, s2);
+      const float g1 = adv * ratio;
+      const float g2 = (ratio >= lo && ratio <= hi) ? adv * ratio : 0.f;
+      g = (s1 < s2) ? g1 : ((s1 > s2) ? g2 : 0.5f * (g1 + g2));
+    }
+    if (p.ent_regularized) obj += p.ent_coeff * Hs;
+    obj_sum += (double)obj;
+    ent_sum += (double)Hs;
+    if (p.dscores) {
+      // dObj/dlogit'_j = g (1[j=a] - q_j) + c_H * (-q_j (lp_j + H))
+      const float cH = (p.ent_regularized && !p.ent_stop_grad)
+                           ? p.ent_coeff * dHs : 0.f;
+      float* ds = p.dscores + i * p.lds;
+      if (!p.double_softmax) {
+        for (int j = 0; j < p.A; ++j) {
+          const float lp = sc[j] - lse;
+          const float q = expf(lp);
+          const float d = g * ((j == a ? 1.f : 0.f) - q) - cH * q * (lp + H);
+          ds[j] = -d * invM;
+        }
+      } else {
+        // chain through p = softmax(scores): dz_k = p_k (dp_k - sum_j dp_j p_j)
+        float dot = 0.f;
+        for (int j = 0; j < p.A; ++j) {
+          const float pj = expf(sc[j] - mx) / den;
+          const float lp = pj - lse;
+          const float q = expf(lp);
+          const float dp = g * ((j == a ? 1.f : 0.f) - q) - cH * q * (lp + H);
+          dot += dp * pj;
+        }
+        for (int k = 0; k < p.A; ++k) {
+          const float pk = expf(sc[k] - mx) / den;
+          const float lp = pk - lse;
+          const float q = expf(lp);
+          const float dp = g * ((k == a ? 1.f : 0.f) - q) - cH * q * (lp + H);
+          ds[k] = -(pk * (dp - dot)) * invM;
+        }
+      }
+    }
+  }
+  const double o = ga_block_sum_256(obj_sum, red);
+  const double e = ga_block_sum_256(ent_sum, red);
+  if (threadIdx.x == 0) {
+    p.partials[2 * blockIdx.x + 0] = o;
+    p.partials[2 * blockIdx.x + 1] = e;
+  }
+}
+
+__global__ void ppo_categorical_finalize_kernel(const double* partials, int nblocks,
+                                                int64_t M, float* loss_out,
+                                                double* ent_sum_out, float* grad_slab0,
+                                                int64_t slab_stride, int64_t n_splits) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double o = 0.0, e = 0.0;
+  for (int b = 0; b < nblocks; ++b) {
+    o += partials[2 * b];
+    e += partials[2 * b + 1];
+  }
+  *loss_out = (float)(-(o / (double)M));
+  if (ent_sum_out) *ent_sum_out = e;
+  if (grad_slab0)  // the (unused) log-std slot of the flat layout stays 0
+    for (int64_t k = 0; k < n_splits; ++k) grad_slab0[k * slab_stride] = 0.f;
+}
+
+// sum over rows of KL(old || new) for categorical heads
+__global__ __launch_bounds__(256) void categorical_kl_kernel(
+    const float* sc_old, const float* sc_new, int64_t ld, int64_t M, int A, int dbl,
+    double* partials) {
+  __shared__ double red[4];
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < M;
+       i += (int64_t)gridDim.x * 256) {
+    const float* so = sc_old + i * ld;
+    const float* sn = sc_new + i * ld;
+    float lo, mo, den_o, ln, mn, dn;
+    cat_row(so, A, dbl, &lo, &mo, &den_o);
+    cat_row(sn, A, dbl, &ln, &mn, &dn);
+    float kl = 0.f;
+    for (int j = 0; j < A; ++j) {
+      const float lpo = (dbl ? expf(so[j] - mo) / den_o : so[j]) - lo;
+      const float lpn = (dbl ? expf(sn[j] - mn) / dn : sn[j]) - ln;
+      kl += expf(lpo) * (lpo - lpn);
+    }
+    acc += (double)kl;
+  }
+  const double r = ga_block_sum_256(acc, red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = r;
+}
+
 struct NllParams {
   const float* v;        // [M, ldv], value in column 0
   int64_t ldv;
@@ -427,6 +599,53 @@ extern "C" int ga_ppo_gaussian_loss_f32(
   f.grad_slab0 = grad_slab0; f.slab_stride = slab_stride; f.n_splits = n_splits;
   hipLaunchKernelGGL(ppo_gaussian_finalize_kernel, dim3(1), dim3(64), 0, stream, f);
   GA_CHECK_LAUNCH("ppo_gaussian_finalize");
+  return GA_OK;
+}
+
+extern "C" int ga_ppo_categorical_loss_f32(
+    const float* scores, int64_t lds, const float* actions, int64_t lda,
+    const float* old_ll, const float* adv, const int32_t* idx, int64_t M, int A,
+    int double_softmax, int algo, float clip, float ent_coeff, int ent_flags,
+    float* dscores, float* ll_out, float* ent_out, float* loss_out,
+    double* ent_sum_out, float* grad_slab0, int64_t slab_stride, int64_t n_splits,
+    double* workspace, hipStream_t stream) {
+  GA_REQUIRE(scores && actions && adv && loss_out && workspace,
+             "ga_ppo_categorical_loss_f32: null pointer");
+  GA_REQUIRE(algo == 1 || old_ll, "ga_ppo_categorical_loss_f32: PPO needs old_ll");
+  GA_REQUIRE(M > 0 && A > 0 && lds >= A && lda >= 1,
+             "ga_ppo_categorical_loss_f32: bad sizes");
+  CatLossParams p;
+  p.scores = scores; p.lds = lds; p.actions = actions; p.lda = lda;
+  p.old_ll = old_ll; p.adv = adv; p.idx = idx; p.M = M; p.A = A;
+  p.double_softmax = double_softmax; p.algo = algo; p.clip = clip;
+  p.ent_coeff = ent_coeff; p.ent_regularized = ent_flags & 1;
+  p.ent_softplus = (ent_flags >> 1) & 1; p.ent_stop_grad = (ent_flags >> 2) & 1;
+  p.dscores = dscores; p.ll_out = ll_out; p.ent_out = ent_out;
+  p.partials = workspace;
+  const int nb = red_blocks(M);
+  hipLaunchKernelGGL(ppo_categorical_loss_kernel, dim3(nb), dim3(256), 0, stream, p);
+  GA_CHECK_LAUNCH("ppo_categorical_loss");
+  hipLaunchKernelGGL(ppo_categorical_finalize_kernel, dim3(1), dim3(64), 0, stream,
+                     (const double*)workspace, nb, M, loss_out, ent_sum_out,
+                     grad_slab0, slab_stride, n_splits);
+  GA_CHECK_LAUNCH("ppo_categorical_finalize");
+  return GA_OK;
+}
+
+extern "C" int ga_categorical_kl_f32(const float* scores_old, const float* scores_new,
+                                     int64_t ld, int64_t M, int A, int double_softmax,
+                                     double* kl_sum_out, double* workspace,
+                                     hipStream_t stream) {
+  GA_REQUIRE(scores_old && scores_new && kl_sum_out && workspace,
+             "ga_categorical_kl_f32: null pointer");
+  GA_REQUIRE(M > 0 && A > 0 && ld >= A, "ga_categorical_kl_f32: bad sizes");
+  const int nb = red_blocks(M);
+  hipLaunchKernelGGL(categorical_kl_kernel, dim3(nb), dim3(256), 0, stream,
+                     scores_old, scores_new, ld, M, A, double_softmax, workspace);
+  GA_CHECK_LAUNCH("categorical_kl");
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, stream,
+                     (const double*)workspace, nb, kl_sum_out);
+  GA_CHECK_LAUNCH("sum_partials");
   return GA_OK;
 }
 

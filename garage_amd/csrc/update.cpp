@@ -50,6 +50,12 @@ extern "C" int ga_update_epoch(const ga_update_args* a, ga_stream_t stream) {
           a->has_min, a->min_log_std, a->has_max, a->max_log_std, M, out_w, a->algo,
           a->clip, a->ent_coeff, a->ent_flags, a->dout, nullptr, loss_slot, a->slabs,
           a->n_flat, splits, a->workspace, stream);
+    } else if (a->kind == 2) {
+      rc = ga_ppo_categorical_loss_f32(
+          a->out, a->ldo, a->actions, a->lda, a->old_ll, a->adv, idx, M, out_w,
+          a->double_softmax, a->algo, a->clip, a->ent_coeff, a->ent_flags, a->dout,
+          nullptr, nullptr, loss_slot, nullptr, a->slabs, a->n_flat, splits,
+          a->workspace, stream);
     } else {
       rc = ga_gaussian_nll_loss_f32(a->out, a->ldo, a->returns, idx, a->params, M,
                                     a->dout, loss_slot, a->slabs, a->n_flat, splits,

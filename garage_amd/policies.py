@@ -301,6 +301,100 @@ class GaussianMLPPolicy(_GaussianMLP):
         return a[0], {k: v[0] for k, v in info.items()}
 
 
+class CategoricalMLPPolicy(_GaussianMLP):
+    """Categorical policy over a discrete action space (BASELINE.json configs 1-2).
+
+    The reference snapshot has **no** torch ``CategoricalMLPPolicy`` (SURVEY.md
+    Q15/Q24); this class follows the conventions of its torch categorical (CNN)
+    policies and of the TF ``CategoricalMLPPolicy``: tanh MLP with
+    ``hidden_sizes=(32, 32)``, xavier-uniform weights, zero biases, a softmax
+    output that is then passed as ``logits=`` to ``Categorical``
+    (``torch/policies/categorical_cnn_policy.py:138-139``;
+    ``double_softmax=True``, the default) -- set ``double_softmax=False`` to
+    treat the MLP output as logits.  Actions come back as int64 ``(n,)`` and are
+    cast to float for the update exactly like ``torch.Tensor(eps.actions)``
+    (``vpg.py:163``).  Parameter names reuse the Gaussian module's scheme
+    (``_module._mean_module._layers.{i}.linear.{weight,bias}`` ...).
+    """
+
+    kind = 'categorical'
+
+    def __init__(self,
+                 env_spec,
+                 hidden_sizes=(32, 32),
+                 hidden_nonlinearity=torch.tanh,
+                 hidden_w_init=nn.init.xavier_uniform_,
+                 hidden_b_init=nn.init.zeros_,
+                 output_w_init=nn.init.xavier_uniform_,
+                 output_b_init=nn.init.zeros_,
+                 layer_normalization=False,
+                 double_softmax=True,
+                 name='CategoricalMLPPolicy',
+                 device=None):
+        _check_supported(hidden_nonlinearity, None, 'exp', layer_normalization)
+        if not is_discrete(env_spec.action_space):
+            raise ValueError('CategoricalMLPPolicy only works '
+                             'with akro.Discrete action space.')
+        self._env_spec = env_spec
+        self._name = name
+        self.double_softmax = bool(double_softmax)
+        self._obs_dim = env_spec.observation_space.flat_dim
+        self._action_dim = env_spec.action_space.n
+        self._build(self._obs_dim, self._action_dim, hidden_sizes,
+                    hidden_w_init, hidden_b_init, output_w_init, output_b_init,
+                    False, 1.0, None, None, device)
+        self._sample_seed = int(torch.initial_seed() & 0x7FFFFFFF)
+        self._sample_calls = 0
+
+    @property
+    def name(self):
+        return self._name
+
+    @property
+    def env_spec(self):
+        return self._env_spec
+
+    def reset(self, do_resets=None):
+        """Stateless."""
+
+    def state_dict(self):
+        sd = super().state_dict()
+        sd.pop(self._prefix + 'init_std', None)  # no std in this head
+        return sd
+
+    def load_state_dict(self, sd):
+        sd = dict(sd)
+        sd.setdefault(self._prefix + 'init_std', torch.zeros(1))
+        super().load_state_dict(sd)
+
+    def _probs(self, scores):
+        p = torch.softmax(scores, dim=-1)
+        return torch.softmax(p, dim=-1) if self.double_softmax else p
+
+    def forward(self, observations):
+        """``(Categorical, {})`` built from the HIP MLP's scores."""
+        obs = self._as_device_obs(observations)
+        scores = self.net.forward(obs, obs.shape[0])[:, :self._action_dim]
+        probs = self._probs(scores.clone())
+        return torch.distributions.Categorical(probs=probs), {}
+
+    __call__ = forward
+
+    def get_actions(self, observations):
+        obs = self._as_device_obs(observations)
+        scores = self.net.forward(obs, obs.shape[0])[:, :self._action_dim]
+        probs = self._probs(scores.clone())
+        self._sample_calls += 1
+        gen = torch.Generator(device=self.device)
+        gen.manual_seed(self._sample_seed + self._sample_calls)
+        a = torch.multinomial(probs, 1, generator=gen)[:, 0]
+        return a.cpu().numpy(), dict(prob=probs.cpu().numpy())
+
+    def get_action(self, observation):
+        a, info = self.get_actions(np.asarray(observation)[None])
+        return a[0], {k: v[0] for k, v in info.items()}
+
+
 class GaussianMLPValueFunction(_GaussianMLP):
     """``garage.torch.value_functions.GaussianMLPValueFunction`` on HIP kernels."""
 

@@ -103,6 +103,25 @@ int ga_ppo_gaussian_loss_f32(const float* mean, int64_t ldm, const float* action
                              int ent_flags, float* dmean, float* ll_out,
                              float* loss_out, float* grad_slab0, int64_t slab_stride,
                              int64_t n_splits, double* workspace, ga_stream_t stream);
+/* The same objective for a categorical MLP head (discrete actions, BASELINE.json
+ * configs 1-2).  No torch CategoricalMLPPolicy exists in the reference; the
+ * convention follows its torch categorical policies, which pass
+ * softmax(net(x)) as `logits=` (torch/policies/categorical_cnn_policy.py:138-139;
+ * double_softmax = 1), and log_prob casts float actions with .long()
+ * (SURVEY.md Q24).  ent_out / ent_sum_out: per-row / summed entropies. */
+int ga_ppo_categorical_loss_f32(const float* scores, int64_t lds,
+                                const float* actions, int64_t lda,
+                                const float* old_ll, const float* adv,
+                                const int32_t* idx, int64_t M, int A,
+                                int double_softmax, int algo, float clip,
+                                float ent_coeff, int ent_flags, float* dscores,
+                                float* ll_out, float* ent_out, float* loss_out,
+                                double* ent_sum_out, float* grad_slab0,
+                                int64_t slab_stride, int64_t n_splits,
+                                double* workspace, ga_stream_t stream);
+int ga_categorical_kl_f32(const float* scores_old, const float* scores_new,
+                          int64_t ld, int64_t M, int A, int double_softmax,
+                          double* kl_sum_out, double* workspace, ga_stream_t stream);
 /* GaussianMLPValueFunction.compute_loss
  * (torch/value_functions/gaussian_mlp_value_function.py:81-98). */
 int ga_gaussian_nll_loss_f32(const float* v, int64_t ldv, const float* returns,
@@ -222,7 +241,8 @@ typedef struct {
   const float* X; int64_t ldx; int64_t S;
   const int32_t* perm;     /* S minibatch ids of this pass, NULL = one full batch */
   int64_t mb;
-  int32_t kind;            /* 0 policy (PPO/VPG objective), 1 value (Gaussian NLL) */
+  int32_t kind;            /* 0 Gaussian policy, 1 value (Gaussian NLL),
+                              2 categorical policy */
   const float* actions; int64_t lda; const float* old_ll; const float* adv;
   const float* returns;
   int32_t has_min; float min_log_std; int32_t has_max; float max_log_std;
@@ -231,6 +251,7 @@ typedef struct {
   float* loss_scratch;     /* 1 float, used when losses == NULL */
   double* workspace;
   void* comm; int32_t world; /* RCCL communicator from ga_comm_init_rank, or NULL */
+  int32_t double_softmax;    /* kind 2 */
 } ga_update_args;
 int ga_update_epoch(const ga_update_args* args, ga_stream_t stream);
 

@@ -310,3 +310,135 @@ def test_full_iteration_vs_oracle():
             assert np.allclose(v.numpy(), wv[k], atol=1e-5), k
         for k, v in algo.last_performance.items():
             assert np.isclose(v, want['performance'][k]), k
+
+
+# ---------------------------------------------------------------------------
+# categorical head (no torch CategoricalMLPPolicy exists in the reference:
+# parity here is against the oracle's torch.distributions.Categorical
+# restatement of the reference's torch categorical convention)
+def _discrete_spec(O, n_act, P):
+    from garage_amd._dtypes import Box, Discrete, EnvSpec
+    return EnvSpec(Box(-np.inf, np.inf, (O, )), Discrete(n_act),
+                   max_episode_length=P)
+
+
+@pytest.mark.parametrize('dbl,ent', [(True, None), (False, None),
+                                     (True, (0.03, False)),
+                                     (False, (0.03, True))])
+def test_categorical_loss_and_grads(dbl, ent):
+    from garage_amd._lib import call, dptr, stream_ptr
+    from garage_amd.engine import pad_rows, reduction_workspace
+    from garage_amd.policies import CategoricalMLPPolicy
+    from oracle import networks as nets
+    O, A, M = 5, 4, 600
+    torch.manual_seed(2)
+    pol = CategoricalMLPPolicy(_discrete_spec(O, A, 8), hidden_sizes=(16, 16),
+                               double_softmax=dbl)
+    dev = pol.device
+    rng = np.random.RandomState(3)
+    obs = torch.from_numpy(rng.randn(M, O).astype(np.float32))
+    act = torch.from_numpy(rng.randint(0, A, M).astype(np.float32))
+    adv = torch.from_numpy(rng.randn(M).astype(np.float32))
+    sd = pol.state_dict()
+    params = OrderedDict((k, v.clone().requires_grad_(True))
+                         for k, v in sd.items())
+    with torch.no_grad():
+        old_ll = nets.categorical_dist(sd, '_module.', obs, dbl).log_prob(
+            act.long()) + torch.from_numpy(
+                (rng.randn(M) * 0.3).astype(np.float32))
+    dist = nets.categorical_dist(params, '_module.', obs, dbl)
+    ll = dist.log_prob(act.long())
+    ratio = (ll - old_ll).exp()
+    obj = torch.min(ratio * adv, torch.clamp(ratio, 0.8, 1.2) * adv)
+    if ent is not None:
+        e = dist.entropy()
+        if ent[1]:
+            e = torch.nn.functional.softplus(e)
+        obj = obj + ent[0] * e
+    loss = -obj.mean()
+    loss.backward()
+
+    net = pol.net
+    X = pad_rows(obs)
+    scores = net.forward(X, M)
+    dout = net.dout_view(M)
+    dout.zero_()
+    ll_out = torch.empty(M, device=dev)
+    loss_out = torch.zeros(1, device=dev)
+    flags = 0 if ent is None else (1 | (2 if ent[1] else 0))
+    actd = pad_rows(act.reshape(-1, 1))
+    olld, advd = old_ll.to(dev), adv.to(dev)  # keep alive across the call
+    call('ga_ppo_categorical_loss_f32', dptr(scores), scores.stride(0),
+         dptr(actd), actd.stride(0), dptr(olld), dptr(advd),
+         None, M, A, int(dbl), 0, 0.2, ent[0] if ent else 0.0, flags,
+         dptr(dout), dptr(ll_out), None, dptr(loss_out), None,
+         dptr(net._slabs), net.n_flat, int(net._splits),
+         dptr(reduction_workspace(dev)), stream_ptr())
+    net.backward(X, M, dout)
+    net.reduce_grads()
+    assert np.isclose(loss_out.item(), loss.item(), atol=1e-6, rtol=1e-5)
+    assert np.allclose(ll_out.cpu().numpy(), ll.detach().numpy(), atol=1e-5)
+    for key, view in net.named_views(net.grads):
+        if key == '_init_std':
+            assert float(view.abs().max()) == 0.0
+            continue
+        ref = params['_module.' + key].grad.numpy()
+        got = view.cpu().numpy().reshape(ref.shape)
+        assert np.allclose(got, ref, atol=2e-6 + 1e-4 * np.abs(ref).max()), key
+
+
+@pytest.mark.parametrize('kw', [dict(), dict(entropy_method='max',
+                                             policy_ent_coeff=0.05,
+                                             center_adv=False,
+                                             stop_entropy_gradient=True),
+                                dict(entropy_method='regularized',
+                                     policy_ent_coeff=0.02)])
+def test_categorical_iteration_vs_oracle(kw):
+    """Discrete synthetic envs -> GPU sampler -> PPO vs the oracle (ragged)."""
+    from garage_amd.algos import PPO
+    from garage_amd.envs import SyntheticVecEnv
+    from garage_amd.optimizers import OptimizerWrapper
+    from garage_amd.policies import (CategoricalMLPPolicy,
+                                     GaussianMLPValueFunction)
+    from garage_amd.sampler import GpuVecSampler, GpuVecWorker
+    from oracle import batch as ob
+    from oracle.ppo import OraclePPO
+    n, O, A, P = 48, 4, 2, 20
+    torch.manual_seed(9)
+    env = SyntheticVecEnv(n, O, A, P, min_len=4, seed=11, discrete=True)
+    pol = CategoricalMLPPolicy(env.spec, hidden_sizes=(16, 16))
+    vf = GaussianMLPValueFunction(env.spec, hidden_sizes=(16, 16))
+    sampler = GpuVecSampler(pol, env, max_episode_length=P, n_workers=1,
+                            worker_class=GpuVecWorker,
+                            worker_args=dict(n_envs=n))
+    E, mb = 2, 128
+    opt = (torch.optim.Adam, dict(lr=1e-3))
+    algo = PPO(env_spec=env.spec, policy=pol, value_function=vf,
+               sampler=sampler,
+               policy_optimizer=OptimizerWrapper(opt, pol, E, mb),
+               vf_optimizer=OptimizerWrapper(opt, vf, E, mb), **kw)
+    oracle = OraclePPO(pol.state_dict(), vf.state_dict(), max_episode_length=P,
+                       policy_kind='categorical', max_optimization_epochs=E,
+                       minibatch_size=mb, policy_lr=1e-3, vf_lr=1e-3, **kw)
+    for it in range(2):
+        eps = sampler.obtain_samples(it, n * P, None)
+        assert eps.actions.dtype == np.int64 and eps.actions.ndim == 1
+        assert set(np.unique(eps.actions)) <= {0, 1}
+        host = ob.OracleEpisodeBatch(
+            observations=eps.observations,
+            last_observations=eps.last_observations, actions=eps.actions,
+            rewards=eps.rewards, step_types=eps.step_types,
+            lengths=eps.lengths, max_episode_length=P)
+        np.random.seed(70 + it)
+        want = oracle.train_once(host)
+        np.random.seed(70 + it)
+        algo._train_once(it, eps)
+        for k in LOG_KEYS:
+            assert np.isclose(algo.last_tabular[k], want[k], atol=1e-5,
+                              rtol=1e-5), (k, it, algo.last_tabular[k],
+                                           want[k])
+        wp, wv = oracle.state()
+        for k, v in pol.state_dict().items():
+            assert np.allclose(v.numpy(), wp[k], atol=1e-5), k
+        for k, v in vf.state_dict().items():
+            assert np.allclose(v.numpy(), wv[k], atol=1e-5), k
