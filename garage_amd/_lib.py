@@ -109,6 +109,10 @@ SIGNATURES = {
     'ga_synth_env_reset': (c_int, [C.POINTER(SynthEnv), ptr, ptr, c_i64, ptr]),
     'ga_synth_env_step': (c_int, [C.POINTER(SynthEnv), ptr, c_i64, ptr, ptr,
                                   c_i64, ptr, ptr, ptr]),
+    'ga_obs_normalize_f64': (c_int, [c_i64, c_int, ptr, c_i64, ptr, ptr, c_f64,
+                                     ptr, ptr]),
+    'ga_reward_normalize_f64': (c_int, [c_i64, ptr, ptr, ptr, c_f64, c_f64,
+                                        c_int, ptr]),
     'ga_policy_head_sample': (c_int, [C.POINTER(HeadArgs), ptr]),
     'ga_record_step': (c_int, [C.POINTER(RecordArgs), ptr]),
     'ga_pack_episodes': (c_int, [ptr, c_i64, c_i64, c_i64, ptr, ptr, ptr, ptr,

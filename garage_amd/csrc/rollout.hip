@@ -123,6 +123,48 @@ __global__ __launch_bounds__(256) void synth_step_kernel(
   step_type[i] = st;
 }
 
+// ---- NormalizedEnv observation / reward path -----------------------------------
+// envs/normalized_env.py:118-132,134-164: per-env exponential moving mean and
+// variance (float64 state, alpha = 0.001 by default); the mean is updated first,
+// the variance uses the NEW mean, and the value is normalised with the updated
+// statistics.  One thread per env; rows with mask == 0 are left untouched.
+__global__ __launch_bounds__(256) void obs_normalize_kernel(
+    int64_t n, int obs_dim, float* obs, int64_t ldo, double* mean, double* var,
+    double alpha, const uint8_t* mask) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  if (mask && !mask[i]) return;
+  float* o = obs + i * ldo;
+  double* m = mean + i * obs_dim;
+  double* v = var + i * obs_dim;
+  for (int j = 0; j < obs_dim; ++j) {
+    const double x = (double)o[j];
+    const double mn = (1.0 - alpha) * m[j] + alpha * x;
+    const double d = x - mn;
+    const double vn = (1.0 - alpha) * v[j] + alpha * (d * d);
+    m[j] = mn;
+    v[j] = vn;
+    o[j] = (float)((x - mn) / (sqrt(vn) + 1e-8));
+  }
+}
+
+__global__ __launch_bounds__(256) void reward_normalize_kernel(
+    int64_t n, float* reward, double* mean, double* var, double alpha, double scale,
+    int normalize) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double r = (double)reward[i];
+  if (normalize) {  // normalized_env.py:126-132,153-164
+    const double mn = (1.0 - alpha) * mean[i] + alpha * r;
+    const double d = r - mn;
+    const double vn = (1.0 - alpha) * var[i] + alpha * (d * d);
+    mean[i] = mn;
+    var[i] = vn;
+    r = r / (sqrt(vn) + 1e-8);
+  }
+  reward[i] = (float)(r * scale);
+}
+
 // ---- action heads --------------------------------------------------------------
 struct HeadParams {
   int64_t n;
@@ -616,5 +658,29 @@ extern "C" int ga_permutation_i32(int64_t n, uint64_t key, int32_t* out,
                      dim3(256), 0, stream, n, half_bits,
                      (uint32_t)(key & 0xffffffffu), (uint32_t)(key >> 32), out);
   GA_CHECK_LAUNCH("feistel_perm");
+  return GA_OK;
+}
+
+extern "C" int ga_obs_normalize_f64(int64_t n, int obs_dim, float* obs, int64_t ldo,
+                                    double* mean, double* var, double alpha,
+                                    const uint8_t* mask, hipStream_t stream) {
+  GA_REQUIRE(obs && mean && var, "ga_obs_normalize_f64: null pointer");
+  GA_REQUIRE(n > 0 && obs_dim > 0 && ldo >= obs_dim, "ga_obs_normalize_f64: bad sizes");
+  hipLaunchKernelGGL(obs_normalize_kernel, dim3((unsigned)ga_ceil_div(n, 256)),
+                     dim3(256), 0, stream, n, obs_dim, obs, ldo, mean, var, alpha, mask);
+  GA_CHECK_LAUNCH("obs_normalize");
+  return GA_OK;
+}
+
+extern "C" int ga_reward_normalize_f64(int64_t n, float* reward, double* mean,
+                                       double* var, double alpha, double scale,
+                                       int normalize, hipStream_t stream) {
+  GA_REQUIRE(reward && (!normalize || (mean && var)),
+             "ga_reward_normalize_f64: null pointer");
+  GA_REQUIRE(n > 0, "ga_reward_normalize_f64: bad size");
+  hipLaunchKernelGGL(reward_normalize_kernel, dim3((unsigned)ga_ceil_div(n, 256)),
+                     dim3(256), 0, stream, n, reward, mean, var, alpha, scale,
+                     normalize);
+  GA_CHECK_LAUNCH("reward_normalize");
   return GA_OK;
 }

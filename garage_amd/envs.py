@@ -150,6 +150,75 @@ class SyntheticVecEnv(VecEnv):
             getattr(self, k).copy_(torch.from_numpy(v))
 
 
+class NormalizedVecEnv(VecEnv):
+    """``garage.envs.normalize`` for a device batch (``envs/normalized_env.py``).
+
+    Wraps any :class:`VecEnv`; keeps one float64 moving mean / variance per
+    member env (the reference deep-copies a ``NormalizedEnv`` per env, so the
+    statistics are per env there too) and normalises every observation the
+    policy sees -- first observations, next observations and terminal ones --
+    with the statistics updated *by that observation* (``:144-147``).  Rewards
+    are scaled by ``scale_reward`` and optionally normalised the same way.
+    Action normalisation (``:90-100``) needs finite action bounds and is left to
+    the wrapped env.
+    """
+
+    def __init__(self, env, scale_reward=1., normalize_reward=False,
+                 normalize_obs=False, obs_alpha=0.001, reward_alpha=0.001):
+        self._env = env
+        self.n_envs = env.n_envs
+        self.spec = env.spec
+        self._scale_reward = float(scale_reward)
+        self._normalize_reward = bool(normalize_reward)
+        self._normalize_obs = bool(normalize_obs)
+        self._obs_alpha = float(obs_alpha)
+        self._reward_alpha = float(reward_alpha)
+        dev = env.device
+        self.device = dev
+        n, O = self.n_envs, env.obs_dim
+        self._obs_mean = torch.zeros(n, O, dtype=torch.float64, device=dev)
+        self._obs_var = torch.ones(n, O, dtype=torch.float64, device=dev)
+        self._reward_mean = torch.zeros(n, dtype=torch.float64, device=dev)
+        self._reward_var = torch.ones(n, dtype=torch.float64, device=dev)
+
+    # the wrapped env owns the buffers; expose them under the protocol names
+    obs = property(lambda self: self._env.obs)
+    next_obs = property(lambda self: self._env.next_obs)
+    reward = property(lambda self: self._env.reward)
+    step_type = property(lambda self: self._env.step_type)
+    env_id0 = property(lambda self: getattr(self._env, 'env_id0', 0))
+
+    def advance(self):
+        self._env.advance()
+
+    def _norm(self, buf, mask=None):
+        if self._normalize_obs:
+            call('ga_obs_normalize_f64', self.n_envs, self.obs_dim, dptr(buf),
+                 buf.stride(0), dptr(self._obs_mean), dptr(self._obs_var),
+                 self._obs_alpha, dptr(mask), stream_ptr())
+
+    def reset_all(self):
+        self._env.reset_all()
+        self._norm(self._env.obs)
+
+    def step_all(self, actions):
+        self._env.step_all(actions)
+        self._norm(self._env.next_obs)
+        if self._normalize_reward or self._scale_reward != 1.0:
+            call('ga_reward_normalize_f64', self.n_envs,
+                 dptr(self._env.reward), dptr(self._reward_mean),
+                 dptr(self._reward_var), self._reward_alpha,
+                 self._scale_reward, int(self._normalize_reward),
+                 stream_ptr())
+
+    def reset_where(self, done):
+        self._env.reset_where(done)
+        self._norm(self._env.next_obs, done)
+
+    def close(self):
+        self._env.close()
+
+
 class HostVecEnv(VecEnv):
     """Adapter: a list of per-env CPU objects behind the batched protocol.
 

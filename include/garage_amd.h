@@ -170,6 +170,17 @@ int ga_synth_env_step(const ga_synth_env* env, const float* actions, int64_t lda
                       const float* obs, float* next_obs, int64_t ldo, float* reward,
                       uint8_t* step_type, ga_stream_t stream);
 
+/* NormalizedEnv's observation / reward normalisation
+ * (envs/normalized_env.py:118-132,134-164): per-env float64 moving mean and
+ * variance, updated before use; rows with mask == 0 (or all when NULL) only.
+ * reward = (normalize ? r / (sqrt(var) + 1e-8) : r) * scale. */
+int ga_obs_normalize_f64(int64_t n, int obs_dim, float* obs, int64_t ldo,
+                         double* mean, double* var, double alpha,
+                         const uint8_t* mask, ga_stream_t stream);
+int ga_reward_normalize_f64(int64_t n, float* reward, double* mean, double* var,
+                            double alpha, double scale, int normalize,
+                            ga_stream_t stream);
+
 /* dist.sample() of StochasticPolicy.get_actions
  * (torch/policies/stochastic_policy.py:46-89) + the per-env list appends of
  * VecWorker.step_episode (sampler/vec_worker.py:187-197) for observations and
