@@ -47,7 +47,8 @@ class RecordArgs(C.Structure):
                 ('step_type', ptr), ('next_obs', ptr), ('ldo', c_i64),
                 ('obs_dim', c_i32), ('ep_t', ptr), ('rew_buf', ptr),
                 ('st_buf', ptr), ('tail_buf', ptr), ('lastobs_buf', ptr),
-                ('done', ptr), ('step_eps', ptr), ('step_samples', ptr)]
+                ('done', ptr), ('step_eps', ptr), ('step_samples', ptr),
+                ('terminal_only', c_i32)]
 
 
 class UpdateArgs(C.Structure):

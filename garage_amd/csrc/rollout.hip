@@ -296,6 +296,7 @@ struct RecordParams {
   uint8_t* done;             // [n] 1 where the env must be reset
   int32_t* step_eps;         // [Tcap] episodes finished at this step
   int32_t* step_samples;     // [Tcap] their total length
+  int terminal_only;         // 1: only TERMINAL (not TIMEOUT) ends an episode
 };
 
 __global__ __launch_bounds__(256) void record_step_kernel(RecordParams p) {
@@ -305,7 +306,10 @@ __global__ __launch_bounds__(256) void record_step_kernel(RecordParams p) {
     const int64_t cell = i * p.Tcap + p.col;
     const int t = p.ep_t[i] + 1;
     const uint8_t st = p.step_type[i];
-    const bool ended = (t >= p.max_episode_length) || (st >= 2);
+    // VecWorker ends an episode on any last step (vec_worker.py:198);
+    // FragmentWorker only on TERMINAL (fragment_worker.py:114-115)
+    const bool ended = (t >= p.max_episode_length) ||
+                       (p.terminal_only ? (st == 2) : (st >= 2));
     p.rew_buf[cell] = p.reward[i];
     p.st_buf[cell] = st;
     p.tail_buf[cell] = ended ? (uint16_t)t : (uint16_t)0;
@@ -552,6 +556,7 @@ struct ga_record_args {
   int64_t ldo; int32_t obs_dim;
   int32_t* ep_t; float* rew_buf; uint8_t* st_buf; uint16_t* tail_buf;
   float* lastobs_buf; uint8_t* done; int32_t* step_eps; int32_t* step_samples;
+  int32_t terminal_only;
 };
 
 extern "C" int ga_record_step(const ga_record_args* a, hipStream_t stream) {
@@ -571,6 +576,7 @@ extern "C" int ga_record_step(const ga_record_args* a, hipStream_t stream) {
   p.obs_dim = a->obs_dim; p.ep_t = a->ep_t; p.rew_buf = a->rew_buf;
   p.st_buf = a->st_buf; p.tail_buf = a->tail_buf; p.lastobs_buf = a->lastobs_buf;
   p.done = a->done; p.step_eps = a->step_eps; p.step_samples = a->step_samples;
+  p.terminal_only = a->terminal_only;
   hipLaunchKernelGGL(record_step_kernel, dim3((unsigned)ga_ceil_div(a->n, 256)),
                      dim3(256), 0, stream, p);
   GA_CHECK_LAUNCH("record_step");

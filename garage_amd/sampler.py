@@ -232,6 +232,7 @@ class GpuVecWorker:
         r.done = b['done'].data_ptr()
         r.step_eps = b['step_eps'].data_ptr()
         r.step_samples = b['step_samples'].data_ptr()
+        r.terminal_only = getattr(self, '_terminal_only', 0)
         call('ga_record_step', C.byref(r), s)
         env.reset_where(b['done'])
         env.advance()
@@ -368,6 +369,123 @@ class GpuVecWorker:
                          'Please pickle the WorkerFactory instead.')
 
 
+class GpuFragmentWorker(GpuVecWorker):
+    """``FragmentWorker`` (``sampler/fragment_worker.py:11-156``) on the GPU.
+
+    Each ``rollout()`` advances every env by ``timesteps_per_call`` steps and
+    returns *fragments*: the pieces of episodes collected during the call, cut
+    at episode ends and at the end of the call.  Fragments that ended with their
+    episode come first, in (step, env) order; the still-running ones follow in
+    env order (``collect_episode``, ``:121-138``).  Episodes continue across
+    calls (``update_agent`` does not reset them) and only TERMINAL -- not
+    TIMEOUT -- or ``max_episode_length`` ends one (``:114-115``).
+    """
+
+    def __init__(self, *, seed, max_episode_length, worker_number,
+                 n_envs=GpuVecWorker.DEFAULT_N_ENVS, timesteps_per_call=1,
+                 noise_fn=None, store_agent_infos=True):
+        super().__init__(seed=seed, max_episode_length=max_episode_length,
+                         worker_number=worker_number, n_envs=n_envs,
+                         noise_fn=noise_fn,
+                         store_agent_infos=store_agent_infos)
+        self._timesteps_per_call = int(timesteps_per_call)
+        self._terminal_only = 1
+
+    def update_agent(self, agent_update):
+        """``default_worker.py:55-69``: no reset flag for fragment workers."""
+        if isinstance(agent_update, (dict, tuple, np.ndarray)):
+            self.agent.set_param_values(agent_update)
+        elif agent_update is not None:
+            self.agent = agent_update
+
+    def _start(self):
+        """``fragment_worker.py:89-96``: only an env update restarts episodes."""
+        if self._needs_env_reset or self._ep_t is None:
+            self.agent.reset([True] * self._n_envs)
+            self.env.reset_all()
+            self._ep_t = torch.zeros(self._n_envs, dtype=torch.int32,
+                                     device=self.device)
+        self._needs_agent_reset = False
+        self._needs_env_reset = False
+
+    def rollout_samples(self, num_samples):
+        raise NotImplementedError('fragment workers are driven by rollout()')
+
+    def rollout(self):
+        self._start()
+        n, tpc = self._n_envs, self._timesteps_per_call
+        b = self._alloc_buffers(n * tpc)
+        for col in range(tpc):
+            self._step(b, col)
+        # fragment table on the host: the (n, tpc) tail matrix is tiny
+        tail = b['tail'][:, :tpc].to(torch.int32).cpu().numpy()
+        env_id, end, length = [], [], []
+        cut = np.zeros(n, dtype=np.int64)  # first column of the open fragment
+        for t in range(tpc):               # fragments closed by an episode end
+            for i in np.nonzero(tail[:, t])[0]:
+                env_id.append(i)
+                end.append(t)
+                length.append(t - cut[i] + 1)
+                cut[i] = t + 1
+        n_closed = len(env_id)
+        for i in range(n):                 # still-running fragments, env order
+            if cut[i] < tpc:
+                env_id.append(i)
+                end.append(tpc - 1)
+                length.append(tpc - cut[i])
+        return self._pack_fragments(b, np.asarray(env_id), np.asarray(end),
+                                    np.asarray(length), n_closed)
+
+    def _pack_fragments(self, b, env_id, end, length, n_closed):
+        dev, tcap = self.device, b['Tcap']
+        s = stream_ptr()
+        n_frag = len(env_id)
+        ep_env = torch.from_numpy(env_id.astype(np.int32)).to(dev)
+        ep_end = torch.from_numpy(end.astype(np.int32)).to(dev)
+        ep_len = torch.from_numpy(length.astype(np.int32)).to(dev)
+        off = np.concatenate([[0], np.cumsum(length)]).astype(np.int64)
+        S = int(off[-1])
+        off_dev = torch.from_numpy(off).to(dev)
+        src = torch.empty(S, dtype=torch.int32, device=dev)
+        call('ga_pack_src_index', dptr(ep_env), dptr(ep_end), dptr(ep_len),
+             dptr(off_dev), n_frag, tcap, dptr(src), s)
+
+        def rows(buf, idx, count, ld=None):
+            w = buf.shape[-1]
+            out = torch.empty(count, w, dtype=torch.float32, device=dev)
+            call('ga_gather_rows_f32', dptr(buf), w, dptr(idx), count, w,
+                 dptr(out), w, s)
+            return out
+
+        obs = rows(b['obs'], src, S)
+        act = rows(b['act'], src, S)
+        head = rows(b['head'], src, S) if b['head'] is not None else None
+        # last observation: the terminal one for closed fragments, the env's
+        # current observation for the running ones
+        last = torch.empty(n_frag, obs.shape[1], dtype=torch.float32,
+                           device=dev)
+        if n_closed:
+            cell = (ep_env[:n_closed].long() * tcap +
+                    ep_end[:n_closed].long()).to(torch.int32)
+            last[:n_closed] = rows(b['lastobs'], cell, n_closed)
+        if n_frag > n_closed:
+            last[n_closed:] = rows(self.env.obs, ep_env[n_closed:].contiguous(),
+                                   n_frag - n_closed)
+        rew = torch.empty(S, dtype=torch.float32, device=dev)
+        call('ga_gather_f32', dptr(b['rew']), dptr(src), S, dptr(rew), s)
+        st = torch.empty(S, dtype=torch.uint8, device=dev)
+        call('ga_gather_u8', dptr(b['st']), dptr(src), S, dptr(st), s)
+        pol = self.agent
+        gaussian = pol.kind == 'gaussian'
+        return DeviceEpisodeBatch(
+            self.env.spec, lengths=length.astype(np.int64), obs_dev=obs,
+            last_obs_dev=last, actions_dev=act, rewards_dev=rew,
+            step_types_dev=st, ep_off_dev=off_dev, head_dev=head,
+            head_name='mean' if gaussian else 'prob',
+            log_std=pol.clamped_log_std() if gaussian else None,
+            discrete=is_discrete(self.env.spec.action_space))
+
+
 class GpuVecSampler:
     """``LocalSampler`` (``sampler/local_sampler.py:13-232``) for GPU workers.
 
@@ -423,7 +541,8 @@ class GpuVecSampler:
         """``local_sampler.py:134-166``."""
         del itr
         self._update_workers(agent_update, env_update)
-        if len(self._workers) == 1:
+        if len(self._workers) == 1 and not isinstance(self._workers[0],
+                                                      GpuFragmentWorker):
             samples = self._workers[0].rollout_samples(num_samples)
         else:
             batches, done = [], 0
@@ -464,4 +583,5 @@ class GpuVecSampler:
         self._build_workers()
 
 
-__all__ = ['WorkerFactory', 'GpuVecWorker', 'GpuVecSampler']
+__all__ = ['WorkerFactory', 'GpuVecWorker', 'GpuFragmentWorker',
+           'GpuVecSampler']

@@ -208,6 +208,8 @@ typedef struct {
   int64_t ldo; int32_t obs_dim;
   int32_t* ep_t; float* rew_buf; uint8_t* st_buf; uint16_t* tail_buf;
   float* lastobs_buf; uint8_t* done; int32_t* step_eps; int32_t* step_samples;
+  int32_t terminal_only; /* 1: FragmentWorker rule, only TERMINAL ends an episode
+                            (sampler/fragment_worker.py:114-115) */
 } ga_record_args;
 int ga_record_step(const ga_record_args* args, ga_stream_t stream);
 
