@@ -190,6 +190,9 @@ def main():
     ap.add_argument('--cpu-envs', type=int, default=256,
                     help='envs of the bounded CPU-baseline sample (0: skip)')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-overlap', action='store_true',
+                    help='run the policy and value-function passes one after '
+                    'the other on one stream (isolated per-kernel timings)')
     args = ap.parse_args()
 
     from garage_amd.distributed import init_from_env
@@ -201,6 +204,7 @@ def main():
               file=sys.stderr)
     cfg = CONFIGS[args.config]
     algo, sampler, pol, S = build_engine(cfg, comm)
+    algo.overlap_updates = not args.no_overlap
 
     def sync():
         if comm is not None:
@@ -247,12 +251,14 @@ def main():
             'workload': '{}: obs {} act {}, {} envs/GPU x T={}, '
                         'MLP{} policy + value, PPO E={} x {} minibatches, '
                         'gamma {} lambda {} clip {} Adam lr {}, device '
-                        'minibatch permutation'.format(
+                        'minibatch permutation, policy/value passes {}'.format(
                             cfg['name'], cfg['obs_dim'], cfg['act_dim'],
                             cfg['n_envs'], cfg['T'], cfg['hidden'],
                             HYPER['epochs'], HYPER['minibatches_per_epoch'],
                             HYPER['discount'], HYPER['gae_lambda'],
-                            HYPER['lr_clip_range'], HYPER['lr']),
+                            HYPER['lr_clip_range'], HYPER['lr'],
+                            'serial' if args.no_overlap else
+                            'overlapped on 2 streams'),
             'config_id': args.config,
             'parallelism': 'dp{}'.format(world),
         },
@@ -268,6 +274,19 @@ def main():
             'launches_per_iteration': dom['launches'],
             'avg_launch_us': dom['total_ms'] * 1e3 / dom['launches'],
             'share_of_iteration': dom['total_ms'] / ms_per_step,
+        }
+        line['roofline']['update_streams'] = 1 if args.no_overlap else 2
+        # all GEMM launches of the iteration against its wall time: with the two
+        # update chains overlapped, per-kernel durations include time sharing,
+        # so this aggregate is the utilisation figure that adds up
+        all_flops = sum(r['work'] for r in rows[:6])
+        agg = all_flops / (ms_per_step * 1e-3) / 1e12
+        line['mfma_aggregate'] = {
+            'achieved': agg, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': agg / PEAK_FP32_MFMA_TFLOPS,
+            'flops_per_iteration': all_flops,
+            'note': 'algorithmic GEMM flops of one iteration / ms_per_step '
+                    '(rollout, scan, losses and optimiser time included)',
         }
         scan = rows[6]
         if scan['launches'] > 0:

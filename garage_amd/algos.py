@@ -416,10 +416,10 @@ class VPG:
     def _train(self, batch, adv, returns, old_ll):
         S = batch.n_samples
         if self._native_update_ok():
-            self._train_native(self._policy_optimizer, self.policy, 0, batch,
-                               adv, returns, old_ll)
-            self._train_native(self._vf_optimizer, self._value_function, 1,
-                               batch, adv, returns, old_ll)
+            if getattr(self, 'overlap_updates', True):
+                self._train_native_pair(batch, adv, returns, old_ll)
+            else:
+                self._train_native_serial(batch, adv, returns, old_ll)
             return
         for idx in self._policy_optimizer.minibatch_indices(S):
             self._train_policy(batch, adv, old_ll, idx)
@@ -440,7 +440,9 @@ class VPG:
                 return False
         return True
 
-    def _train_native(self, opt, module, kind, batch, adv, returns, old_ll):
+    def _update_args(self, opt, module, kind, batch, adv, returns, old_ll,
+                     tag):
+        """``ga_update_args`` of one network (kept alive by the caller)."""
         from garage_amd import _lib
         import ctypes as C
         net = module.net
@@ -484,16 +486,79 @@ class VPG:
             a.returns = returns.data_ptr()
         scratch = torch.empty(1, dtype=torch.float32, device=dev)
         a.loss_scratch = scratch.data_ptr()
-        a.workspace = reduction_workspace(dev).data_ptr()
+        a.workspace = reduction_workspace(dev, tag).data_ptr()
         comm = getattr(opt, 'native_comm', None)
         if comm is not None:
             a.comm, a.world = comm.handle, comm.world_size
         n_mb = 1 if mb is None else -(-S // mb)
-        for perm in opt.epoch_permutations(S):
-            a.perm = None if perm is None else perm.data_ptr()
-            a.step0 = net.adam_steps
-            call('ga_update_epoch', C.byref(a), stream_ptr())
-            net.adam_steps += n_mb
+        return a, scratch, n_mb
+
+    def _train_native_serial(self, batch, adv, returns, old_ll):
+        """Policy pass then value pass on the current stream (the reference's
+        order, ``vpg.py:244-248``); ``overlap_updates = False`` selects it."""
+        import ctypes as C
+        S = batch.n_samples
+        for opt, module, kind in ((self._policy_optimizer, self.policy, 0),
+                                  (self._vf_optimizer, self._value_function,
+                                   1)):
+            a, keep, n_mb = self._update_args(opt, module, kind, batch, adv,
+                                              returns, old_ll, 0)
+            for perm in opt.epoch_permutations(S):
+                a.perm = None if perm is None else perm.data_ptr()
+                a.step0 = module.net.adam_steps
+                call('ga_update_epoch', C.byref(a), stream_ptr())
+                module.net.adam_steps += n_mb
+            del keep
+
+    def _train_native_pair(self, batch, adv, returns, old_ll):
+        """Policy and value-function passes, interleaved on two HIP streams.
+
+        The reference finishes the policy before it starts the value function
+        (``vpg.py:244-248``); the two share no written state, so
+        overlapping them changes nothing but the wall time.  The host-side
+        permutation draws keep the reference's order: every policy shuffle
+        happens before the first value-function shuffle.
+        """
+        import ctypes as C
+        S = batch.n_samples
+        popt, vopt = self._policy_optimizer, self._vf_optimizer
+        pa, keep_p, n_p = self._update_args(popt, self.policy, 0, batch, adv,
+                                            returns, old_ll, 0)
+        va, keep_v, n_v = self._update_args(vopt, self._value_function, 1,
+                                            batch, adv, returns, old_ll, 1)
+        p_perms = list(popt.epoch_permutations(S))
+        v_perms = list(vopt.epoch_permutations(S))
+        main = torch.cuda.current_stream()
+        if getattr(self, '_side_stream', None) is None:
+            self._side_stream = torch.cuda.Stream()
+        side = self._side_stream
+        side.wait_stream(main)  # inputs (adv, returns, perms) are ready
+        pnet, vnet = self.policy.net, self._value_function.net
+        s_main = C.c_void_p(main.cuda_stream)
+        s_side = C.c_void_p(side.cuda_stream)
+        for e in range(max(len(p_perms), len(v_perms))):
+            has_p, has_v = e < len(p_perms), e < len(v_perms)
+            if has_p:
+                pp = p_perms[e]
+                pa.perm = None if pp is None else pp.data_ptr()
+                pa.step0 = pnet.adam_steps
+            if has_v:
+                vp = v_perms[e]
+                va.perm = None if vp is None else vp.data_ptr()
+                va.step0 = vnet.adam_steps
+            if has_p and has_v:
+                call('ga_update_epoch_pair', C.byref(pa), s_main, C.byref(va),
+                     s_side)
+            elif has_p:
+                call('ga_update_epoch', C.byref(pa), s_main)
+            else:
+                call('ga_update_epoch', C.byref(va), s_side)
+            if has_p:
+                pnet.adam_steps += n_p
+            if has_v:
+                vnet.adam_steps += n_v
+        main.wait_stream(side)
+        del keep_p, keep_v
 
     def _train_policy(self, batch, adv, old_ll, idx):
         M = batch.n_samples if idx is None else int(idx.numel())

@@ -110,15 +110,16 @@ def shard_algo(algo, comm):
     if comm is None:
         return algo
     algo._comm = comm
-    native = None
-    if dist.get_backend(comm.group) == 'nccl':
-        native = NativeComm(comm)  # RCCL inside the C++ epoch loop
+    use_rccl = dist.get_backend(comm.group) == 'nccl'
     for module, opt in ((algo.policy, algo._policy_optimizer),
                         (algo._value_function, algo._vf_optimizer)):
         comm.broadcast(module.net.params)
         comm.broadcast(module.net.exp_avg)
         comm.broadcast(module.net.exp_avg_sq)
         opt.grad_hook = comm.all_reduce_mean
-        opt.native_comm = native
+        # RCCL inside the C++ epoch loop; one communicator per network because
+        # the two passes run on two streams and a communicator's collectives
+        # must be issued in one order on every rank
+        opt.native_comm = NativeComm(comm) if use_rccl else None
     algo._old_policy.sync(algo.policy)
     return algo

@@ -27,9 +27,9 @@ def require_gpu():
 _WS = {}
 
 
-def reduction_workspace(device):
-    """Per-device fp64 scratch for the two-level reductions."""
-    key = (device.type, device.index)
+def reduction_workspace(device, tag=0):
+    """Per-device (and per concurrent stream: ``tag``) fp64 reduction scratch."""
+    key = (device.type, device.index, tag)
     if key not in _WS:
         n = int(_lib.load().ga_reduction_workspace_doubles())
         _WS[key] = torch.empty(n, dtype=torch.float64, device=device)

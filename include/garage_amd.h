@@ -267,6 +267,13 @@ typedef struct {
   int32_t double_softmax;    /* kind 2 */
 } ga_update_args;
 int ga_update_epoch(const ga_update_args* args, ga_stream_t stream);
+/* The policy pass and the value-function pass of one epoch, minibatch by
+ * minibatch alternately on two streams.  The reference runs them back to back
+ * (vpg.py:244-248); they share no written state, so the results are identical
+ * and the two launch chains overlap on the device.  The two argument sets must
+ * not share parameter, slab, activation or reduction buffers. */
+int ga_update_epoch_pair(const ga_update_args* a, ga_stream_t stream_a,
+                         const ga_update_args* b, ga_stream_t stream_b);
 
 /* RCCL communicator for the data-parallel gradient all-reduce (new: the
  * reference has no collective on this path).
