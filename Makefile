@@ -6,7 +6,7 @@ HIPCC ?= /opt/rocm/bin/hipcc
 ARCH  ?= gfx950
 CSRC  := garage_amd/csrc
 OUT   := garage_amd/_C
-HIPS  := gae_scan gemm losses rollout
+HIPS  := gae_scan gemm losses rollout policy_fused
 CPPS  := errors prof update comm
 OBJS  := $(patsubst %,$(OUT)/%.o,$(HIPS) $(CPPS))
 FLAGS := --offload-arch=$(ARCH) -O3 -fPIC -std=c++17 -Wall -Wno-unused-function

@@ -56,6 +56,18 @@ KIND_NAMES = [
 ]
 
 
+TRAFFIC_FILE = 'profiles/r01_traffic.json'
+
+
+def load_traffic():
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (C3)."""
+    path = os.path.join(ROOT, TRAFFIC_FILE)
+    if not os.path.exists(path):
+        return {}
+    with open(path) as f:
+        return json.load(f).get('kernels', {})
+
+
 def build_engine(cfg, comm, seed=1):
     from garage_amd.algos import PPO
     from garage_amd.distributed import shard_algo
@@ -276,6 +288,11 @@ def main():
             'share_of_iteration': dom['total_ms'] / ms_per_step,
         }
         line['roofline']['update_streams'] = 1 if args.no_overlap else 2
+        traffic = load_traffic()
+        key = dom['kernel'].split(' (')[0].replace(',', ', ')
+        if args.config == 'c3' and key in traffic:
+            line['roofline']['traffic'] = traffic[key]['hbm_bytes']
+            line['roofline']['traffic_source'] = TRAFFIC_FILE
         # all GEMM launches of the iteration against its wall time: with the two
         # update chains overlapped, per-kernel durations include time sharing,
         # so this aggregate is the utilisation figure that adds up
@@ -298,6 +315,10 @@ def main():
                 'avg_launch_us': scan['total_ms'] * 1e3 / scan['launches'],
                 'bytes_per_launch': scan['work'] / scan['launches'],
             }
+            if args.config == 'c3' and 'gae_scan_kernel<true>' in traffic:
+                line['roofline_gae_scan']['traffic'] = \
+                    traffic['gae_scan_kernel<true>']['hbm_bytes']
+                line['roofline_gae_scan']['traffic_source'] = TRAFFIC_FILE
         line['kernels'] = [
             dict(kernel=r['kernel'], launches=r['launches'],
                  total_ms=round(r['total_ms'], 3),

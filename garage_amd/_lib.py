@@ -115,6 +115,9 @@ SIGNATURES = {
     'ga_reward_normalize_f64': (c_int, [c_i64, ptr, ptr, ptr, c_f64, c_f64,
                                         c_int, ptr]),
     'ga_policy_head_sample': (c_int, [C.POINTER(HeadArgs), ptr]),
+    'ga_policy_step_fused_supported': (c_int, [C.POINTER(MlpDesc)]),
+    'ga_policy_step_fused_f32': (c_int, [C.POINTER(MlpDesc), ptr,
+                                         C.POINTER(HeadArgs), ptr]),
     'ga_record_step': (c_int, [C.POINTER(RecordArgs), ptr]),
     'ga_pack_episodes': (c_int, [ptr, c_i64, c_i64, c_i64, ptr, ptr, ptr, ptr,
                                  ptr]),

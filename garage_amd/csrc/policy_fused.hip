@@ -1,0 +1,374 @@
+// Fused rollout step: MLP policy forward + action head in ONE launch.
+//
+// Replaces, per vectorised step of VecWorker.step_episode
+// (sampler/vec_worker.py:176-204), the chain
+//   StochasticPolicy.get_actions -> GaussianMLPModule.forward -> MLP layers ->
+//   dist.sample()  (torch/policies/stochastic_policy.py:46-89,
+//   torch/modules/gaussian_mlp_module.py:158-192, multi_headed_mlp_module.py:136-151)
+// and the per-env appends of observations / actions / agent_info.
+//
+// One workgroup (4 waves) owns 32 envs for the whole network: the activations
+// of those 32 rows never leave the CU (two [32][H+4] fp32 tiles in LDS, ping /
+// pong between layers), the weights stream from L2 through a double-buffered
+// [N][32+4] LDS stage in 32-wide k chunks (16-B loads, branch free), hidden
+// layers run on v_mfma_f32_32x32x2_f32 with the same k <-> slot map as the
+// update GEMMs (so means agree with the unfused path to rounding), the narrow
+// output layer is an 8-lane VALU dot product, and the head (Gaussian: mean +
+// std * noise; categorical: inverse CDF) writes the action and the rollout
+// buffers.  At n = 4096 that is 128 workgroups and one ~10 us launch instead of
+// four launches (~65 us).  Hidden widths up to 256 (C2, C3); wider nets use the
+// per-layer path.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int ROWS = 32;          // envs per workgroup
+constexpr int HMAX = 256;         // widest supported layer
+constexpr int LDACT = HMAX + 4;   // activation tile row stride (floats)
+constexpr int KC = 32;            // k chunk
+constexpr int LDW = KC + 4;       // weight stage row stride
+constexpr int MAX_OUT = 32;       // widest output head
+
+struct U4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2,
+                                            uint32_t c3, uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+    const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+    const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return U4{c0, c1, c2, c3};
+}
+__device__ __forceinline__ float unit_interval(uint32_t u) {
+  return ((float)(u >> 8) + 0.5f) * 5.9604644775390625e-08f;
+}
+__device__ __forceinline__ void box_muller(uint32_t u0, uint32_t u1, float* z0,
+                                           float* z1) {
+  const float a = unit_interval(u0), b = unit_interval(u1);
+  const float rad = sqrtf(-2.f * logf(a));
+  float s, c;
+  sincosf(6.28318530717958647692f * b, &s, &c);
+  *z0 = rad * c;
+  *z1 = rad * s;
+}
+__device__ __forceinline__ float tanh_fast(float x) {
+  const float e = __expf(2.f * x);
+  return 1.f - 2.f * __frcp_rn(e + 1.f);
+}
+
+struct FusedParams {
+  int n_layers;
+  int dims[9];
+  int64_t w_off[8], b_off[8];
+  const float* params;
+  int64_t n, env_id0;
+  int kind;  // 0 gaussian, 1 categorical
+  int has_min, has_max;
+  float min_log_std, max_log_std;
+  const float* noise;
+  int64_t ldn;
+  uint32_t k0, k1, step;
+  int double_softmax;
+  const float* obs;
+  int64_t ldo;
+  int64_t col, Tcap;
+  float* action;
+  int64_t lda;
+  float* obs_buf;
+  float* act_buf;
+  float* head_buf;
+  int64_t ldh;
+};
+
+// Stage W[:, k0 : k0 + 32] of a [N][ldw] weight matrix: registers -> LDS.
+struct WeightStage {
+  float4 regs[HMAX * KC / 4 / 256];  // 8 vectors per thread at N = 256
+
+  __device__ __forceinline__ void load(const float* __restrict__ W, int ldw, int N,
+                                       int K, int k0) {
+    const int last = max(((K + 3) & ~3) - 4, 0);
+#pragma unroll
+    for (int i = 0; i < HMAX * KC / 4 / 256; ++i) {
+      const int f = threadIdx.x + 256 * i;
+      const int nrow = min(f >> 3, N - 1);
+      const int k = min(k0 + 4 * (f & 7), last);
+      regs[i] = *reinterpret_cast<const float4*>(W + (int64_t)nrow * ldw + k);
+    }
+  }
+  __device__ __forceinline__ void store(float* __restrict__ stage, int N, int K,
+                                        int k0) const {
+#pragma unroll
+    for (int i = 0; i < HMAX * KC / 4 / 256; ++i) {
+      const int f = threadIdx.x + 256 * i;
+      const int nrow = f >> 3;
+      const int k = 4 * (f & 7);
+      float4 v = regs[i];
+      const bool ok = nrow < N;
+      v.x = (ok && k0 + k + 0 < K) ? v.x : 0.f;
+      v.y = (ok && k0 + k + 1 < K) ? v.y : 0.f;
+      v.z = (ok && k0 + k + 2 < K) ? v.z : 0.f;
+      v.w = (ok && k0 + k + 3 < K) ? v.w : 0.f;
+      *reinterpret_cast<float4*>(stage + nrow * LDW + k) = v;
+    }
+  }
+};
+
+__global__ __launch_bounds__(256) void policy_step_fused_kernel(FusedParams p) {
+  __shared__ __attribute__((aligned(16))) float act[2][ROWS * LDACT];
+  __shared__ __attribute__((aligned(16))) float wst[2][HMAX * LDW];
+  __shared__ float head[ROWS][MAX_OUT];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int64_t row0 = (int64_t)blockIdx.x * ROWS;
+  const int L = p.n_layers;
+
+  // ---- observations -> act[0] (zero padded to a multiple of the k chunk) and
+  //      into the rollout buffer (the list append of vec_worker.py:188)
+  const int in_w = p.dims[0];
+  const int in_pad = (in_w + KC - 1) / KC * KC;
+  for (int e = tid; e < ROWS * in_pad; e += 256) {
+    const int r = e / in_pad, c = e % in_pad;
+    const int64_t env = row0 + r;
+    float v = 0.f;
+    if (env < p.n && c < in_w) {
+      v = p.obs[env * p.ldo + c];
+      p.obs_buf[(env * p.Tcap + p.col) * p.ldo + c] = v;
+    }
+    act[0][r * LDACT + c] = v;
+  }
+  __syncthreads();
+
+  // ---- hidden layers on the matrix cores
+  int cur = 0;
+  for (int l = 0; l < L - 1; ++l) {
+    const int K = p.dims[l], N = p.dims[l + 1];
+    const int ldw = (K + 3) & ~3;
+    const float* W = p.params + p.w_off[l];
+    const float* bias = p.params + p.b_off[l];
+    const int nk = (K + KC - 1) / KC;
+    const int n0 = wave * 64;  // this wave's 64 output columns
+    const bool wave_on = n0 < N;
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    WeightStage ws;
+    ws.load(W, ldw, N, K, 0);
+    ws.store(wst[0], N, K, 0);
+    __syncthreads();
+    for (int s = 0; s < nk; ++s) {
+      const bool more = s + 1 < nk;
+      if (more) ws.load(W, ldw, N, K, (s + 1) * KC);
+      if (wave_on) {
+        const float* A = act[cur] + l31 * LDACT + s * KC;
+        const float* B = wst[s & 1];
+#pragma unroll
+        for (int g = 0; g < KC / 8; ++g) {
+          const float4 av = *reinterpret_cast<const float4*>(A + 8 * g + 4 * half);
+          const float a4[4] = {av.x, av.y, av.z, av.w};
+          float b4[2][4];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const float4 bv = *reinterpret_cast<const float4*>(
+                B + (n0 + 32 * j + l31) * LDW + 8 * g + 4 * half);
+            b4[j][0] = bv.x; b4[j][1] = bv.y; b4[j][2] = bv.z; b4[j][3] = bv.w;
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q], b4[j][q], acc[j],
+                                                            0, 0, 0);
+        }
+      }
+      if (more) ws.store(wst[(s + 1) & 1], N, K, (s + 1) * KC);
+      __syncthreads();
+    }
+    // bias + tanh -> the other activation tile (zero padded to the k chunk)
+    float* out = act[cur ^ 1];
+    const int n_pad = (N + KC - 1) / KC * KC;
+    if (wave_on) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int ncol = n0 + 32 * j + l31;
+        const float bv = ncol < N ? bias[ncol] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
+          const float v = ncol < N ? tanh_fast(acc[j][r] + bv) : 0.f;
+          if (ncol < n_pad) out[m * LDACT + ncol] = v;
+        }
+      }
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- narrow output layer: 8 lanes per row split k, VALU dot products
+  {
+    const int K = p.dims[L - 1], N = p.dims[L];
+    const int ldw = (K + 3) & ~3;
+    const float* W = p.params + p.w_off[L - 1];
+    const float* bias = p.params + p.b_off[L - 1];
+    const int r = tid >> 3, part = tid & 7;
+    const float* a = act[cur] + r * LDACT;
+    for (int o = 0; o < N; ++o) {
+      const float* w = W + (int64_t)o * ldw;
+      float sum = 0.f;
+      for (int k = part * 4; k < K; k += 32) {
+        const float4 wv = *reinterpret_cast<const float4*>(w + k);
+        const float4 xv = *reinterpret_cast<const float4*>(a + k);
+        sum += xv.x * wv.x;
+        if (k + 1 < K) sum += xv.y * wv.y;
+        if (k + 2 < K) sum += xv.z * wv.z;
+        if (k + 3 < K) sum += xv.w * wv.w;
+      }
+      sum += __shfl_xor(sum, 1, 64);
+      sum += __shfl_xor(sum, 2, 64);
+      sum += __shfl_xor(sum, 4, 64);
+      if (part == 0) head[r][o] = sum + bias[o];
+    }
+  }
+  __syncthreads();
+
+  // ---- action head: one thread per env
+  if (tid < ROWS) {
+    const int64_t env = row0 + tid;
+    if (env < p.n) {
+      const int N = p.dims[L];
+      const int64_t cell = env * p.Tcap + p.col;
+      const float* h = head[tid];
+      if (p.head_buf) {
+        // agent_info: Gaussian mean (probabilities are written below)
+        if (p.kind == 0)
+          for (int j = 0; j < N; ++j) p.head_buf[cell * p.ldh + j] = h[j];
+      }
+      if (p.kind == 0) {
+        float s = p.params[0];
+        if (p.has_min) s = fmaxf(s, p.min_log_std);
+        if (p.has_max) s = fminf(s, p.max_log_std);
+        const float sd = expf(s);
+        for (int b = 0; b * 4 < N; ++b) {
+          float z[4];
+          if (p.noise) {
+            for (int j = 0; j < 4 && b * 4 + j < N; ++j)
+              z[j] = p.noise[env * p.ldn + b * 4 + j];
+          } else {
+            const U4 rr = philox4x32_10((uint32_t)(p.env_id0 + env), p.step,
+                                        (uint32_t)b, 3u << 16, p.k0, p.k1);
+            box_muller(rr.x, rr.y, &z[0], &z[1]);
+            box_muller(rr.z, rr.w, &z[2], &z[3]);
+          }
+          for (int j = 0; j < 4 && b * 4 + j < N; ++j) {
+            const float a = h[b * 4 + j] + sd * z[j];
+            p.action[env * p.lda + b * 4 + j] = a;
+            p.act_buf[cell * p.lda + b * 4 + j] = a;
+          }
+        }
+      } else {
+        float mx = h[0];
+        for (int j = 1; j < N; ++j) mx = fmaxf(mx, h[j]);
+        float den = 0.f;
+        for (int j = 0; j < N; ++j) den += expf(h[j] - mx);
+        float den2 = 0.f;
+        if (p.double_softmax)
+          for (int j = 0; j < N; ++j) den2 += expf(expf(h[j] - mx) / den);
+        float u;
+        if (p.noise) {
+          u = p.noise[env * p.ldn];
+        } else {
+          const U4 rr = philox4x32_10((uint32_t)(p.env_id0 + env), p.step, 0u,
+                                      3u << 16, p.k0, p.k1);
+          u = unit_interval(rr.x);
+        }
+        float cdf = 0.f;
+        int pick = N - 1;
+        bool found = false;
+        for (int j = 0; j < N; ++j) {
+          float pr = expf(h[j] - mx) / den;
+          if (p.double_softmax) pr = expf(pr) / den2;
+          if (p.head_buf) p.head_buf[cell * p.ldh + j] = pr;
+          cdf += pr;
+          if (!found && u < cdf) { pick = j; found = true; }
+        }
+        p.action[env * p.lda] = (float)pick;
+        p.act_buf[cell * p.lda] = (float)pick;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+struct ga_mlp_desc_c {
+  int32_t n_layers;
+  int32_t dims[9];
+  int64_t w_off[8];
+  int64_t b_off[8];
+  int64_t act_off[8];
+};
+
+struct ga_head_args_c {
+  int64_t n, env_id0;
+  int32_t A, kind;
+  const float* head; int64_t ldh;
+  const float* log_std; int32_t has_min, has_max; float min_log_std, max_log_std;
+  const float* noise; int64_t ldn;
+  uint64_t seed; uint32_t step; int32_t double_softmax;
+  const float* obs; int64_t ldo; int32_t obs_dim;
+  int64_t col, Tcap;
+  float* action; int64_t lda;
+  float* obs_buf; float* act_buf; float* head_buf;
+};
+
+// 1 when ga_policy_step_fused_f32 supports this network shape.
+extern "C" int ga_policy_step_fused_supported(const ga_mlp_desc_c* d) {
+  if (!d || d->n_layers < 1 || d->n_layers > 8) return 0;
+  for (int l = 0; l < d->n_layers; ++l)
+    if (d->dims[l] > HMAX) return 0;  // every layer INPUT lives in an LDS tile
+  if (d->dims[d->n_layers] > MAX_OUT) return 0;
+  return 1;
+}
+
+// `head` of args is ignored (the means / scores stay on chip); everything else
+// as in ga_policy_head_sample.
+extern "C" int ga_policy_step_fused_f32(const ga_mlp_desc_c* d, const float* params,
+                                        const ga_head_args_c* a, hipStream_t stream) {
+  GA_REQUIRE(d && params && a, "ga_policy_step_fused_f32: null pointer");
+  GA_REQUIRE(ga_policy_step_fused_supported(d),
+             "ga_policy_step_fused_f32: unsupported network shape");
+  GA_REQUIRE(a->obs && a->action && a->obs_buf && a->act_buf,
+             "ga_policy_step_fused_f32: null buffer");
+  GA_REQUIRE(a->n > 0 && a->A == d->dims[d->n_layers] && a->obs_dim == d->dims[0],
+             "ga_policy_step_fused_f32: head / network size mismatch");
+  GA_REQUIRE(a->col >= 0 && a->col < a->Tcap,
+             "ga_policy_step_fused_f32: col out of range");
+  GA_REQUIRE(ga_aligned16(params), "ga_policy_step_fused_f32: params alignment");
+  FusedParams p;
+  p.n_layers = d->n_layers;
+  for (int i = 0; i < 9; ++i) p.dims[i] = d->dims[i];
+  for (int i = 0; i < 8; ++i) { p.w_off[i] = d->w_off[i]; p.b_off[i] = d->b_off[i]; }
+  p.params = params; p.n = a->n; p.env_id0 = a->env_id0; p.kind = a->kind;
+  p.has_min = a->has_min; p.has_max = a->has_max; p.min_log_std = a->min_log_std;
+  p.max_log_std = a->max_log_std; p.noise = a->noise; p.ldn = a->ldn;
+  p.k0 = (uint32_t)(a->seed & 0xffffffffu); p.k1 = (uint32_t)(a->seed >> 32);
+  p.step = a->step; p.double_softmax = a->double_softmax; p.obs = a->obs;
+  p.ldo = a->ldo; p.col = a->col; p.Tcap = a->Tcap; p.action = a->action;
+  p.lda = a->lda; p.obs_buf = a->obs_buf; p.act_buf = a->act_buf;
+  p.head_buf = a->head_buf; p.ldh = a->ldh;
+  hipLaunchKernelGGL(policy_step_fused_kernel,
+                     dim3((unsigned)ga_ceil_div(a->n, ROWS)), dim3(256), 0, stream, p);
+  GA_CHECK_LAUNCH("policy_step_fused");
+  return GA_OK;
+}

@@ -72,7 +72,9 @@ class GpuVecWorker:
     DEFAULT_N_ENVS = 8
 
     def __init__(self, *, seed, max_episode_length, worker_number,
-                 n_envs=DEFAULT_N_ENVS, noise_fn=None, store_agent_infos=True):
+                 n_envs=DEFAULT_N_ENVS, noise_fn=None, store_agent_infos=True,
+                 fused_policy_step=True):
+        self._use_fused = bool(fused_policy_step)
         self._seed = seed
         self._max_episode_length = max_episode_length
         self._worker_number = worker_number
@@ -193,12 +195,17 @@ class GpuVecWorker:
     def _step(self, b, col):
         """One vectorised step into column ``col`` of the rollout buffers."""
         env, pol, n = self.env, self.agent, self._n_envs
-        head = pol.net.forward(env.obs, n)
+        fused = self._use_fused and bool(
+            _lib.load().ga_policy_step_fused_supported(C.byref(pol.net._desc)))
         a = _lib.HeadArgs()
         a.n, a.env_id0 = n, getattr(env, 'env_id0', 0)
         a.kind = 0 if pol.kind == 'gaussian' else 1
         a.A = pol.net.out_dim
-        a.head, a.ldh = head.data_ptr(), head.stride(0)
+        if fused:
+            a.ldh = round4(pol.net.out_dim)
+        else:
+            head = pol.net.forward(env.obs, n)
+            a.head, a.ldh = head.data_ptr(), head.stride(0)
         if pol.kind == 'gaussian':
             a.log_std = pol.net.log_std.data_ptr()
             a.has_min, a.min_log_std, a.has_max, a.max_log_std = \
@@ -217,7 +224,11 @@ class GpuVecWorker:
         a.obs_buf, a.act_buf = b['obs'].data_ptr(), b['act'].data_ptr()
         a.head_buf = b['head'].data_ptr() if b['head'] is not None else None
         s = stream_ptr()
-        call('ga_policy_head_sample', C.byref(a), s)
+        if fused:
+            call('ga_policy_step_fused_f32', C.byref(pol.net._desc),
+                 dptr(pol.net.params), C.byref(a), s)
+        else:
+            call('ga_policy_head_sample', C.byref(a), s)
         env.step_all(b['action'])
         r = _lib.RecordArgs()
         r.n, r.col, r.Tcap = n, col, b['Tcap']

@@ -198,6 +198,15 @@ typedef struct {
   float* obs_buf; float* act_buf; float* head_buf;
 } ga_head_args;
 int ga_policy_head_sample(const ga_head_args* args, ga_stream_t stream);
+/* The same step with the MLP fused in: policy forward (all layers, activations
+ * resident in LDS, weights streamed through LDS, hidden layers on MFMA) + the
+ * action head + the rollout-buffer writes in ONE launch; `args->head` is
+ * ignored.  Supported when every layer input is <= 256 wide and the head <= 32
+ * (ga_policy_step_fused_supported); otherwise use ga_mlp_forward_f32 +
+ * ga_policy_head_sample. */
+int ga_policy_step_fused_supported(const ga_mlp_desc* d);
+int ga_policy_step_fused_f32(const ga_mlp_desc* d, const float* params,
+                             const ga_head_args* args, ga_stream_t stream);
 
 /* Reward / step-type / episode-end bookkeeping of VecWorker.step_episode and
  * _gather_episode (sampler/vec_worker.py:139-204). */
