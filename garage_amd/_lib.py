@@ -78,6 +78,9 @@ SIGNATURES = {
                                 c_f32, ptr, ptr, ptr]),
     'ga_mlp_forward_f32': (c_int, [C.POINTER(MlpDesc), ptr, ptr, c_i64, ptr,
                                    c_i64, ptr, ptr, c_i64, ptr]),
+    'ga_mlp_forward_fused_f32': (c_int, [C.POINTER(MlpDesc), ptr, ptr, c_i64,
+                                         ptr, c_i64, ptr, ptr, c_i64, ptr]),
+    'ga_set_fused_forward': (c_int, [c_int]),
     'ga_mlp_backward_splits': (c_i64, [C.POINTER(MlpDesc), c_i64]),
     'ga_mlp_backward_f32': (c_int, [C.POINTER(MlpDesc), ptr, ptr, c_i64, ptr,
                                     c_i64, ptr, ptr, c_i64, ptr, ptr, c_i64,
@@ -119,6 +122,11 @@ SIGNATURES = {
     'ga_policy_step_fused_f32': (c_int, [C.POINTER(MlpDesc), ptr,
                                          C.POINTER(HeadArgs), ptr]),
     'ga_record_step': (c_int, [C.POINTER(RecordArgs), ptr]),
+    'ga_rollout_synth_steps': (c_int, [C.POINTER(MlpDesc), ptr,
+                                       C.POINTER(HeadArgs),
+                                       C.POINTER(SynthEnv),
+                                       C.POINTER(RecordArgs), ptr, ptr, c_i64,
+                                       ptr]),
     'ga_pack_episodes': (c_int, [ptr, c_i64, c_i64, c_i64, ptr, ptr, ptr, ptr,
                                  ptr]),
     'ga_pack_src_index': (c_int, [ptr, ptr, ptr, ptr, c_i64, c_i64, ptr, ptr]),

@@ -385,6 +385,25 @@ struct ga_mlp_desc {
                        // workspace, row stride round4(dims[l + 1]) (hidden layers)
 };
 
+// The whole-network forward in one launch (policy_fused.hip) for nets whose
+// layers fit its LDS tiles; ga_set_fused_forward(0) forces the per-layer GEMMs.
+extern "C" int ga_policy_step_fused_supported(const ga_mlp_desc* d);
+extern "C" int ga_mlp_forward_fused_f32(const ga_mlp_desc* d, const float* params,
+                                        const float* X, int64_t ldx,
+                                        const int32_t* row_idx, int64_t M,
+                                        float* acts, float* out, int64_t ldo,
+                                        hipStream_t stream);
+// Off by default: at the C3 minibatch (32768 x 256 x 256) the fused forward
+// measures 86-107 us against 82-87 us for the three per-layer GEMMs -- it keeps
+// one workgroup per CU (140 KB of LDS) and its per-layer epilogues are exposed,
+// which costs what the saved activation round trip gains.  The rollout step
+// (policy_step_fused_kernel, n_envs rows) is where the fusion pays.
+static int g_fused_forward = 0;
+extern "C" int ga_set_fused_forward(int on) {
+  g_fused_forward = on != 0;
+  return 0;
+}
+
 static int check_desc(const ga_mlp_desc* d, const char* who) {
   GA_REQUIRE(d != nullptr, "%s: null descriptor", who);
   GA_REQUIRE(d->n_layers >= 1 && d->n_layers <= 8, "%s: n_layers %d not in 1..8",
@@ -412,6 +431,9 @@ extern "C" int ga_mlp_forward_f32(const ga_mlp_desc* d, const float* params,
   GA_REQUIRE(ga_aligned16(params) && ga_aligned16(X) && (!acts || ga_aligned16(acts)),
              "ga_mlp_forward_f32: pointers must be 16-B aligned");
   if (M == 0) return GA_OK;
+  if (g_fused_forward && ga_policy_step_fused_supported(d))
+    return ga_mlp_forward_fused_f32(d, params, X, ldx, row_idx, M, acts, out, ldo,
+                                    stream);
   const int L = d->n_layers;
   for (int l = 0; l < L; ++l) {
     GemmParams p;

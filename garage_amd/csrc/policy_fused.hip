@@ -309,6 +309,177 @@ __global__ __launch_bounds__(256) void policy_step_fused_kernel(FusedParams p) {
   }
 }
 
+// ---- the same network, training forward ---------------------------------------
+// All layers of one minibatch forward in one launch: 8 waves own 32 (gathered)
+// rows; hidden activations go to LDS for the next layer AND to HBM for the
+// backward pass; the narrow output layer is a 16-lane VALU dot.  Replaces the
+// three per-layer GEMM launches of ga_mlp_forward_f32 (the activations' HBM
+// read between layers disappears, the weights come from L2).
+struct TrainFwdParams {
+  int n_layers;
+  int dims[9];
+  int64_t w_off[8], b_off[8], act_off[8];
+  const float* params;
+  const float* X;
+  int64_t ldx;
+  const int32_t* idx;
+  int64_t M;
+  float* acts;
+  float* out;
+  int64_t ldo;
+};
+
+constexpr int TROWS = 64;  // rows per workgroup of the training forward
+
+__global__ __launch_bounds__(512) void mlp_train_fwd_fused_kernel(TrainFwdParams p) {
+  // 64 rows x 8 waves: wave (ri, cj) owns rows [32 ri, 32 ri + 32) and columns
+  // [64 cj, 64 cj + 64).  One activation tile, updated IN PLACE: a layer's
+  // outputs wait in the accumulators until every wave has finished reading the
+  // inputs, so LDS holds 64 rows (66.5 KB) + two weight stages (74 KB) and each
+  // weight chunk fetched from L2 is amortised over 64 rows (32 MFMAs per wave per
+  // chunk = ~1.7 us per SIMD, enough to cover the fetch of the next chunk).
+  constexpr int NT = 512;
+  __shared__ __attribute__((aligned(16))) float act[TROWS * LDACT];
+  __shared__ __attribute__((aligned(16))) float wst[2][HMAX * LDW];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int ri = wave >> 2, cj = wave & 3;
+  const int64_t row0 = (int64_t)blockIdx.x * TROWS;
+  const int L = p.n_layers;
+
+  const int in_w = p.dims[0];
+  const int in_pad = (in_w + KC - 1) / KC * KC;
+  for (int e = tid; e < TROWS * in_pad; e += NT) {
+    const int r = e / in_pad, c = e % in_pad;
+    const int64_t m = row0 + r;
+    float v = 0.f;
+    if (m < p.M && c < in_w) {
+      const int64_t src = p.idx ? (int64_t)p.idx[m] : m;
+      v = p.X[src * p.ldx + c];
+    }
+    act[r * LDACT + c] = v;
+  }
+  __syncthreads();
+
+  for (int l = 0; l < L - 1; ++l) {
+    const int K = p.dims[l], N = p.dims[l + 1];
+    const int ldw = (K + 3) & ~3;
+    const int ldh = (N + 3) & ~3;
+    const float* W = p.params + p.w_off[l];
+    const float* bias = p.params + p.b_off[l];
+    float* gact = p.acts + p.act_off[l];
+    const int nk = (K + KC - 1) / KC;
+    const int n0 = cj * 64;
+    const bool wave_on = n0 < N;
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    float4 wr[4];  // weight stage: 256 x 32 floats = 2048 vectors, 4 per thread
+    const int last = max(((K + 3) & ~3) - 4, 0);
+    auto wload = [&](int k0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int f = tid + NT * i;
+        const int nrow = min(f >> 3, N - 1);
+        wr[i] = *reinterpret_cast<const float4*>(W + (int64_t)nrow * ldw +
+                                                 min(k0 + 4 * (f & 7), last));
+      }
+    };
+    auto wstore = [&](float* stage, int k0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int f = tid + NT * i;
+        const int nrow = f >> 3, k = 4 * (f & 7);
+        float4 v = wr[i];
+        const bool ok = nrow < N;
+        v.x = (ok && k0 + k + 0 < K) ? v.x : 0.f;
+        v.y = (ok && k0 + k + 1 < K) ? v.y : 0.f;
+        v.z = (ok && k0 + k + 2 < K) ? v.z : 0.f;
+        v.w = (ok && k0 + k + 3 < K) ? v.w : 0.f;
+        *reinterpret_cast<float4*>(stage + nrow * LDW + k) = v;
+      }
+    };
+    wload(0);
+    wstore(wst[0], 0);
+    __syncthreads();
+    for (int s = 0; s < nk; ++s) {
+      const bool more = s + 1 < nk;
+      if (more) wload((s + 1) * KC);
+      if (wave_on) {
+        const float* A = act + (32 * ri + l31) * LDACT + s * KC;
+        const float* B = wst[s & 1] + (n0 + l31) * LDW;
+#pragma unroll
+        for (int g = 0; g < KC / 8; ++g) {
+          const float4 av = *reinterpret_cast<const float4*>(A + 8 * g + 4 * half);
+          const float4 b0 = *reinterpret_cast<const float4*>(B + 8 * g + 4 * half);
+          const float4 b1 =
+              *reinterpret_cast<const float4*>(B + 32 * LDW + 8 * g + 4 * half);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b0.x, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b1.x, acc[1], 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b0.y, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b1.y, acc[1], 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b0.z, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b1.z, acc[1], 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b0.w, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b1.w, acc[1], 0, 0, 0);
+        }
+      }
+      if (more) wstore(wst[(s + 1) & 1], (s + 1) * KC);
+      __syncthreads();
+    }
+    // every wave is past its last read of `act`: overwrite it with this layer
+    const int n_pad = (N + KC - 1) / KC * KC;
+    if (wave_on) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int ncol = n0 + 32 * j + l31;
+        const float bv = ncol < N ? bias[ncol] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = 32 * ri + (r & 3) + 8 * (r >> 2) + 4 * half;
+          const float v = ncol < N ? tanh_fast(acc[j][r] + bv) : 0.f;
+          if (ncol < n_pad) act[m * LDACT + ncol] = v;
+          if (ncol < N && row0 + m < p.M) gact[(row0 + m) * ldh + ncol] = v;
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // narrow output layer: its weights go to LDS once, then 8 lanes per row
+  {
+    const int K = p.dims[L - 1], N = p.dims[L];
+    const int ldw = (K + 3) & ~3;
+    const float* W = p.params + p.w_off[L - 1];
+    const float* bias = p.params + p.b_off[L - 1];
+    float* wo = wst[0];  // [N][ldw] fits: N <= 32, ldw <= 256
+    for (int e = tid; e < N * (ldw / 4); e += NT)
+      reinterpret_cast<float4*>(wo)[e] = reinterpret_cast<const float4*>(W)[e];
+    __syncthreads();
+    const int r = tid >> 3, part = tid & 7;
+    const float* a = act + r * LDACT;
+    for (int o = 0; o < N; ++o) {
+      const float* w = wo + o * ldw;
+      float sum = 0.f;
+      for (int k = part * 4; k < K; k += 32) {
+        const float4 wv = *reinterpret_cast<const float4*>(w + k);
+        const float4 xv = *reinterpret_cast<const float4*>(a + k);
+        sum += xv.x * wv.x;
+        if (k + 1 < K) sum += xv.y * wv.y;
+        if (k + 2 < K) sum += xv.z * wv.z;
+        if (k + 3 < K) sum += xv.w * wv.w;
+      }
+      sum += __shfl_xor(sum, 1, 64);
+      sum += __shfl_xor(sum, 2, 64);
+      sum += __shfl_xor(sum, 4, 64);
+      if (part == 0 && row0 + r < p.M) p.out[(row0 + r) * p.ldo + o] = sum + bias[o];
+    }
+  }
+}
+
 }  // namespace
 
 struct ga_mlp_desc_c {
@@ -370,5 +541,32 @@ extern "C" int ga_policy_step_fused_f32(const ga_mlp_desc_c* d, const float* par
   hipLaunchKernelGGL(policy_step_fused_kernel,
                      dim3((unsigned)ga_ceil_div(a->n, ROWS)), dim3(256), 0, stream, p);
   GA_CHECK_LAUNCH("policy_step_fused");
+  return GA_OK;
+}
+
+// Training / evaluation forward of the whole MLP in one launch (same contract
+// as ga_mlp_forward_f32, which dispatches here when the shape is supported).
+extern "C" int ga_mlp_forward_fused_f32(const ga_mlp_desc_c* d, const float* params,
+                                        const float* X, int64_t ldx,
+                                        const int32_t* row_idx, int64_t M,
+                                        float* acts, float* out, int64_t ldo,
+                                        hipStream_t stream) {
+  GA_REQUIRE(d && params && X && out, "ga_mlp_forward_fused_f32: null pointer");
+  GA_REQUIRE(ga_policy_step_fused_supported(d),
+             "ga_mlp_forward_fused_f32: unsupported network shape");
+  GA_REQUIRE(d->n_layers == 1 || acts, "ga_mlp_forward_fused_f32: acts needed");
+  GA_REQUIRE(M > 0 && M < (1ll << 31), "ga_mlp_forward_fused_f32: bad M");
+  GA_REQUIRE(ga_aligned16(params), "ga_mlp_forward_fused_f32: params alignment");
+  TrainFwdParams p;
+  p.n_layers = d->n_layers;
+  for (int i = 0; i < 9; ++i) p.dims[i] = d->dims[i];
+  for (int i = 0; i < 8; ++i) {
+    p.w_off[i] = d->w_off[i]; p.b_off[i] = d->b_off[i]; p.act_off[i] = d->act_off[i];
+  }
+  p.params = params; p.X = X; p.ldx = ldx; p.idx = row_idx; p.M = M; p.acts = acts;
+  p.out = out; p.ldo = ldo;
+  hipLaunchKernelGGL(mlp_train_fwd_fused_kernel, dim3((unsigned)ga_ceil_div(M, TROWS)),
+                     dim3(512), 0, stream, p);
+  GA_CHECK_LAUNCH("mlp_train_fwd_fused");
   return GA_OK;
 }

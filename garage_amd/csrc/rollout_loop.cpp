@@ -1,0 +1,56 @@
+// `n_steps` vectorised rollout steps of the synthetic environment enqueued from
+// C++: fused policy step -> env step -> bookkeeping -> reset of finished envs,
+// ping-ponging the two observation buffers.  Same kernels and order as
+// GpuVecWorker._step drives from Python (VecWorker.step_episode,
+// sampler/vec_worker.py:176-204); it exists because at 4 launches per step the
+// Python/ctypes overhead (~50 us) is twice the device time of a step.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/garage_amd.h"
+
+void ga_set_error(const char* fmt, ...);
+
+extern "C" int ga_rollout_synth_steps(const ga_mlp_desc* desc, const float* params,
+                                      const ga_head_args* head,
+                                      const ga_synth_env* env,
+                                      const ga_record_args* rec, float* obs_a,
+                                      float* obs_b, int64_t n_steps,
+                                      ga_stream_t stream) {
+  if (!desc || !params || !head || !env || !rec || !obs_a || !obs_b) {
+    ga_set_error("ga_rollout_synth_steps: null pointer");
+    return -1;
+  }
+  if (n_steps < 0 || head->col + n_steps > head->Tcap) {
+    ga_set_error("ga_rollout_synth_steps: steps exceed the rollout buffer");
+    return -1;
+  }
+  if (!ga_policy_step_fused_supported(desc)) {
+    ga_set_error("ga_rollout_synth_steps: network not supported by the fused step");
+    return -1;
+  }
+  float* cur = obs_a;
+  float* nxt = obs_b;
+  ga_head_args h = *head;
+  ga_record_args r = *rec;
+  for (int64_t s = 0; s < n_steps; ++s) {
+    h.col = head->col + s;
+    h.step = head->step + (uint32_t)s;
+    h.obs = cur;
+    int rc = ga_policy_step_fused_f32(desc, params, &h, stream);
+    if (rc) return rc;
+    rc = ga_synth_env_step(env, h.action, h.lda, cur, nxt, h.ldo, (float*)r.reward,
+                           (uint8_t*)r.step_type, stream);
+    if (rc) return rc;
+    r.col = h.col;
+    r.next_obs = nxt;
+    rc = ga_record_step(&r, stream);
+    if (rc) return rc;
+    rc = ga_synth_env_reset(env, r.done, nxt, h.ldo, stream);
+    if (rc) return rc;
+    float* t = cur;
+    cur = nxt;
+    nxt = t;
+  }
+  return 0;
+}

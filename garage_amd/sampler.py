@@ -195,8 +195,28 @@ class GpuVecWorker:
     def _step(self, b, col):
         """One vectorised step into column ``col`` of the rollout buffers."""
         env, pol, n = self.env, self.agent, self._n_envs
-        fused = self._use_fused and bool(
-            _lib.load().ga_policy_step_fused_supported(C.byref(pol.net._desc)))
+        fused = self._fused_ok()
+        a = self._head_args(b, col, fused)
+        s = stream_ptr()
+        if fused:
+            call('ga_policy_step_fused_f32', C.byref(pol.net._desc),
+                 dptr(pol.net.params), C.byref(a), s)
+        else:
+            call('ga_policy_head_sample', C.byref(a), s)
+        env.step_all(b['action'])
+        r = self._record_args(b, col)
+        call('ga_record_step', C.byref(r), s)
+        env.reset_where(b['done'])
+        env.advance()
+        self._global_step += 1
+
+    def _fused_ok(self):
+        return self._use_fused and bool(
+            _lib.load().ga_policy_step_fused_supported(
+                C.byref(self.agent.net._desc)))
+
+    def _head_args(self, b, col, fused):
+        env, pol, n = self.env, self.agent, self._n_envs
         a = _lib.HeadArgs()
         a.n, a.env_id0 = n, getattr(env, 'env_id0', 0)
         a.kind = 0 if pol.kind == 'gaussian' else 1
@@ -214,6 +234,7 @@ class GpuVecWorker:
             a.double_softmax = int(pol.double_softmax)
         noise = self._noise_fn(self._global_step) if self._noise_fn else None
         if noise is not None:
+            self._noise_keepalive = noise
             a.noise, a.ldn = noise.data_ptr(), noise.stride(0)
         a.seed = (self._seed or 0) + 7919 * (self._worker_number + 1)
         a.step = self._global_step & 0xFFFFFFFF
@@ -223,13 +244,10 @@ class GpuVecWorker:
         a.action, a.lda = b['action'].data_ptr(), b['action'].stride(0)
         a.obs_buf, a.act_buf = b['obs'].data_ptr(), b['act'].data_ptr()
         a.head_buf = b['head'].data_ptr() if b['head'] is not None else None
-        s = stream_ptr()
-        if fused:
-            call('ga_policy_step_fused_f32', C.byref(pol.net._desc),
-                 dptr(pol.net.params), C.byref(a), s)
-        else:
-            call('ga_policy_head_sample', C.byref(a), s)
-        env.step_all(b['action'])
+        return a
+
+    def _record_args(self, b, col):
+        env, n = self.env, self._n_envs
         r = _lib.RecordArgs()
         r.n, r.col, r.Tcap = n, col, b['Tcap']
         r.max_episode_length = int(self._max_episode_length)
@@ -244,11 +262,26 @@ class GpuVecWorker:
         r.step_eps = b['step_eps'].data_ptr()
         r.step_samples = b['step_samples'].data_ptr()
         r.terminal_only = getattr(self, '_terminal_only', 0)
-        call('ga_record_step', C.byref(r), s)
-        env.reset_where(b['done'])
-        env.advance()
-        self._global_step += 1
-        self.agent.reset(None)
+        return r
+
+    def _native_steps(self, b, col, n_steps):
+        """``n_steps`` steps enqueued by ``ga_rollout_synth_steps`` (synthetic
+        env, fused policy step, device RNG); False when not applicable."""
+        from garage_amd.envs import SyntheticVecEnv
+        env = self.env
+        if (n_steps <= 0 or type(env) is not SyntheticVecEnv
+                or self._noise_fn is not None or not self._fused_ok()):
+            return False
+        a = self._head_args(b, col, True)
+        r = self._record_args(b, col)
+        call('ga_rollout_synth_steps', C.byref(self.agent.net._desc),
+             dptr(self.agent.net.params), C.byref(a), C.byref(env._c),
+             C.byref(r), dptr(env.obs), dptr(env.next_obs), n_steps,
+             stream_ptr())
+        if n_steps % 2:
+            env.advance()
+        self._global_step += n_steps
+        return True
 
     def rollout_samples(self, num_samples):
         """Everything ``LocalSampler.obtain_samples`` collects from one worker.
@@ -262,6 +295,11 @@ class GpuVecWorker:
         n = self._n_envs
         b = self._alloc_buffers(num_samples)
         col = 0
+        # the target cannot be reached before step ceil(num_samples / n): those
+        # steps need no host check and are enqueued natively when possible
+        first_check = -(-int(num_samples) // n)
+        if self._native_steps(b, 0, first_check - 1):
+            col = first_check - 1
         while True:
             self._step(b, col)
             col += 1
@@ -286,12 +324,13 @@ class GpuVecWorker:
         ep_end = torch.empty_like(ep_env)
         ep_len = torch.empty_like(ep_env)
         base_dev = torch.from_numpy(ep_base.astype(np.int32)).to(dev)
-        tail = b['tail']
+        # columns before first_step are skipped by offsetting the column base
+        tail = b['tail'][:, first_step:]
+        call('ga_pack_episodes', dptr(tail), n, tcap, n_steps - first_step,
+             dptr(base_dev[first_step:]), dptr(ep_env), dptr(ep_end),
+             dptr(ep_len), s)
         if first_step:
-            tail = tail.clone()
-            tail[:, :first_step] = 0
-        call('ga_pack_episodes', dptr(tail), n, tcap, n_steps, dptr(base_dev),
-             dptr(ep_env), dptr(ep_end), dptr(ep_len), s)
+            ep_end += first_step
         lengths = ep_len.cpu().numpy().astype(np.int64)
         off = np.concatenate([[0], np.cumsum(lengths)])
         S = int(off[-1])

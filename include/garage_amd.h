@@ -71,6 +71,15 @@ typedef struct {
 int ga_mlp_forward_f32(const ga_mlp_desc* d, const float* params, const float* X,
                        int64_t ldx, const int32_t* row_idx, int64_t M, float* acts,
                        float* out, int64_t ldo, ga_stream_t stream);
+/* The same forward with every layer in ONE launch (activations of 32 rows stay in
+ * LDS between layers, weights stream from L2); ga_mlp_forward_f32 dispatches to
+ * it when ga_policy_step_fused_supported(d).  ga_set_fused_forward(0) forces
+ * the per-layer GEMM path (A/B measurements). */
+int ga_mlp_forward_fused_f32(const ga_mlp_desc* d, const float* params,
+                             const float* X, int64_t ldx, const int32_t* row_idx,
+                             int64_t M, float* acts, float* out, int64_t ldo,
+                             ga_stream_t stream);
+int ga_set_fused_forward(int on);
 /* split count ga_mlp_backward_f32 should be called with for M rows */
 int64_t ga_mlp_backward_splits(const ga_mlp_desc* d, int64_t M);
 /* dout = dLoss/d(out).  Writes n_splits partial gradient slabs, each laid out
@@ -221,6 +230,17 @@ typedef struct {
                             (sampler/fragment_worker.py:114-115) */
 } ga_record_args;
 int ga_record_step(const ga_record_args* args, ga_stream_t stream);
+
+/* n_steps consecutive vectorised steps (fused policy step, synthetic env step,
+ * bookkeeping, reset of finished envs) starting at head->col / head->step,
+ * alternating the observation buffers obs_a (current) / obs_b; after an odd
+ * number of steps the current observations are in obs_b.  The while-loop body of
+ * VecWorker.rollout (sampler/default_worker.py:176-186 + vec_worker.py:176-204)
+ * enqueued natively. */
+int ga_rollout_synth_steps(const ga_mlp_desc* desc, const float* params,
+                           const ga_head_args* head, const ga_synth_env* env,
+                           const ga_record_args* rec, float* obs_a, float* obs_b,
+                           int64_t n_steps, ga_stream_t stream);
 
 /* EpisodeBatch.concatenate in completion order (sampler/vec_worker.py:206-219,
  * local_sampler.py:134-166; order = (completion step, env index)). */

@@ -62,3 +62,77 @@ def test_fused_step_matches_per_layer_path(discrete, O, A, hidden, n):
     else:
         assert np.allclose(a.actions, b.actions, atol=2e-6)
         assert np.allclose(a.rewards, b.rewards, atol=2e-6)
+
+
+@pytest.mark.parametrize('ragged', [False, True])
+def test_native_rollout_loop_equals_python_driven_steps(ragged):
+    """ga_rollout_synth_steps enqueues the same launches as GpuVecWorker._step:
+    with the device RNG both give bit-identical batches, twice in a row (the
+    second call exercises the partial reset and the odd/even buffer parity)."""
+    from garage_amd.envs import SyntheticVecEnv
+    from garage_amd.policies import GaussianMLPPolicy
+    from garage_amd.sampler import GpuVecSampler, GpuVecWorker
+
+    class PythonSteps(GpuVecWorker):
+
+        def _native_steps(self, b, col, n_steps):
+            return False
+
+    n, O, A, P = 70, 6, 3, 11
+    out = []
+    for cls in (GpuVecWorker, PythonSteps):
+        torch.manual_seed(4)
+        env = SyntheticVecEnv(n, O, A, P, min_len=3 if ragged else None, seed=8)
+        pol = GaussianMLPPolicy(env.spec, hidden_sizes=(32, 32))
+        sampler = GpuVecSampler(pol, env, max_episode_length=P, n_workers=1,
+                                seed=3, worker_class=cls,
+                                worker_args=dict(n_envs=n))
+        out.append([sampler.obtain_samples(0, num, None)
+                    for num in (n * P, n * P + 17)])
+    for a, b in zip(*out):
+        assert np.array_equal(a.lengths, b.lengths)
+        assert np.array_equal(a.observations, b.observations)
+        assert np.array_equal(a.actions, b.actions)
+        assert np.array_equal(a.rewards, b.rewards)
+        assert np.array_equal(a.last_observations, b.last_observations)
+        assert np.array_equal([int(s) for s in a.step_types],
+                              [int(s) for s in b.step_types])
+
+
+@pytest.mark.parametrize('O,A,hidden,M', [(17, 6, (256, 256), 1000),
+                                          (17, 1, (256, 256), 4100),
+                                          (5, 3, (16, 40), 333),
+                                          (33, 2, (100, ), 65)])
+def test_fused_training_forward_matches_per_layer_gemms(O, A, hidden, M):
+    """ga_mlp_forward_fused_f32 (off by default) == ga_mlp_forward_f32:
+    outputs AND the stored hidden activations the backward pass consumes."""
+    import ctypes as C
+
+    from garage_amd._lib import call, dptr, load, stream_ptr
+    from garage_amd.engine import FlatMLP, pad_rows, require_gpu
+    dev = require_gpu()
+    rng = np.random.RandomState(0)
+    net = FlatMLP(O, A, hidden, dev)
+    for l in range(len(hidden) + 1):
+        net.weight(l).copy_(torch.from_numpy(
+            (rng.randn(net.dims[l + 1], net.dims[l]) * 0.2).astype(np.float32)))
+        net.bias(l).copy_(torch.from_numpy(
+            (rng.randn(net.dims[l + 1]) * 0.2).astype(np.float32)))
+    X = pad_rows(rng.randn(2 * M, O).astype(np.float32))
+    idx = torch.from_numpy(rng.permutation(2 * M)[:M].astype(np.int32)).to(dev)
+    load().ga_set_fused_forward(0)
+    want = net.forward(X, M, row_idx=idx).clone()
+    want_acts = net._acts.clone()
+    net._acts.zero_()
+    out = torch.zeros_like(want)
+    call('ga_mlp_forward_fused_f32', C.byref(net._desc), dptr(net.params),
+         dptr(X), X.stride(0), dptr(idx), M, dptr(net._acts), dptr(out),
+         out.stride(0), stream_ptr())
+    assert np.allclose(out[:, :A].cpu().numpy(), want[:, :A].cpu().numpy(),
+                       atol=2e-6)
+    for l, h in enumerate(hidden):
+        w = (h + 3) // 4 * 4
+        off = net.act_off[l] * net._cap
+        a = net._acts[off:off + M * w].view(M, w)[:, :h]
+        b = want_acts[off:off + M * w].view(M, w)[:, :h]
+        assert torch.equal(a, b), l  # same k <-> MFMA slot map: bit identical
