@@ -150,7 +150,7 @@ class VPG:
 
     def _policy_loss_pass(self, batch, adv, old_ll, M, idx, params=None,
                           want_grad=False, ll_out=None, obs=None,
-                          ent_out=None, ent_sum=None):
+                          ent_out=None, ent_sum=None, head=None):
         """Forward + fused loss (+ gradient seed) over ``M`` rows.
 
         Returns ``(loss, head, dout)``; ``head`` is the policy MLP output (means
@@ -163,7 +163,8 @@ class VPG:
             saved, net.params = net.params, params
         obs = batch.obs_dev if obs is None else obs
         try:
-            head = net.forward(obs, M, row_idx=idx)
+            if head is None:
+                head = net.forward(obs, M, row_idx=idx)
             dout = net.dout_view(M) if want_grad else None
             loss = torch.empty(1, dtype=torch.float32, device=net.device)
             algo = self._algo_id if old_ll is not None else 1
@@ -194,10 +195,12 @@ class VPG:
                 net.params = saved
         return loss, head, dout
 
-    def _value_loss_pass(self, batch, returns, M, idx, want_grad=False):
+    def _value_loss_pass(self, batch, returns, M, idx, want_grad=False,
+                         v=None):
         vf = self._value_function
         net = vf.net
-        v = net.forward(batch.obs_dev, M, row_idx=idx)
+        if v is None:
+            v = net.forward(batch.obs_dev, M, row_idx=idx)
         dout = net.dout_view(M) if want_grad else None
         loss = torch.empty(1, dtype=torch.float32, device=net.device)
         call('ga_gaussian_nll_loss_f32', dptr(v), v.stride(0), dptr(returns),
@@ -308,11 +311,18 @@ class VPG:
         pol.net.params = self._old_policy.params
         mean_old_pad = pol.net.forward(zero_obs, 1).clone()
         pol.net.params = saved
+        # The old policy equals the current one unless somebody changed the
+        # parameters between iterations (vpg.py:201 syncs them): then the
+        # "new" forward of LossBefore / KLBefore would recompute mean_old bit
+        # for bit, so it is reused.  Likewise the baselines ARE the value
+        # function's outputs for LossBefore.
+        same = bool(torch.equal(self._old_policy.params, pol.net.params))
         loss_before, mean_new, _ = self._policy_loss_pass(
-            batch, adv, old_ll, S, None)
+            batch, adv, old_ll, S, None, head=mean_old if same else None)
         kl_before = self._mean_kl(mean_old, mean_old_pad, s_old, mean_new,
                                   zero_obs, S, n_pad, n_cells)
-        vf_before, _, _ = self._value_loss_pass(batch, returns, S, None)
+        vf_before, _, _ = self._value_loss_pass(batch, returns, S, None,
+                                                v=values)
 
         self._train(batch, adv, returns, old_ll)
 
