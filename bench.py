@@ -199,7 +199,7 @@ def main():
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--config', default='c3', choices=sorted(CONFIGS))
-    ap.add_argument('--cpu-envs', type=int, default=256,
+    ap.add_argument('--cpu-envs', type=int, default=1024,
                     help='envs of the bounded CPU-baseline sample (0: skip)')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-overlap', action='store_true',
