@@ -130,12 +130,15 @@ struct PpoFinalizeParams {
 };
 
 __global__ void ppo_gaussian_finalize_kernel(PpoFinalizeParams p) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  // one wave: lanes stride over the block partials, then a fixed-order wave sum
   double obj = 0.0, ds = 0.0;
-  for (int b = 0; b < p.nblocks; ++b) {
+  for (int b = threadIdx.x; b < p.nblocks; b += 64) {
     obj += p.partials[2 * b + 0];
     ds += p.partials[2 * b + 1];
   }
+  obj = ga_wave_sum(obj);
+  ds = ga_wave_sum(ds);
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
   float s = *p.log_std;
   bool s_grad = true;
   if (p.has_min && s < p.min_log_std) { s = p.min_log_std; s_grad = false; }
@@ -295,12 +298,14 @@ __global__ void ppo_categorical_finalize_kernel(const double* partials, int nblo
                                                 int64_t M, float* loss_out,
                                                 double* ent_sum_out, float* grad_slab0,
                                                 int64_t slab_stride, int64_t n_splits) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
   double o = 0.0, e = 0.0;
-  for (int b = 0; b < nblocks; ++b) {
+  for (int b = threadIdx.x; b < nblocks; b += 64) {
     o += partials[2 * b];
     e += partials[2 * b + 1];
   }
+  o = ga_wave_sum(o);
+  e = ga_wave_sum(e);
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
   *loss_out = (float)(-(o / (double)M));
   if (ent_sum_out) *ent_sum_out = e;
   if (grad_slab0)  // the (unused) log-std slot of the flat layout stays 0
@@ -370,12 +375,14 @@ __global__ void gaussian_nll_finalize_kernel(const double* partials, int nblocks
                                              int64_t M, float* loss_out,
                                              float* grad_slab0, int64_t slab_stride,
                                              int64_t n_splits) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
   double a = 0.0, b = 0.0;
-  for (int k = 0; k < nblocks; ++k) {
+  for (int k = threadIdx.x; k < nblocks; k += 64) {
     a += partials[2 * k];
     b += partials[2 * k + 1];
   }
+  a = ga_wave_sum(a);
+  b = ga_wave_sum(b);
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
   *loss_out = (float)(a / (double)M);
   if (grad_slab0) {
     grad_slab0[0] = (float)(b / (double)M);
@@ -407,10 +414,10 @@ __global__ __launch_bounds__(256) void gaussian_kl_kernel(
 }
 
 __global__ void sum_partials_kernel(const double* partials, int nblocks, double* out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
   double a = 0.0;
-  for (int k = 0; k < nblocks; ++k) a += partials[k];
-  *out = a;
+  for (int k = threadIdx.x; k < nblocks; k += 64) a += partials[k];
+  a = ga_wave_sum(a);
+  if (threadIdx.x == 0 && blockIdx.x == 0) *out = a;
 }
 
 // ---- optimiser --------------------------------------------------------------
@@ -519,14 +526,17 @@ __global__ __launch_bounds__(256) void stats_partial_kernel(const float* x, int6
 template <int WHAT>
 __global__ void stats_finalize_kernel(const double* partials, int nblocks, int64_t n,
                                       double* stats) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
   if (WHAT == 2) {
     double a = 1.0e300;
-    for (int k = 0; k < nblocks; ++k) a = fmin(a, partials[k]);
-    stats[3] = a;
+    for (int k = threadIdx.x; k < nblocks; k += 64) a = fmin(a, partials[k]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a = fmin(a, __shfl_down(a, o, 64));
+    if (threadIdx.x == 0 && blockIdx.x == 0) stats[3] = a;
   } else {
     double a = 0.0;
-    for (int k = 0; k < nblocks; ++k) a += partials[k];
+    for (int k = threadIdx.x; k < nblocks; k += 64) a += partials[k];
+    a = ga_wave_sum(a);
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (WHAT == 0) {
       stats[0] = a;
       stats[1] = (double)n;
@@ -557,7 +567,7 @@ __global__ __launch_bounds__(256) void sub_scalar_kernel(float* x, int64_t n,
 }
 
 inline int red_blocks(int64_t n) {
-  int64_t b = ga_ceil_div(n, 256 * 4);
+  int64_t b = ga_ceil_div(n, 256);  // one row per thread up to RED_BLOCKS blocks
   if (b < 1) b = 1;
   if (b > RED_BLOCKS) b = RED_BLOCKS;
   return (int)b;
