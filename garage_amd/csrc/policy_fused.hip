@@ -215,24 +215,41 @@ __global__ __launch_bounds__(256) void policy_step_fused_kernel(FusedParams p) {
     cur ^= 1;
   }
 
-  // ---- narrow output layer: 8 lanes per row split k, VALU dot products
+  // ---- narrow output layer: its weights go to LDS once; 8 lanes per row hold
+  //      their k slice of the row in registers and dot it with every output
   {
     const int K = p.dims[L - 1], N = p.dims[L];
     const int ldw = (K + 3) & ~3;
     const float* W = p.params + p.w_off[L - 1];
     const float* bias = p.params + p.b_off[L - 1];
+    float* wo = wst[0];  // [N][ldw]: N <= 32, ldw <= 256 -> fits one stage
+    for (int e = tid; e < N * (ldw / 4); e += 256)
+      reinterpret_cast<float4*>(wo)[e] = reinterpret_cast<const float4*>(W)[e];
     const int r = tid >> 3, part = tid & 7;
     const float* a = act[cur] + r * LDACT;
+    float4 xr[HMAX / 32];
+#pragma unroll
+    for (int i = 0; i < HMAX / 32; ++i) {
+      const int k = part * 4 + 32 * i;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k < K) {
+        v = *reinterpret_cast<const float4*>(a + k);
+        if (k + 1 >= K) v.y = 0.f;
+        if (k + 2 >= K) v.z = 0.f;
+        if (k + 3 >= K) v.w = 0.f;
+      }
+      xr[i] = v;
+    }
+    __syncthreads();
     for (int o = 0; o < N; ++o) {
-      const float* w = W + (int64_t)o * ldw;
+      const float* w = wo + o * ldw + part * 4;
       float sum = 0.f;
-      for (int k = part * 4; k < K; k += 32) {
-        const float4 wv = *reinterpret_cast<const float4*>(w + k);
-        const float4 xv = *reinterpret_cast<const float4*>(a + k);
-        sum += xv.x * wv.x;
-        if (k + 1 < K) sum += xv.y * wv.y;
-        if (k + 2 < K) sum += xv.z * wv.z;
-        if (k + 3 < K) sum += xv.w * wv.w;
+#pragma unroll
+      for (int i = 0; i < HMAX / 32; ++i) {
+        if (part * 4 + 32 * i < ldw) {
+          const float4 wv = *reinterpret_cast<const float4*>(w + 32 * i);
+          sum += xr[i].x * wv.x + xr[i].y * wv.y + xr[i].z * wv.z + xr[i].w * wv.w;
+        }
       }
       sum += __shfl_xor(sum, 1, 64);
       sum += __shfl_xor(sum, 2, 64);

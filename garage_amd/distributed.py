@@ -120,6 +120,18 @@ def shard_algo(algo, comm):
         # RCCL inside the C++ epoch loop; one communicator per network because
         # the two passes run on two streams and a communicator's collectives
         # must be issued in one order on every rank
-        opt.native_comm = NativeComm(comm) if use_rccl else None
+        opt.native_comm = None
+        if use_rccl:
+            try:
+                opt.native_comm = NativeComm(comm)
+            except Exception as exc:  # pragma: no cover - needs >1 GPU
+                # fall back to the Python-driven minibatch loop, which
+                # all-reduces through torch.distributed (same results, more
+                # host overhead); every rank takes the same branch because
+                # ncclCommInitRank fails or succeeds collectively
+                import warnings
+                warnings.warn('native RCCL communicator unavailable ({}); '
+                              'using torch.distributed for the gradient '
+                              'all-reduce'.format(exc))
     algo._old_policy.sync(algo.policy)
     return algo
