@@ -66,7 +66,8 @@ class UpdateArgs(C.Structure):
                 ('has_max', c_i32), ('max_log_std', c_f32), ('algo', c_i32),
                 ('clip', c_f32), ('ent_coeff', c_f32), ('ent_flags', c_i32),
                 ('losses', ptr), ('loss_scratch', ptr), ('workspace', ptr),
-                ('comm', ptr), ('world', c_i32), ('double_softmax', c_i32)]
+                ('comm', ptr), ('world', c_i32), ('double_softmax', c_i32),
+                ('grad_scale', c_f32)]
 
 
 # name -> (restype, argtypes); mirrors include/garage_amd.h one to one.

@@ -261,6 +261,7 @@ class VPG:
         pol.net._workspace(S)
         vf.net._workspace(S)
         zero_obs = torch.zeros(1, batch.obs_dev.shape[1], device=dev)
+        share = self._dp_setup(S)
 
         # baselines on every valid step and on the all-zero observation the
         # reference feeds through the padding (vpg.py:147,155-156; Q2)
@@ -342,8 +343,11 @@ class VPG:
                                vf_after[0]]).to(torch.float64)
         scalars = torch.cat([scalars, kl_before, kl_after])
         if self._comm is not None:
+            # losses are per-sample means: weight by this rank's sample share;
+            # the KLs are already global (see _mean_kl)
+            scalars[:4] *= share
+            scalars[4:] /= self._comm.world_size
             self._allreduce(scalars, 'sum')
-            scalars = scalars / self._comm.world_size
         pl_b, pl_a, vl_b, vl_a, kl_b, kl_a = scalars.cpu().tolist()
         tab = logger.tabular
         with tab.prefix(self.policy.name):
@@ -396,10 +400,27 @@ class VPG:
                                  device=total.device)
             self._allreduce(total, 'sum')
             self._allreduce(cells, 'sum')
-            # every rank divides by the global cell count; the later scalar
-            # average over ranks is undone by multiplying with world_size
-            return total / cells * self._comm.world_size
+            return total / cells  # identical on every rank
         return total / n_cells
+
+    def _dp_setup(self, S):
+        """Data parallel bookkeeping of one iteration: every rank learns all
+        sample counts (one tiny collective), from which follow this rank's
+        share of the global batch and a common number of minibatches per pass.
+        Returns the share (1.0 in a single process)."""
+        if self._comm is None:
+            return 1.0
+        counts = self._comm.all_gather_int(S, device=self.policy.device)
+        share = S / float(sum(counts))
+        for opt in (self._policy_optimizer, self._vf_optimizer):
+            opt.dp_grad_scale = share
+            mb = opt._minibatch_size
+            opt.dp_minibatches = (None if mb is None else
+                                  -(-max(counts) // int(mb)))
+            if mb is not None and min(counts) < opt.dp_minibatches:
+                raise RuntimeError('a rank holds fewer samples than there are '
+                                   'minibatches per pass')
+        return share
 
     def _normalise_advantages(self, adv):
         """``vpg.py:371-377`` (global moments when the batch is sharded)."""
@@ -457,7 +478,7 @@ class VPG:
         import ctypes as C
         net = module.net
         S = batch.n_samples
-        mb = opt._minibatch_size
+        mb = opt.local_minibatch_size(S)
         net._workspace(S if mb is None else min(S, mb))
         dev = net.device
         a = _lib.UpdateArgs()
@@ -500,6 +521,7 @@ class VPG:
         comm = getattr(opt, 'native_comm', None)
         if comm is not None:
             a.comm, a.world = comm.handle, comm.world_size
+            a.grad_scale = float(opt.dp_grad_scale)
         n_mb = 1 if mb is None else -(-S // mb)
         return a, scratch, n_mb
 

@@ -81,7 +81,9 @@ int run_minibatch(const ga_update_args* a, int64_t k, ga_stream_t stream) {
                            a->dout, a->ldo, a->dacts, a->slabs, a->n_flat, splits,
                            stream);
   if (rc) return rc;
-  const float scale = (a->comm && a->world > 1) ? 1.0f / (float)a->world : 1.0f;
+  // data parallel: the global gradient is the sample-count weighted sum of the
+  // rank gradients (mean over the union of the shards)
+  const float scale = (a->comm && a->world > 1) ? a->grad_scale : 1.0f;
   rc = ga_reduce_slabs_f32(a->slabs, splits, a->n_flat, a->n_flat, scale, a->grads,
                            stream);
   if (rc) return rc;

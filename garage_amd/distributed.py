@@ -39,6 +39,15 @@ class Comm:
         tensor.mul_(1.0 / self.world_size)
         return tensor
 
+    def all_gather_int(self, value, device=None):
+        """One integer per rank, as a Python list (sample counts etc.)."""
+        t = torch.zeros(self.world_size, dtype=torch.int64,
+                        device=device or ('cuda' if dist.get_backend(
+                            self.group) == 'nccl' else 'cpu'))
+        t[self.rank] = int(value)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return [int(v) for v in t.cpu().tolist()]
+
     def broadcast(self, tensor, src=0):
         dist.broadcast(tensor, src=src, group=self.group)
         return tensor
@@ -116,7 +125,9 @@ def shard_algo(algo, comm):
         comm.broadcast(module.net.params)
         comm.broadcast(module.net.exp_avg)
         comm.broadcast(module.net.exp_avg_sq)
-        opt.grad_hook = comm.all_reduce_mean
+        # the local gradient is pre-scaled by S_local / S_global
+        # (OptimizerWrapper.dp_grad_scale), so the exchange is a plain sum
+        opt.grad_hook = comm.all_reduce
         # RCCL inside the C++ epoch loop; one communicator per network because
         # the two passes run on two streams and a communicator's collectives
         # must be issued in one order on every rank

@@ -59,6 +59,11 @@ class OptimizerWrapper:
         self._draws = 0
         self.grad_hook = None  # multi-GPU: called on the flat grads
         self.native_comm = None  # RCCL handle for the C++ epoch loop
+        # data parallel, set per iteration by the algorithm: minibatches per
+        # pass (identical on every rank, or the collectives would not line up)
+        # and this rank's share of the global sample count
+        self.dp_minibatches = None
+        self.dp_grad_scale = 1.0
 
     def __getstate__(self):
         state = self.__dict__.copy()
@@ -104,13 +109,23 @@ class OptimizerWrapper:
         Same number, sizes and -- in ``'numpy'`` mode -- contents as the
         minibatches ``get_minibatch`` of the reference yields for ``n`` rows.
         """
-        mb = self._minibatch_size
+        mb = self.local_minibatch_size(n)
         for perm in self.epoch_permutations(n):
             if perm is None:
                 yield None
                 continue
             for k in range(-(-n // mb)):
                 yield perm[k * mb:(k + 1) * mb]
+
+    def local_minibatch_size(self, n):
+        """Rows per minibatch on this rank.  Single process: ``minibatch_size``.
+        Data parallel: every rank must run the same number of minibatches, so
+        the local size is ``ceil(n / dp_minibatches)``."""
+        if self._minibatch_size is None:
+            return None
+        if self.dp_minibatches:
+            return -(-n // int(self.dp_minibatches))
+        return int(self._minibatch_size)
 
     def get_minibatch(self, *inputs):
         """Reference-shaped generator: lists of gathered tensors."""
@@ -127,7 +142,8 @@ class OptimizerWrapper:
     def step(self, **closure):
         """Reduce the gradient slabs, (all-reduce,) Adam."""
         del closure
-        self.net.reduce_grads()
+        self.net.reduce_grads(scale=self.dp_grad_scale
+                              if self.grad_hook is not None else 1.0)
         if not getattr(self._module, '_learn_std', True):
             self.net.grads[0:1].zero_()
         if self.grad_hook is not None:

@@ -294,6 +294,8 @@ typedef struct {
   double* workspace;
   void* comm; int32_t world; /* RCCL communicator from ga_comm_init_rank, or NULL */
   int32_t double_softmax;    /* kind 2 */
+  float grad_scale;          /* with comm: this rank's share S_local / S_global of the
+                                minibatch, applied before the all-reduce(sum) */
 } ga_update_args;
 int ga_update_epoch(const ga_update_args* args, ga_stream_t stream);
 /* The policy pass and the value-function pass of one epoch, minibatch by

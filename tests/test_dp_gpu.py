@@ -1,0 +1,140 @@
+"""Data-parallel PPO on real kernels: 2 ranks (gloo, sharing the one GPU of the
+test box) == the single-process oracle on the concatenated batch.
+
+Full-batch optimizer steps (``minibatch_size=None``) make the comparison exact:
+the global gradient is the mean over the union of the shards, i.e. the average
+of the rank means for equal shard sizes, and ``center_adv`` must use the global
+moments.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+N_EPS, P, O, A = 12, 10, 5, 3  # per rank
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _make_shard(rank):
+    rng = np.random.RandomState(100 + rank)
+    lens = rng.randint(3, P + 1, size=N_EPS)
+    lens[0] = P
+    S = int(lens.sum())
+    st = []
+    for L in lens:
+        t = [1] * L
+        t[0] = 0
+        t[-1] = 3 if L == P else 2
+        st += t
+    return dict(observations=rng.randn(S, O).astype(np.float32),
+                last_observations=rng.randn(N_EPS, O).astype(np.float32),
+                actions=rng.randn(S, A).astype(np.float32),
+                rewards=rng.randn(S), step_types=np.asarray(st), lengths=lens)
+
+
+def _rank_main(rank, world, port, q, init_pol, init_vf):
+    try:
+        os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank),
+                          WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
+                          MASTER_PORT=str(port), GARAGE_AMD_BACKEND='gloo')
+        import sys
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        sys.path.insert(0, root)
+        from garage_amd._dtypes import Box, EnvSpec, EpisodeBatch, StepType
+        from garage_amd.algos import PPO
+        from garage_amd.distributed import init_from_env, shard_algo
+        from garage_amd.optimizers import OptimizerWrapper
+        from garage_amd.policies import (GaussianMLPPolicy,
+                                         GaussianMLPValueFunction)
+        comm = init_from_env()
+        spec = EnvSpec(Box(-np.inf, np.inf, (O, )), Box(-np.inf, np.inf, (A, )),
+                       max_episode_length=P)
+        pol = GaussianMLPPolicy(spec, hidden_sizes=(16, 16))
+        vf = GaussianMLPValueFunction(spec, hidden_sizes=(16, 16))
+        if rank == 0:  # rank 0's parameters must win (broadcast in shard_algo)
+            pol.load_state_dict(init_pol)
+            vf.load_state_dict(init_vf)
+        opt = (torch.optim.Adam, dict(lr=1e-3))
+        algo = PPO(env_spec=spec, policy=pol, value_function=vf, sampler=None,
+                   policy_optimizer=OptimizerWrapper(opt, pol, 3, None),
+                   vf_optimizer=OptimizerWrapper(opt, vf, 3, None))
+        shard_algo(algo, comm)
+        d = _make_shard(rank)
+        st = np.asarray([StepType(int(s)) for s in d['step_types']],
+                        dtype=object)
+        batch = EpisodeBatch(env_spec=spec, episode_infos={},
+                             observations=d['observations'],
+                             last_observations=d['last_observations'],
+                             actions=d['actions'], rewards=d['rewards'],
+                             env_infos={}, agent_infos={}, step_types=st,
+                             lengths=d['lengths'])
+        algo._train_once(0, batch)
+        out = {k: v.numpy() for k, v in pol.state_dict().items()}
+        out.update({'vf:' + k: v.numpy() for k, v in vf.state_dict().items()})
+        out['tab'] = dict(algo.last_tabular)
+        import torch.distributed as dist
+        dist.destroy_process_group()
+        q.put((rank, 'ok', out))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, 'error: %r\n%s' % (e, traceback.format_exc()), None))
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_ppo_equals_single_process_oracle():
+    from oracle import batch as ob
+    from oracle import networks as nets
+    from oracle.ppo import OraclePPO
+    rng = np.random.RandomState(0)
+    init_pol = nets.init_gaussian_mlp(rng, nets.POLICY_PREFIX, O, A, (16, 16),
+                                      min_std=1e-6)
+    init_vf = nets.init_gaussian_mlp(rng, nets.VALUE_PREFIX, O, 1, (16, 16))
+    for p in (init_pol, init_vf):  # biases / log-std away from their inits
+        for k in p:
+            if 'min_std' not in k:
+                p[k] = p[k] + torch.from_numpy(
+                    (rng.randn(*p[k].shape) * 0.05).astype(np.float32))
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_main,
+                         args=(r, 2, port, q, init_pol, init_vf))
+             for r in range(2)]
+    for p in procs:
+        p.start()
+    results = {}
+    for _ in range(2):
+        rank, status, out = q.get(timeout=240)
+        assert status == 'ok', status
+        results[rank] = out
+    for p in procs:
+        p.join(30)
+
+    shards = [_make_shard(r) for r in range(2)]
+    cat = {k: np.concatenate([s[k] for s in shards]) for k in shards[0]}
+    batch = ob.OracleEpisodeBatch(max_episode_length=P, **cat)
+    oracle = OraclePPO(init_pol, init_vf, max_episode_length=P,
+                       max_optimization_epochs=3, minibatch_size=None,
+                       policy_lr=1e-3, vf_lr=1e-3)
+    want = oracle.train_once(batch)
+    wp, wv = oracle.state()
+    for rank in (0, 1):
+        got = results[rank]
+        for k, v in wp.items():
+            assert np.allclose(got[k], v, atol=2e-6), (rank, k)
+        for k, v in wv.items():
+            assert np.allclose(got['vf:' + k], v, atol=2e-6), (rank, k)
+        for k in ('policy/LossBefore', 'policy/LossAfter', 'policy/KL',
+                  'vf/LossBefore', 'vf/LossAfter'):
+            assert np.isclose(got['tab'][k], want[k], atol=2e-5, rtol=2e-5), \
+                (rank, k, got['tab'][k], want[k])
