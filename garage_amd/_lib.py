@@ -106,6 +106,9 @@ SIGNATURES = {
     'ga_gaussian_kl_f32': (c_int, [ptr, ptr, c_i64, c_i64, c_int, c_f32, c_f32,
                                    ptr, ptr, ptr]),
     'ga_reduce_slabs_f32': (c_int, [ptr, c_i64, c_i64, c_i64, c_f32, ptr, ptr]),
+    'ga_reduce_adam_f32': (c_int, [ptr, c_i64, c_i64, ptr, ptr, ptr, ptr, c_i64,
+                                   c_i64, c_f64, c_f64, c_f64, c_f64, c_int,
+                                   ptr]),
     'ga_adam_step_f32': (c_int, [ptr, ptr, ptr, ptr, c_i64, c_i64, c_f64,
                                  c_f64, c_f64, c_f64, ptr]),
     'ga_stats_f32': (c_int, [ptr, c_i64, c_int, ptr, ptr, ptr]),

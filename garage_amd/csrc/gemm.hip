@@ -79,9 +79,10 @@ struct GemmParams {
 // a load inside a data-dependent branch makes hipcc wait vmcnt(0) right behind
 // it, which serialises the whole tile fetch in front of the MFMAs.  The gathered
 // line numbers (`idx`) are fetched one tile ahead for the same reason.
-template <int BR, bool KC, int NT>
+template <int BR, bool KC, int NT, int BKT>
 struct TileLoader {
-  static constexpr int NV = BR * BK / 4 / NT;  // float4 per thread
+  static constexpr int NV = BR * BKT / 4 / NT;  // float4 per thread
+  static constexpr int VPR = BKT / 4;           // vectors per row (KC = true)
   static constexpr int VPL = BR / 4;            // vectors per line (KC = false)
   float4 regs[NV];
   int32_t cur[NV];  // memory line (after the optional gather) of each vector
@@ -95,7 +96,7 @@ struct TileLoader {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int f = tid + NT * i;
-      want[i] = KC ? min(r0 + (f >> 3), R - 1) : min(kbeg + f / VPL, kend - 1);
+      want[i] = KC ? min(r0 + f / VPR, R - 1) : min(kbeg + f / VPL, kend - 1);
       want[i] = max(want[i], 0);
     }
     if (idx) {
@@ -137,7 +138,7 @@ struct TileLoader {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int f = tid + NT * i;
-      const int c = KC ? (k0 + 4 * (f & 7)) : (r0 + 4 * (f % VPL));
+      const int c = KC ? (k0 + 4 * (f % VPR)) : (r0 + 4 * (f % VPL));
       regs[i] = *reinterpret_cast<const float4*>(base + (int64_t)cur[i] * ld +
                                                  min(c, last));
     }
@@ -152,8 +153,8 @@ struct TileLoader {
       const int f = tid + NT * i;
       float4 v = regs[i];
       if (KC) {
-        const int r = f >> 3;
-        const int k = 4 * (f & 7);
+        const int r = f / VPR;
+        const int k = 4 * (f % VPR);
         const bool row_ok = (r0 + r) < R;
         v.x = (row_ok && k0 + k + 0 < kend) ? v.x : 0.f;
         v.y = (row_ok && k0 + k + 1 < kend) ? v.y : 0.f;
@@ -161,7 +162,7 @@ struct TileLoader {
         v.w = (row_ok && k0 + k + 3 < kend) ? v.w : 0.f;
         // k-contiguous in memory stays k-contiguous in LDS: [BR][BK + PAD],
         // one ds_write_b128 per vector, conflict free (8 lanes = one 128-B row)
-        *reinterpret_cast<float4*>(tile + r * (BK + PAD) + k) = v;
+        *reinterpret_cast<float4*>(tile + r * (BKT + PAD) + k) = v;
       } else {
         const int k = f / VPL;
         const int r = 4 * (f % VPL);
@@ -176,16 +177,17 @@ struct TileLoader {
   }
 };
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KC, bool B_KC>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KC, bool B_KC,
+          int BKT = BK>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_f32_kernel(
     GemmParams p) {
   constexpr int NT = 64 * WAVES_M * WAVES_N;  // threads per workgroup
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int TM = WM / 32, TN = WN / 32;
   // row-contiguous operands: [BK][BR + PAD]; k-contiguous ones: [BR][BK + PAD]
-  constexpr int LDA_S = BM + PAD, LDB_S = BN + PAD, LDK = BK + PAD;
-  constexpr int A_FLOATS = A_KC ? BM * LDK : BK * LDA_S;
-  constexpr int B_FLOATS = B_KC ? BN * LDK : BK * LDB_S;
+  constexpr int LDA_S = BM + PAD, LDB_S = BN + PAD, LDK = BKT + PAD;
+  constexpr int A_FLOATS = A_KC ? BM * LDK : BKT * LDA_S;
+  constexpr int B_FLOATS = B_KC ? BN * LDK : BKT * LDB_S;
   // two LDS stages: tile s+1 is written (3/4 of the way through the MFMAs of
   // tile s) into the stage nobody reads, so each k-step needs ONE barrier and the
   // ds_writes issue under the matrix pipe instead of between barriers
@@ -214,18 +216,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_f32_kernel(
       p.colsum != nullptr &&
       (p.colsum_of_b ? (blockIdx.x == 0) : (blockIdx.y == 0));
 
-  TileLoader<BM, A_KC, NT> la;
-  TileLoader<BN, B_KC, NT> lb;
+  TileLoader<BM, A_KC, NT, BKT> la;
+  TileLoader<BN, B_KC, NT, BKT> lb;
   const int a_span = A_KC ? p.K : p.M;  // valid floats along the contiguous axis
   const int b_span = B_KC ? p.K : p.N;
-  const int nk = (kend - kbeg + BK - 1) / BK;
+  const int nk = (kend - kbeg + BKT - 1) / BKT;
   if (nk > 0) {
     la.init(p.a_idx, m0, p.M, kbeg, kend);
     lb.init(p.b_idx, n0, p.N, kbeg, kend);
     la.load(p.A, p.lda, m0, kbeg, a_span);
     lb.load(p.B, p.ldb, n0, kbeg, b_span);
-    la.prefetch_lines(p.a_idx, kbeg + BK, kend);
-    lb.prefetch_lines(p.b_idx, kbeg + BK, kend);
+    la.prefetch_lines(p.a_idx, kbeg + BKT, kend);
+    lb.prefetch_lines(p.b_idx, kbeg + BKT, kend);
     la.store(lds, m0, p.M, kbeg, kend);
     lb.store(lds + A_FLOATS, n0, p.N, kbeg, kend);
   }
@@ -234,14 +236,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_f32_kernel(
   const int half = lane >> 5, l31 = lane & 31;
   for (int s = 0; s < nk; ++s) {
     const bool more = (s + 1 < nk);
-    const int k_next = kbeg + (s + 1) * BK;
+    const int k_next = kbeg + (s + 1) * BKT;
     if (more) {
       la.rotate();
       lb.rotate();
       la.load(p.A, p.lda, m0, k_next, a_span);
       lb.load(p.B, p.ldb, n0, k_next, b_span);
-      la.prefetch_lines(p.a_idx, k_next + BK, kend);
-      lb.prefetch_lines(p.b_idx, k_next + BK, kend);
+      la.prefetch_lines(p.a_idx, k_next + BKT, kend);
+      lb.prefetch_lines(p.b_idx, k_next + BKT, kend);
     }
     const float* As = lds + (STAGES == 2 ? (s & 1) : 0) * (A_FLOATS + B_FLOATS);
     const float* Bs = As + A_FLOATS;
@@ -251,7 +253,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_f32_kernel(
     // to step q (any k <-> slot map is valid as long as A and B agree), so a
     // k-contiguous operand is ONE ds_read_b128 per 4 MFMAs.
 #pragma unroll
-    for (int g = 0; g < BK / 8; ++g) {
+    for (int g = 0; g < BKT / 8; ++g) {
       float a[TM][4], b[TN][4];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_f32_kernel(
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[j][q],
                                                              acc[i][j], 0, 0, 0);
-      if (STAGES == 2 && g == BK / 8 - 2 && more) {
+      if (STAGES == 2 && g == BKT / 8 - 2 && more) {
         la.store(An, m0, p.M, k_next, kend);
         lb.store(Bn, n0, p.N, k_next, kend);
       }
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_f32_kernel(
       const int W = p.colsum_of_b ? BN : BM;
       if ((int)threadIdx.x < W) {
 #pragma unroll 8
-        for (int k = 0; k < BK; ++k) csum += T[k * LD + threadIdx.x];
+        for (int k = 0; k < BKT; ++k) csum += T[k * LD + threadIdx.x];
       }
     }
     __syncthreads();
@@ -354,6 +356,8 @@ int launch_gemm(const GemmParams& p, int splits, hipStream_t stream) {
     dim3 grid((unsigned)ga_ceil_div(p.M, 128), (unsigned)ga_ceil_div(p.N, 32),
               (unsigned)splits);
     ga_prof_events(GA_PROF_GEMM_NT_256 + mode, flops, &e0, &e1);
+    // (a 128-deep k tile -- 80 KB in flight per workgroup -- was tried for these
+    // latency-bound shapes and measured no better than 32: one workgroup per CU)
     hipExtLaunchKernelGGL((gemm_f32_kernel<128, 32, 4, 1, A_KC, B_KC>), grid,
                           dim3(256), 0, stream, e0, e1, 0, p);
   } else {

@@ -492,6 +492,63 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamParams a) {
   a.v[i] = v;
 }
 
+// reduce_slabs_kernel + adam_kernel in one launch (single process: nothing has
+// to happen between the slab sum and the optimizer step).  Same arithmetic and
+// the same summation order as the two separate kernels.
+__global__ __launch_bounds__(256) void reduce_adam_kernel(const float* slabs,
+                                                          int64_t n_splits,
+                                                          int64_t stride, int zero_slot0,
+                                                          AdamParams a, float* grads) {
+  __shared__ float4 part[4][64];
+  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int64_t i4 = ((int64_t)blockIdx.x * 64 + col) * 4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i4 < a.n) {
+    int64_t s = grp;
+    for (; s + 12 < n_splits; s += 16) {
+      const float4 v0 = *reinterpret_cast<const float4*>(slabs + s * stride + i4);
+      const float4 v1 =
+          *reinterpret_cast<const float4*>(slabs + (s + 4) * stride + i4);
+      const float4 v2 =
+          *reinterpret_cast<const float4*>(slabs + (s + 8) * stride + i4);
+      const float4 v3 =
+          *reinterpret_cast<const float4*>(slabs + (s + 12) * stride + i4);
+      acc.x += (v0.x + v1.x) + (v2.x + v3.x);
+      acc.y += (v0.y + v1.y) + (v2.y + v3.y);
+      acc.z += (v0.z + v1.z) + (v2.z + v3.z);
+      acc.w += (v0.w + v1.w) + (v2.w + v3.w);
+    }
+    for (; s < n_splits; s += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(slabs + s * stride + i4);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  }
+  part[grp][col] = acc;
+  __syncthreads();
+  if (grp != 0 || i4 >= a.n) return;
+  const float4 pa = part[0][col], pb = part[1][col], pc = part[2][col],
+               pd = part[3][col];
+  float g[4] = {(pa.x + pb.x) + (pc.x + pd.x), (pa.y + pb.y) + (pc.y + pd.y),
+                (pa.z + pb.z) + (pc.z + pd.z), (pa.w + pb.w) + (pc.w + pd.w)};
+  if (zero_slot0 && i4 == 0) g[0] = 0.f;  // log-std slot of a fixed-std module
+  *reinterpret_cast<float4*>(grads + i4) = make_float4(g[0], g[1], g[2], g[3]);
+  float4 p4 = *reinterpret_cast<float4*>(a.p + i4);
+  float4 m4 = *reinterpret_cast<float4*>(a.m + i4);
+  float4 v4 = *reinterpret_cast<float4*>(a.v + i4);
+  float pp[4] = {p4.x, p4.y, p4.z, p4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w},
+        vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    mm[j] = mm[j] + a.lerp_w * (g[j] - mm[j]);
+    vv[j] = vv[j] * a.beta2 + a.one_minus_beta2 * g[j] * g[j];
+    const float denom = sqrtf(vv[j]) / a.bc2_sqrt + a.eps;
+    pp[j] = pp[j] + (a.neg_step_size * mm[j]) / denom;
+  }
+  *reinterpret_cast<float4*>(a.p + i4) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+  *reinterpret_cast<float4*>(a.m + i4) = make_float4(mm[0], mm[1], mm[2], mm[3]);
+  *reinterpret_cast<float4*>(a.v + i4) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+}
+
 // ---- advantage statistics ---------------------------------------------------
 // stats (device, double[4]): [0] sum, [1] count, [2] sum of squared deviations,
 // [3] minimum.  Between the stages a multi-GPU caller all-reduces the slots.
@@ -710,6 +767,35 @@ extern "C" int ga_reduce_slabs_f32(const float* slabs, int64_t n_splits,
   hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)nb), dim3(256), 0, stream,
                      slabs, n_splits, slab_stride, n, out, scale);
   GA_CHECK_LAUNCH("reduce_slabs");
+  return GA_OK;
+}
+
+extern "C" int ga_reduce_adam_f32(const float* slabs, int64_t n_splits,
+                                  int64_t slab_stride, float* params, float* grads,
+                                  float* exp_avg, float* exp_avg_sq, int64_t n,
+                                  int64_t step, double lr, double beta1, double beta2,
+                                  double eps, int zero_slot0, hipStream_t stream) {
+  GA_REQUIRE(slabs && params && grads && exp_avg && exp_avg_sq,
+             "ga_reduce_adam_f32: null pointer");
+  GA_REQUIRE(n > 0 && n % 4 == 0 && slab_stride % 4 == 0 && n_splits >= 1 && step >= 1,
+             "ga_reduce_adam_f32: bad sizes");
+  GA_REQUIRE(ga_aligned16(slabs) && ga_aligned16(params) && ga_aligned16(grads) &&
+                 ga_aligned16(exp_avg) && ga_aligned16(exp_avg_sq),
+             "ga_reduce_adam_f32: 16-B alignment required");
+  AdamParams a;
+  a.p = params; a.g = grads; a.m = exp_avg; a.v = exp_avg_sq; a.n = n;
+  a.lerp_w = (float)(1.0 - beta1);
+  a.beta2 = (float)beta2;
+  a.one_minus_beta2 = (float)(1.0 - beta2);
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  const double bc2 = 1.0 - pow(beta2, (double)step);
+  a.neg_step_size = (float)(-(lr / bc1));
+  a.bc2_sqrt = (float)sqrt(bc2);
+  a.eps = (float)eps;
+  const int64_t nb = ga_ceil_div(n / 4, 64);
+  hipLaunchKernelGGL(reduce_adam_kernel, dim3((unsigned)nb), dim3(256), 0, stream,
+                     slabs, n_splits, slab_stride, zero_slot0, a, grads);
+  GA_CHECK_LAUNCH("reduce_adam");
   return GA_OK;
 }
 

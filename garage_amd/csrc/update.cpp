@@ -81,11 +81,17 @@ int run_minibatch(const ga_update_args* a, int64_t k, ga_stream_t stream) {
                            a->dout, a->ldo, a->dacts, a->slabs, a->n_flat, splits,
                            stream);
   if (rc) return rc;
+  if (!(a->comm && a->world > 1)) {
+    // single process: slab sum and Adam in one launch
+    return ga_reduce_adam_f32(a->slabs, splits, a->n_flat, a->params, a->grads,
+                              a->exp_avg, a->exp_avg_sq, a->n_flat, a->step0 + k + 1,
+                              a->lr, a->beta1, a->beta2, a->eps, !a->learn_std,
+                              stream);
+  }
   // data parallel: the global gradient is the sample-count weighted sum of the
   // rank gradients (mean over the union of the shards)
-  const float scale = (a->comm && a->world > 1) ? a->grad_scale : 1.0f;
-  rc = ga_reduce_slabs_f32(a->slabs, splits, a->n_flat, a->n_flat, scale, a->grads,
-                           stream);
+  rc = ga_reduce_slabs_f32(a->slabs, splits, a->n_flat, a->n_flat, a->grad_scale,
+                           a->grads, stream);
   if (rc) return rc;
   if (!a->learn_std) {
     if (hipMemsetAsync(a->grads, 0, sizeof(float), (hipStream_t)stream) !=
@@ -94,16 +100,14 @@ int run_minibatch(const ga_update_args* a, int64_t k, ga_stream_t stream) {
       return -2;
     }
   }
-  if (a->comm && a->world > 1) {
-    if (!g_allreduce) {
-      ga_set_error("ga_update_epoch: no all-reduce hook installed");
-      return -1;
-    }
-    rc = g_allreduce(a->comm, a->grads, a->n_flat, stream);
-    if (rc) {
-      ga_set_error("ga_update_epoch: all-reduce failed (%d)", rc);
-      return -2;
-    }
+  if (!g_allreduce) {
+    ga_set_error("ga_update_epoch: no all-reduce hook installed");
+    return -1;
+  }
+  rc = g_allreduce(a->comm, a->grads, a->n_flat, stream);
+  if (rc) {
+    ga_set_error("ga_update_epoch: all-reduce failed (%d)", rc);
+    return -2;
   }
   return ga_adam_step_f32(a->params, a->grads, a->exp_avg, a->exp_avg_sq, a->n_flat,
                           a->step0 + k + 1, a->lr, a->beta1, a->beta2, a->eps,

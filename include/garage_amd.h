@@ -147,6 +147,14 @@ int ga_gaussian_kl_f32(const float* mean_old, const float* mean_new, int64_t ld,
  * (torch/optimizers/optimizer_wrapper.py:53-63, _functions.py:25-65) */
 int ga_reduce_slabs_f32(const float* slabs, int64_t n_splits, int64_t slab_stride,
                         int64_t n, float scale, float* out, ga_stream_t stream);
+/* ga_reduce_slabs_f32 (scale 1) + ga_adam_step_f32 in one launch; the reduced
+ * gradient is also written to `grads`.  zero_slot0: keep element 0 (the log-std
+ * slot) untrained. */
+int ga_reduce_adam_f32(const float* slabs, int64_t n_splits, int64_t slab_stride,
+                       float* params, float* grads, float* exp_avg,
+                       float* exp_avg_sq, int64_t n, int64_t step, double lr,
+                       double beta1, double beta2, double eps, int zero_slot0,
+                       ga_stream_t stream);
 int ga_adam_step_f32(float* params, const float* grads, float* exp_avg,
                      float* exp_avg_sq, int64_t n, int64_t step, double lr,
                      double beta1, double beta2, double eps, ga_stream_t stream);
