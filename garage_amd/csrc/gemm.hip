@@ -408,6 +408,23 @@ extern "C" int ga_set_fused_forward(int on) {
   return 0;
 }
 
+// Streaming kernels for the layer products with one dimension <= 32 (skinny.hip).
+// Return 1 when they do not take the shape: the MFMA tile kernel handles it.
+int ga_skinny_forward(const float* X, int64_t ldx, const int32_t* idx, const float* W,
+                      int64_t ldw, bool w_kc, const float* bias, int act,
+                      const float* H, int64_t ldh, float* Y, int64_t ldy, int M, int N,
+                      int K, hipStream_t stream);
+int ga_skinny_wgrad(const float* Wd, int64_t ldw, const int32_t* w_idx, const float* Nr,
+                    int64_t ldn, const int32_t* n_idx, int rows, int wide, int NS,
+                    int rows_per_split, int n_splits, float* C, int64_t c_wide_stride,
+                    int64_t c_narrow_stride, int64_t split_stride, float* colsum_wide,
+                    float* colsum_narrow, hipStream_t stream);
+static int g_skinny = 1;
+extern "C" int ga_set_skinny_kernels(int on) {
+  g_skinny = on != 0;
+  return 0;
+}
+
 static int check_desc(const ga_mlp_desc* d, const char* who) {
   GA_REQUIRE(d != nullptr, "%s: null descriptor", who);
   GA_REQUIRE(d->n_layers >= 1 && d->n_layers <= 8, "%s: n_layers %d not in 1..8",
@@ -458,6 +475,12 @@ extern "C" int ga_mlp_forward_f32(const ga_mlp_desc* d, const float* params,
     p.bias = params + d->b_off[l];
     p.act = last ? 0 : 1;
     p.k_per_split = (int)ga_ceil_div(p.K, BK) * BK;
+    if (g_skinny && p.K <= 32 && p.N > 32) {
+      rc = ga_skinny_forward(p.A, p.lda, p.a_idx, p.B, p.ldb, true, p.bias, p.act,
+                             nullptr, 0, p.C, p.c_rs, p.M, p.N, p.K, stream);
+      if (rc < 0) return rc;
+      if (rc == 0) continue;
+    }
     rc = launch_gemm<true, true>(p, 1, stream);
     if (rc) return rc;
   }
@@ -533,8 +556,22 @@ extern "C" int ga_mlp_backward_f32(const ga_mlp_desc* d, const float* params,
         p.C = grad_slabs + d->w_off[l]; p.c_rs = round4(in_w); p.c_cs = 1;
         p.colsum_of_b = 0;
       }
-      rc = launch_gemm<false, false>(p, (int)n_splits, stream);
-      if (rc) return rc;
+      rc = 1;
+      if (g_skinny && in_w <= 32 && out_w > 32) {
+        // wide = dz (bias gradient = its column sums), narrow = layer input
+        rc = ga_skinny_wgrad(dz, lddz, nullptr, in, ldin, in_idx, (int)M, out_w, in_w, kps,
+                             (int)n_splits, grad_slabs + d->w_off[l], round4(in_w), 1,
+                             slab_stride, grad_slabs + d->b_off[l], nullptr, stream);
+      } else if (g_skinny && out_w <= 32 && in_w > 32) {
+        rc = ga_skinny_wgrad(in, ldin, in_idx, dz, lddz, nullptr, (int)M, in_w, out_w, kps,
+                             (int)n_splits, grad_slabs + d->w_off[l], 1, round4(in_w),
+                             slab_stride, nullptr, grad_slabs + d->b_off[l], stream);
+      }
+      if (rc < 0) return rc;
+      if (rc == 1) {
+        rc = launch_gemm<false, false>(p, (int)n_splits, stream);
+        if (rc) return rc;
+      }
     }
     // ---- data gradient for the layer below
     if (l > 0) {
@@ -547,8 +584,15 @@ extern "C" int ga_mlp_backward_f32(const ga_mlp_desc* d, const float* params,
       p.epi = EPI_MUL_DTANH;
       p.H = acts + d->act_off[l - 1]; p.ldh = round4(in_w);
       p.k_per_split = (int)ga_ceil_div(p.K, BK) * BK;
-      rc = launch_gemm<true, false>(p, 1, stream);
-      if (rc) return rc;
+      rc = 1;
+      if (g_skinny && p.K <= 32 && p.N > 32)
+        rc = ga_skinny_forward(p.A, p.lda, nullptr, p.B, p.ldb, false, nullptr, 0, p.H,
+                               p.ldh, p.C, p.c_rs, p.M, p.N, p.K, stream);
+      if (rc < 0) return rc;
+      if (rc == 1) {
+        rc = launch_gemm<true, false>(p, 1, stream);
+        if (rc) return rc;
+      }
     }
   }
   return GA_OK;

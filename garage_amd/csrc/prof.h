@@ -10,7 +10,9 @@ enum GaProfKind {
   GA_PROF_GEMM_NN_256 = 4,  // gemm_f32_kernel<128,32,4,1,true,false>
   GA_PROF_GEMM_TN_256 = 5,  // gemm_f32_kernel<128,32,4,1,false,false>
   GA_PROF_GAE_SCAN = 6,     // gae_scan_kernel<*>
-  GA_PROF_KINDS = 7
+  GA_PROF_SKINNY_FWD = 7,   // skinny_fwd_kernel<*>   (work = algorithmic bytes)
+  GA_PROF_SKINNY_WGRAD = 8, // skinny_wgrad_kernel<*> (work = algorithmic bytes)
+  GA_PROF_KINDS = 9
 };
 
 // When profiling is on, hands out a (start, stop) event pair to attach to ONE

@@ -80,6 +80,10 @@ int ga_mlp_forward_fused_f32(const ga_mlp_desc* d, const float* params,
                              int64_t M, float* acts, float* out, int64_t ldo,
                              ga_stream_t stream);
 int ga_set_fused_forward(int on);
+/* Layer products with one dimension <= 32 (first-layer forward, head data
+ * gradient, first-layer / head weight gradients) run as HBM-streaming kernels
+ * instead of MFMA tiles (default on; 0 = MFMA tiles everywhere, for A/B runs). */
+int ga_set_skinny_kernels(int on);
 /* split count ga_mlp_backward_f32 should be called with for M rows */
 int64_t ga_mlp_backward_splits(const ga_mlp_desc* d, int64_t M);
 /* dout = dLoss/d(out).  Writes n_splits partial gradient slabs, each laid out

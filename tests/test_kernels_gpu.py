@@ -192,6 +192,54 @@ def test_mlp_forward_gathered_rows(dev):
     assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize('shape', [(17, 6, (256, 256)), (4, 2, (64, 64)),
+                                   (3, 1, (32, 128)), (24, 17, (512,)),
+                                   (32, 24, (256, 64)), (8, 1, (1024, 16))])
+def test_streaming_layer_kernels_match_mfma_tiles(dev, shape):
+    """The HBM-streaming kernels for the narrow layer products (skinny.hip) against
+    the MFMA tile kernels on the same inputs: forward, gathered rows, ragged row
+    counts, several gradient splits."""
+    from garage_amd import _lib
+    from garage_amd.engine import FlatMLP, pad_rows
+    lib = _lib.load()
+    O, A, hs = shape
+    rng = np.random.RandomState(11)
+    mlp = FlatMLP(O, A, hs, dev)
+    mlp.params.copy_(torch.from_numpy(
+        (rng.randn(mlp.n_flat) * 0.3).astype(np.float32)))
+    for l in range(len(hs) + 1):
+        w = mlp.params[mlp.w_off[l]:mlp.b_off[l]].view(mlp.dims[l + 1], -1)
+        w[:, mlp.dims[l]:] = 0
+    n_rows = 3000
+    X = pad_rows(rng.randn(n_rows, O).astype(np.float32))
+    for M, gather in ((1, False), (777, True), (2999, True), (3000, False)):
+        idx = None
+        if gather:
+            idx = torch.from_numpy(
+                rng.randint(0, n_rows, size=M).astype(np.int32)).to(dev)
+        G = rng.randn(M, A).astype(np.float32)
+        res = {}
+        for on in (0, 1):
+            lib.ga_set_skinny_kernels(on)
+            out = mlp.forward(X, M, row_idx=idx).clone()
+            dout = mlp.dout_view(M)
+            dout.fill_(float('nan'))  # padding columns must never be read
+            dout[:, :A] = torch.from_numpy(G).to(dev)
+            mlp.backward(X, M, dout, row_idx=idx)
+            mlp.reduce_grads()
+            res[on] = (out[:, :A].clone(), mlp.grads.clone())
+        lib.ga_set_skinny_kernels(1)
+        assert torch.isfinite(res[1][0]).all() and torch.isfinite(res[1][1]).all()
+        # different summation orders of the same fp32 products: a few ulp of the
+        # largest term
+        scale = max(1.0, float(res[0][0].abs().max()))
+        assert torch.allclose(res[0][0], res[1][0], atol=5e-6 * scale,
+                              rtol=1e-5), M
+        scale = max(1.0, float(res[0][1].abs().max()))
+        assert torch.allclose(res[0][1], res[1][1], atol=5e-6 * scale,
+                              rtol=1e-5), M
+
+
 def _ppo_oracle_loss(pol, obs, act, old_ll, adv, clip, algo='ppo', ent=None):
     from oracle import networks as nets
     dist = nets.gaussian_dist(pol, '_module.', obs)

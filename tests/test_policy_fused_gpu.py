@@ -129,10 +129,12 @@ def test_fused_training_forward_matches_per_layer_gemms(O, A, hidden, M):
          dptr(X), X.stride(0), dptr(idx), M, dptr(net._acts), dptr(out),
          out.stride(0), stream_ptr())
     assert np.allclose(out[:, :A].cpu().numpy(), want[:, :A].cpu().numpy(),
-                       atol=2e-6)
+                       atol=1e-5)
     for l, h in enumerate(hidden):
         w = (h + 3) // 4 * 4
         off = net.act_off[l] * net._cap
         a = net._acts[off:off + M * w].view(M, w)[:, :h]
         b = want_acts[off:off + M * w].view(M, w)[:, :h]
-        assert torch.equal(a, b), l  # same k <-> MFMA slot map: bit identical
+        # (layers the streaming kernels take sum k in a different order than the
+        # MFMA slot map the fused kernel shares with the tile GEMMs)
+        assert torch.allclose(a, b, atol=5e-6), l
