@@ -79,7 +79,9 @@ struct GemmParams {
 // a load inside a data-dependent branch makes hipcc wait vmcnt(0) right behind
 // it, which serialises the whole tile fetch in front of the MFMAs.  The gathered
 // line numbers (`idx`) are fetched one tile ahead for the same reason.
-template <int BR, bool KC, int NT, int BKT>
+// FULL: the launch guarantees every tile is entirely inside the matrices, so the
+// clamps and the zero masks (16 v_cndmask per vector pair and k-step) drop out.
+template <int BR, bool KC, int NT, int BKT, bool FULL>
 struct TileLoader {
   static constexpr int NV = BR * BKT / 4 / NT;  // float4 per thread
   static constexpr int VPR = BKT / 4;           // vectors per row (KC = true)
@@ -140,7 +142,7 @@ struct TileLoader {
       const int f = tid + NT * i;
       const int c = KC ? (k0 + 4 * (f % VPR)) : (r0 + 4 * (f % VPL));
       regs[i] = *reinterpret_cast<const float4*>(base + (int64_t)cur[i] * ld +
-                                                 min(c, last));
+                                                 (FULL ? c : min(c, last)));
     }
   }
 
@@ -155,22 +157,26 @@ struct TileLoader {
       if (KC) {
         const int r = f / VPR;
         const int k = 4 * (f % VPR);
-        const bool row_ok = (r0 + r) < R;
-        v.x = (row_ok && k0 + k + 0 < kend) ? v.x : 0.f;
-        v.y = (row_ok && k0 + k + 1 < kend) ? v.y : 0.f;
-        v.z = (row_ok && k0 + k + 2 < kend) ? v.z : 0.f;
-        v.w = (row_ok && k0 + k + 3 < kend) ? v.w : 0.f;
+        if (!FULL) {
+          const bool row_ok = (r0 + r) < R;
+          v.x = (row_ok && k0 + k + 0 < kend) ? v.x : 0.f;
+          v.y = (row_ok && k0 + k + 1 < kend) ? v.y : 0.f;
+          v.z = (row_ok && k0 + k + 2 < kend) ? v.z : 0.f;
+          v.w = (row_ok && k0 + k + 3 < kend) ? v.w : 0.f;
+        }
         // k-contiguous in memory stays k-contiguous in LDS: [BR][BK + PAD],
         // one ds_write_b128 per vector, conflict free (8 lanes = one 128-B row)
         *reinterpret_cast<float4*>(tile + r * (BKT + PAD) + k) = v;
       } else {
         const int k = f / VPL;
         const int r = 4 * (f % VPL);
-        const bool k_ok = (k0 + k) < kend;
-        v.x = (k_ok && r0 + r + 0 < R) ? v.x : 0.f;
-        v.y = (k_ok && r0 + r + 1 < R) ? v.y : 0.f;
-        v.z = (k_ok && r0 + r + 2 < R) ? v.z : 0.f;
-        v.w = (k_ok && r0 + r + 3 < R) ? v.w : 0.f;
+        if (!FULL) {
+          const bool k_ok = (k0 + k) < kend;
+          v.x = (k_ok && r0 + r + 0 < R) ? v.x : 0.f;
+          v.y = (k_ok && r0 + r + 1 < R) ? v.y : 0.f;
+          v.z = (k_ok && r0 + r + 2 < R) ? v.z : 0.f;
+          v.w = (k_ok && r0 + r + 3 < R) ? v.w : 0.f;
+        }
         *reinterpret_cast<float4*>(tile + k * LD + r) = v;
       }
     }
@@ -178,7 +184,7 @@ struct TileLoader {
 };
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KC, bool B_KC,
-          int BKT = BK>
+          int BKT = BK, bool FULL = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_f32_kernel(
     GemmParams p) {
   constexpr int NT = 64 * WAVES_M * WAVES_N;  // threads per workgroup
@@ -216,8 +222,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_f32_kernel(
       p.colsum != nullptr &&
       (p.colsum_of_b ? (blockIdx.x == 0) : (blockIdx.y == 0));
 
-  TileLoader<BM, A_KC, NT, BKT> la;
-  TileLoader<BN, B_KC, NT, BKT> lb;
+  TileLoader<BM, A_KC, NT, BKT, FULL> la;
+  TileLoader<BN, B_KC, NT, BKT, FULL> lb;
   const int a_span = A_KC ? p.K : p.M;  // valid floats along the contiguous axis
   const int b_span = B_KC ? p.K : p.N;
   const int nk = (kend - kbeg + BKT - 1) / BKT;
@@ -366,8 +372,15 @@ int launch_gemm(const GemmParams& p, int splits, hipStream_t stream) {
     ga_prof_events(GA_PROF_GEMM_NT_128 + mode, flops, &e0, &e1);
     // 8 waves (64x32 each): two workgroups per CU put 4 waves on every SIMD, so
     // the matrix pipe has work while other waves sit at the barrier / vmcnt
-    hipExtLaunchKernelGGL((gemm_f32_kernel<128, 128, 2, 4, A_KC, B_KC>), grid,
-                          dim3(512), 0, stream, e0, e1, 0, p);
+    // interior-only launches (every C3 update GEMM) skip the edge masks
+    const bool full = p.M % 128 == 0 && p.N % 128 == 0 && p.K % BK == 0 &&
+                      p.k_per_split % BK == 0 && p.K % p.k_per_split == 0;
+    if (full)
+      hipExtLaunchKernelGGL((gemm_f32_kernel<128, 128, 2, 4, A_KC, B_KC, BK, true>),
+                            grid, dim3(512), 0, stream, e0, e1, 0, p);
+    else
+      hipExtLaunchKernelGGL((gemm_f32_kernel<128, 128, 2, 4, A_KC, B_KC>), grid,
+                            dim3(512), 0, stream, e0, e1, 0, p);
   }
   GA_CHECK_LAUNCH("gemm_f32");
   return GA_OK;
