@@ -45,14 +45,18 @@ CPU_THREADS = int(os.environ.get('GARAGE_AMD_CPU_THREADS', '16'))
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
 
+# garage_amd/csrc/prof.h kinds.  The 128x128 kinds cover the mask-free
+# (<...,32,true>, every C3 launch) and the masked (<...,32,false>) instantiation.
 KIND_NAMES = [
-    'gemm_f32_kernel<128,128,2,4,true,true> (forward)',
-    'gemm_f32_kernel<128,128,2,4,true,false> (data grad)',
-    'gemm_f32_kernel<128,128,2,4,false,false> (weight grad)',
-    'gemm_f32_kernel<128,32,4,1,true,true> (forward, narrow)',
-    'gemm_f32_kernel<128,32,4,1,true,false> (data grad, narrow)',
-    'gemm_f32_kernel<128,32,4,1,false,false> (weight grad, narrow)',
+    'gemm_f32_kernel<128,128,2,4,true,true,32,true> (forward)',
+    'gemm_f32_kernel<128,128,2,4,true,false,32,true> (data grad)',
+    'gemm_f32_kernel<128,128,2,4,false,false,32,true> (weight grad)',
+    'gemm_f32_kernel<128,32,4,1,true,true,32,false> (forward, narrow)',
+    'gemm_f32_kernel<128,32,4,1,true,false,32,false> (data grad, narrow)',
+    'gemm_f32_kernel<128,32,4,1,false,false,32,false> (weight grad, narrow)',
     'gae_scan_kernel',
+    'skinny_fwd_kernel (first-layer forward / head data grad; work = bytes)',
+    'skinny_wgrad_kernel (first-layer / head weight grad; work = bytes)',
 ]
 
 
@@ -324,6 +328,15 @@ def main():
                  total_ms=round(r['total_ms'], 3),
                  avg_us=round(r['total_ms'] * 1e3 / max(1, r['launches']), 2))
             for r in rows if r['launches'] > 0
+        ]
+        # the HBM-streaming layer kernels: algorithmic bytes / their own time
+        line['roofline_streaming'] = [
+            dict(kernel=r['kernel'].split(' (')[0], bound='hbm',
+                 achieved=r['work'] / (r['total_ms'] * 1e-3) / 1e9,
+                 peak=PEAK_HBM_GBS, unit='GB/s',
+                 frac=r['work'] / (r['total_ms'] * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                 avg_launch_us=r['total_ms'] * 1e3 / r['launches'])
+            for r in rows[7:9] if r['launches'] > 0
         ]
     if args.cpu_envs > 0 and world == 1:
         line['cpu_baseline'] = cpu_baseline(cfg, args.cpu_envs)

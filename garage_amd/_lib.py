@@ -127,6 +127,9 @@ SIGNATURES = {
     'ga_policy_step_fused_f32': (c_int, [C.POINTER(MlpDesc), ptr,
                                          C.POINTER(HeadArgs), ptr]),
     'ga_record_step': (c_int, [C.POINTER(RecordArgs), ptr]),
+    'ga_synth_env_step_record': (c_int, [C.POINTER(SynthEnv),
+                                         C.POINTER(RecordArgs), ptr, c_i64, ptr,
+                                         ptr]),
     'ga_rollout_synth_steps': (c_int, [C.POINTER(MlpDesc), ptr,
                                        C.POINTER(HeadArgs),
                                        C.POINTER(SynthEnv),

@@ -73,12 +73,8 @@ __device__ __forceinline__ int synth_len(const SynthEnv& e, uint32_t env,
 }
 
 // reset envs where mask != 0 (mask == null: all); writes the first observation.
-__global__ __launch_bounds__(256) void synth_reset_kernel(SynthEnv e,
-                                                          const uint8_t* mask,
-                                                          float* obs, int64_t ldo) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= e.n) return;
-  if (mask && !mask[i]) return;
+__device__ __forceinline__ void synth_reset_one(const SynthEnv& e, int64_t i,
+                                                float* obs, int64_t ldo) {
   const uint32_t env = (uint32_t)(e.env_id0 + i);
   const int ep = e.episode[i] + 1;
   e.episode[i] = ep;
@@ -87,12 +83,19 @@ __global__ __launch_bounds__(256) void synth_reset_kernel(SynthEnv e,
   synth_obs(e, env, (uint32_t)ep, 0u, obs + i * ldo);
 }
 
-// one env step: reward, step type and the (true) next observation.
-__global__ __launch_bounds__(256) void synth_step_kernel(
-    SynthEnv e, const float* actions, int64_t lda, const float* obs, float* next_obs,
-    int64_t ldo, float* reward, uint8_t* step_type) {
+__global__ __launch_bounds__(256) void synth_reset_kernel(SynthEnv e,
+                                                          const uint8_t* mask,
+                                                          float* obs, int64_t ldo) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= e.n) return;
+  if (mask && !mask[i]) return;
+  synth_reset_one(e, i, obs, ldo);
+}
+
+// one env step: reward, step type and the (true) next observation.
+__device__ __forceinline__ void synth_step_one(
+    const SynthEnv& e, int64_t i, const float* actions, int64_t lda, const float* obs,
+    float* next_obs, int64_t ldo, float* reward, uint8_t* step_type) {
   const uint32_t env = (uint32_t)(e.env_id0 + i);
   const uint32_t ep = (uint32_t)e.episode[i];
   const int t = e.t[i];
@@ -121,6 +124,14 @@ __global__ __launch_bounds__(256) void synth_step_kernel(
   else if (tn == 1) st = 0;
   else st = 1;
   step_type[i] = st;
+}
+
+__global__ __launch_bounds__(256) void synth_step_kernel(
+    SynthEnv e, const float* actions, int64_t lda, const float* obs, float* next_obs,
+    int64_t ldo, float* reward, uint8_t* step_type) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= e.n) return;
+  synth_step_one(e, i, actions, lda, obs, next_obs, ldo, reward, step_type);
 }
 
 // ---- NormalizedEnv observation / reward path -----------------------------------
@@ -299,10 +310,10 @@ struct RecordParams {
   int terminal_only;         // 1: only TERMINAL (not TIMEOUT) ends an episode
 };
 
-__global__ __launch_bounds__(256) void record_step_kernel(RecordParams p) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+// bookkeeping of env i; returns the length of the episode that ended (else 0)
+__device__ __forceinline__ int record_one(const RecordParams& p, int64_t i) {
   int ended_len = 0;
-  if (i < p.n) {
+  {
     const int64_t cell = i * p.Tcap + p.col;
     const int t = p.ep_t[i] + 1;
     const uint8_t st = p.step_type[i];
@@ -322,7 +333,12 @@ __global__ __launch_bounds__(256) void record_step_kernel(RecordParams p) {
       for (int j = 0; j < p.obs_dim; ++j) lo[j] = o[j];
     }
   }
-  // wave-aggregated integer atomics (deterministic: integer adds commute)
+  return ended_len;
+}
+
+// per-step completion counts: wave-aggregated integer atomics (deterministic:
+// integer adds commute)
+__device__ __forceinline__ void record_counts(const RecordParams& p, int ended_len) {
   const uint64_t ballot = __ballot(ended_len > 0);
   int sum = ended_len;
 #pragma unroll
@@ -331,6 +347,26 @@ __global__ __launch_bounds__(256) void record_step_kernel(RecordParams p) {
     atomicAdd(&p.step_eps[p.col], (int)__popcll(ballot));
     atomicAdd(&p.step_samples[p.col], sum);
   }
+}
+
+__global__ __launch_bounds__(256) void record_step_kernel(RecordParams p) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  record_counts(p, i < p.n ? record_one(p, i) : 0);
+}
+
+// env step -> bookkeeping -> reset of the envs that finished, one thread per env
+// and one launch (the three stages only touch env i's own state).
+__global__ __launch_bounds__(256) void synth_step_record_kernel(
+    SynthEnv e, RecordParams p, const float* actions, int64_t lda, const float* obs,
+    float* next_obs, float* reward, uint8_t* step_type) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int ended_len = 0;
+  if (i < e.n) {
+    synth_step_one(e, i, actions, lda, obs, next_obs, p.ldo, reward, step_type);
+    ended_len = record_one(p, i);
+    if (ended_len > 0) synth_reset_one(e, i, next_obs, p.ldo);
+  }
+  record_counts(p, ended_len);
 }
 
 // ---- ragged -> packed ------------------------------------------------------------
@@ -580,6 +616,39 @@ extern "C" int ga_record_step(const ga_record_args* a, hipStream_t stream) {
   hipLaunchKernelGGL(record_step_kernel, dim3((unsigned)ga_ceil_div(a->n, 256)),
                      dim3(256), 0, stream, p);
   GA_CHECK_LAUNCH("record_step");
+  return GA_OK;
+}
+
+extern "C" int ga_synth_env_step_record(const ga_synth_env* env,
+                                        const ga_record_args* a, const float* actions,
+                                        int64_t lda, const float* obs,
+                                        hipStream_t stream) {
+  int rc = check_env(env, "ga_synth_env_step_record");
+  if (rc) return rc;
+  GA_REQUIRE(a && a->reward && a->step_type && a->next_obs && a->ep_t && a->rew_buf &&
+                 a->st_buf && a->tail_buf && a->lastobs_buf && a->done &&
+                 a->step_eps && a->step_samples && actions && obs,
+             "ga_synth_env_step_record: null pointer");
+  GA_REQUIRE(a->n == env->n && a->col >= 0 && a->col < a->Tcap,
+             "ga_synth_env_step_record: col %lld out of range (Tcap %lld)",
+             (long long)a->col, (long long)a->Tcap);
+  GA_REQUIRE(a->max_episode_length >= 1 && a->max_episode_length <= 65535,
+             "ga_synth_env_step_record: max_episode_length must be in 1..65535");
+  GA_REQUIRE(a->ldo >= env->obs_dim && a->obs_dim == env->obs_dim &&
+                 lda >= (env->discrete ? 1 : env->act_dim),
+             "ga_synth_env_step_record: leading dimensions too small");
+  RecordParams p;
+  p.n = a->n; p.col = a->col; p.Tcap = a->Tcap;
+  p.max_episode_length = a->max_episode_length; p.reward = a->reward;
+  p.step_type = a->step_type; p.next_obs = a->next_obs; p.ldo = a->ldo;
+  p.obs_dim = a->obs_dim; p.ep_t = a->ep_t; p.rew_buf = a->rew_buf;
+  p.st_buf = a->st_buf; p.tail_buf = a->tail_buf; p.lastobs_buf = a->lastobs_buf;
+  p.done = a->done; p.step_eps = a->step_eps; p.step_samples = a->step_samples;
+  p.terminal_only = a->terminal_only;
+  hipLaunchKernelGGL(synth_step_record_kernel, dim3((unsigned)ga_ceil_div(a->n, 256)),
+                     dim3(256), 0, stream, to_dev(env), p, actions, lda, obs,
+                     (float*)a->next_obs, (float*)a->reward, (uint8_t*)a->step_type);
+  GA_CHECK_LAUNCH("synth_step_record");
   return GA_OK;
 }
 

@@ -1,9 +1,9 @@
 // `n_steps` vectorised rollout steps of the synthetic environment enqueued from
-// C++: fused policy step -> env step -> bookkeeping -> reset of finished envs,
-// ping-ponging the two observation buffers.  Same kernels and order as
-// GpuVecWorker._step drives from Python (VecWorker.step_episode,
-// sampler/vec_worker.py:176-204); it exists because at 4 launches per step the
-// Python/ctypes overhead (~50 us) is twice the device time of a step.
+// C++: fused policy step, then env step -> bookkeeping -> reset of finished envs
+// in one launch, ping-ponging the two observation buffers.  Same per-env
+// operations and order as GpuVecWorker._step drives from Python
+// (VecWorker.step_episode, sampler/vec_worker.py:176-204); it exists because the
+// Python/ctypes overhead per launch (~12 us) exceeds the device time of a step.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -39,14 +39,10 @@ extern "C" int ga_rollout_synth_steps(const ga_mlp_desc* desc, const float* para
     h.obs = cur;
     int rc = ga_policy_step_fused_f32(desc, params, &h, stream);
     if (rc) return rc;
-    rc = ga_synth_env_step(env, h.action, h.lda, cur, nxt, h.ldo, (float*)r.reward,
-                           (uint8_t*)r.step_type, stream);
-    if (rc) return rc;
+    // env step -> bookkeeping -> reset of the finished envs: one launch
     r.col = h.col;
     r.next_obs = nxt;
-    rc = ga_record_step(&r, stream);
-    if (rc) return rc;
-    rc = ga_synth_env_reset(env, r.done, nxt, h.ldo, stream);
+    rc = ga_synth_env_step_record(env, &r, h.action, h.lda, cur, stream);
     if (rc) return rc;
     float* t = cur;
     cur = nxt;

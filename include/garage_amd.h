@@ -242,6 +242,12 @@ typedef struct {
                             (sampler/fragment_worker.py:114-115) */
 } ga_record_args;
 int ga_record_step(const ga_record_args* args, ga_stream_t stream);
+/* ga_synth_env_step -> ga_record_step -> ga_synth_env_reset(done) of the synthetic
+ * environment in one launch (same per-env results; rec->next_obs receives the next
+ * observation, or the first observation of the new episode where one ended). */
+int ga_synth_env_step_record(const ga_synth_env* env, const ga_record_args* rec,
+                             const float* actions, int64_t lda, const float* obs,
+                             ga_stream_t stream);
 
 /* n_steps consecutive vectorised steps (fused policy step, synthetic env step,
  * bookkeeping, reset of finished envs) starting at head->col / head->step,

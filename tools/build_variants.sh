@@ -13,7 +13,6 @@ build() {  # name, flags...
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs $OUT/gemm_$name.o -ldl -o $OUT/lib_$name.so
   echo built $name
 }
-build nostoreonly -DGA_ABL_NOSTORE &
-build nomask -DGA_ABL_NOMASK &
-build nomask_nobar -DGA_ABL_NOMASK -DGA_ABL_NOBARRIER &
+build w8 -DGA_WN=4 &
+build w4 -DGA_WN=2 &
 wait
