@@ -243,9 +243,20 @@ def main():
         comm.all_reduce(elapsed, 'max')
     elapsed = float(elapsed.item())
 
-    rows = None
+    # Instrumented iterations after the timed region (every GEMM / scan /
+    # streaming launch bracketed by HIP events on its stream).  `rows`: policy and
+    # value passes on ONE stream, so a launch's duration is the kernel's own;
+    # `rows_ovl`: the timed region's mode when that is the overlapped one (there
+    # a duration includes the time the kernel shares the chip with the other
+    # chain's kernels).
+    rows = rows_ovl = None
     if not args.no_roofline:
+        algo.overlap_updates = False
         rows = roofline_pass(algo, sampler, pol, S, itr)
+        itr += 1
+        if not args.no_overlap:
+            algo.overlap_updates = True
+            rows_ovl = roofline_pass(algo, sampler, pol, S, itr)
     if rank != 0:
         return
     ms_per_step = elapsed / args.steps * 1e3
@@ -289,9 +300,23 @@ def main():
             'frac': tflops / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
             'launches_per_iteration': dom['launches'],
             'avg_launch_us': dom['total_ms'] * 1e3 / dom['launches'],
-            'share_of_iteration': dom['total_ms'] / ms_per_step,
+            'measured': 'HIP events attached to every launch of the kernel in one '
+                        'instrumented iteration after the timed region, policy '
+                        'and value passes on one stream (the kernel alone on the '
+                        'chip; agrees with profiles/*no_overlap_kernel_stats.csv)',
         }
-        line['roofline']['update_streams'] = 1 if args.no_overlap else 2
+        if rows_ovl is not None:
+            o = rows_ovl[rows.index(dom)]
+            otf = o['work'] / (o['total_ms'] * 1e-3) / 1e12
+            line['roofline_overlapped'] = {
+                'kernel': o['kernel'], 'achieved': otf, 'unit': 'TFLOP/s',
+                'frac': otf / PEAK_FP32_MFMA_TFLOPS,
+                'avg_launch_us': o['total_ms'] * 1e3 / o['launches'],
+                'note': 'the same kernel during an instrumented iteration in the '
+                        'timed region\'s mode (2 streams): durations include '
+                        'sharing the chip with the other chain; agrees with '
+                        'profiles/*_overlap_kernel_stats.csv',
+            }
         traffic = load_traffic()
         key = dom['kernel'].split(' (')[0].replace(',', ', ')
         if args.config == 'c3' and key in traffic:

@@ -39,6 +39,27 @@ static inline bool ga_aligned16(const void* p) {
 static inline int64_t ga_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // ---- device helpers --------------------------------------------------------
+// XCD-aware workgroup order.  Workgroups are dealt to the 8 XCDs round-robin by
+// their linear id, and each XCD has its own L2, so workgroups that read the same
+// operand tile should have equal id % 8 (one L2 fetch instead of one per XCD) and
+// close ids (co-resident).  Groups of `n_members` such workgroups are laid out as
+//   id = (grp / 8) * 8 * n_members + member * 8 + grp % 8
+// with the last n_groups % 8 groups in plain order.
+__device__ __forceinline__ void ga_xcd_group(int id, int n_groups, int n_members,
+                                             int* grp, int* member) {
+  const int chunk = 8 * n_members;
+  const int full = (n_groups / 8) * chunk;
+  if (id < full) {
+    const int c = id / chunk, r = id % chunk;
+    *grp = c * 8 + (r & 7);
+    *member = r >> 3;
+  } else {
+    const int r = id - full;
+    *grp = (n_groups / 8) * 8 + r / n_members;
+    *member = r % n_members;
+  }
+}
+
 __device__ __forceinline__ float ga_wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);

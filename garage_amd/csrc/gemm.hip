@@ -69,6 +69,7 @@ struct GemmParams {
   float* colsum;         // optional: sum_k of operand A (or B) -> colsum[line]
   int colsum_of_b;       // 0: columns of A tile (index m), 1: of B tile (index n)
   int64_t colsum_split_stride;
+  int gx, gy, gz;        // logical grid (m blocks, n blocks, splits); 1-D launch
 };
 
 // One [BR x BK] operand tile: global -> registers -> LDS.
@@ -203,9 +204,22 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_f32_kernel(
   const int wave = threadIdx.x >> 6;
   const int wm0 = (wave / WAVES_N) * WM;
   const int wn0 = (wave % WAVES_N) * WN;
-  const int m0 = blockIdx.x * BM;
-  const int n0 = blockIdx.y * BN;
-  const int split = blockIdx.z;
+  // logical block from the linear id (XCD-aware order, common.h): with one split
+  // the n blocks of an m block share its A tile; with split-K every block of a
+  // split shares the split's A and B rows
+  int bx, by, bz;
+  if (p.gz == 1) {
+    ga_xcd_group((int)blockIdx.x, p.gx, p.gy, &bx, &by);
+    bz = 0;
+  } else {
+    int mem;
+    ga_xcd_group((int)blockIdx.x, p.gz, p.gx * p.gy, &bz, &mem);
+    bx = mem % p.gx;
+    by = mem / p.gx;
+  }
+  const int m0 = bx * BM;
+  const int n0 = by * BN;
+  const int split = bz;
   const int kbeg = split * p.k_per_split;
   const int kend = min(p.K, kbeg + p.k_per_split);
 
@@ -220,7 +234,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_f32_kernel(
   float csum = 0.f;  // colsum accumulator (threads < BM or < BN)
   const bool do_colsum =
       p.colsum != nullptr &&
-      (p.colsum_of_b ? (blockIdx.x == 0) : (blockIdx.y == 0));
+      (p.colsum_of_b ? (bx == 0) : (by == 0));
 
   TileLoader<BM, A_KC, NT, BKT, FULL> la;
   TileLoader<BN, B_KC, NT, BKT, FULL> lb;
@@ -351,7 +365,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_f32_kernel(
 }
 
 template <bool A_KC, bool B_KC>
-int launch_gemm(const GemmParams& p, int splits, hipStream_t stream) {
+int launch_gemm(const GemmParams& p_in, int splits, hipStream_t stream) {
+  GemmParams p = p_in;
   const int mode = (A_KC && B_KC) ? 0 : (A_KC ? 1 : 2);
   // algorithmic flops: 2 M N K (the padding of ragged tiles is not counted)
   const double flops = 2.0 * (double)p.M * (double)p.N * (double)p.K;
@@ -359,16 +374,16 @@ int launch_gemm(const GemmParams& p, int splits, hipStream_t stream) {
   if (p.N <= 32) {
     // narrow outputs are HBM bound on the wide operand: 128-row tiles give
     // M/128 workgroups (256 at the C3 minibatch) to pull it through
-    dim3 grid((unsigned)ga_ceil_div(p.M, 128), (unsigned)ga_ceil_div(p.N, 32),
-              (unsigned)splits);
+    p.gx = (int)ga_ceil_div(p.M, 128); p.gy = (int)ga_ceil_div(p.N, 32); p.gz = splits;
+    dim3 grid((unsigned)(p.gx * p.gy * p.gz));
     ga_prof_events(GA_PROF_GEMM_NT_256 + mode, flops, &e0, &e1);
     // (a 128-deep k tile -- 80 KB in flight per workgroup -- was tried for these
     // latency-bound shapes and measured no better than 32: one workgroup per CU)
     hipExtLaunchKernelGGL((gemm_f32_kernel<128, 32, 4, 1, A_KC, B_KC>), grid,
                           dim3(256), 0, stream, e0, e1, 0, p);
   } else {
-    dim3 grid((unsigned)ga_ceil_div(p.M, 128), (unsigned)ga_ceil_div(p.N, 128),
-              (unsigned)splits);
+    p.gx = (int)ga_ceil_div(p.M, 128); p.gy = (int)ga_ceil_div(p.N, 128); p.gz = splits;
+    dim3 grid((unsigned)(p.gx * p.gy * p.gz));
     ga_prof_events(GA_PROF_GEMM_NT_128 + mode, flops, &e0, &e1);
     // 8 waves (64x32 each): two workgroups per CU put 4 waves on every SIMD, so
     // the matrix pipe has work while other waves sit at the barrier / vmcnt

@@ -162,6 +162,7 @@ struct SkinnyWgradParams {
   int rows, wide, NS;
   int rows_per_split;
   int qpr;               // wide column quads per workgroup (<= 64)
+  int n_colblk, n_splits;  // logical grid; launched 1-D in XCD-aware order
   float* C;
   int64_t c_wide_stride, c_narrow_stride;  // C(c, j) at c * cws + j * cns
   int64_t split_stride;
@@ -188,10 +189,12 @@ __global__ __launch_bounds__(SW_THREADS) void skinny_wgrad_kernel(SkinnyWgradPar
   const int q = tid % p.qpr;
   const int rg = tid / p.qpr;
   const int n_rg = SW_THREADS / p.qpr;
-  const int c0 = (blockIdx.x * p.qpr + q) * 4;
+  // the column blocks of a split read the same narrow rows: same XCD (common.h)
+  int split, colblk;
+  ga_xcd_group((int)blockIdx.x, p.n_splits, p.n_colblk, &split, &colblk);
+  const int c0 = (colblk * p.qpr + q) * 4;
   const bool col_ok = c0 < p.wide;
   const int cc = col_ok ? c0 : 0;
-  const int split = blockIdx.y;
   const int r_beg = split * p.rows_per_split;
   const int r_end = min(p.rows, r_beg + p.rows_per_split);
 
@@ -203,7 +206,7 @@ __global__ __launch_bounds__(SW_THREADS) void skinny_wgrad_kernel(SkinnyWgradPar
     acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (NSUM) nsum[j] = 0.f;
   }
-  const bool want_nsum = NSUM && blockIdx.x == 0 && q == 0;
+  const bool want_nsum = NSUM && colblk == 0 && q == 0;
 
   for (int rc = r_beg; rc < r_end; rc += SW_CHUNK) {
     const int rc_end = min(r_end, rc + SW_CHUNK);
@@ -288,7 +291,7 @@ __global__ __launch_bounds__(SW_THREADS) void skinny_wgrad_kernel(SkinnyWgradPar
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
       }
       const int j = j0 + jj;
-      const int c = (blockIdx.x * p.qpr + qq) * 4;
+      const int c = (colblk * p.qpr + qq) * 4;
       if (c >= p.wide) continue;
       if (j < 4 * NV) {
         if (j >= p.NS) continue;
@@ -306,7 +309,7 @@ __global__ __launch_bounds__(SW_THREADS) void skinny_wgrad_kernel(SkinnyWgradPar
     }
   }
   // ---- narrow column sums: thread q == 0 of every row group holds a partial
-  if (NSUM && blockIdx.x == 0) {
+  if (NSUM && colblk == 0) {
     __syncthreads();
     if (q == 0) {
 #pragma unroll
@@ -414,7 +417,9 @@ int ga_skinny_wgrad(const float* Wd, int64_t ldw, const int32_t* w_idx, const fl
   p.qpr = qpr; p.C = C; p.c_wide_stride = c_wide_stride;
   p.c_narrow_stride = c_narrow_stride; p.split_stride = split_stride;
   p.colsum_wide = colsum_wide; p.colsum_narrow = colsum_narrow;
-  dim3 grid((unsigned)ga_ceil_div(wide, 4 * qpr), (unsigned)n_splits);
+  p.n_colblk = (int)ga_ceil_div(wide, 4 * qpr);
+  p.n_splits = n_splits;
+  dim3 grid((unsigned)(p.n_colblk * p.n_splits));
   hipEvent_t e0 = nullptr, e1 = nullptr;
   const double bytes = 4.0 * rows * ((double)wide + NS);
   ga_prof_events(GA_PROF_SKINNY_WGRAD, bytes, &e0, &e1);

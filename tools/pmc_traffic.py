@@ -10,13 +10,19 @@ Bytes are averages per launch over every launch of a kernel name.
 import collections
 import csv
 import json
-import re
 import sys
 
 
 def short(name):
     name = name.replace('(anonymous namespace)::', '').replace('void ', '')
-    name = re.sub(r'\\(.*$', '', name)  # drop the parameter list
+    depth = 0
+    for i, ch in enumerate(name):  # drop the parameter list
+        if ch == '<':
+            depth += 1
+        elif ch == '>':
+            depth -= 1
+        elif ch == '(' and depth == 0:
+            return name[:i].strip()
     return name.strip()
 
 
