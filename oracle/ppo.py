@@ -143,6 +143,19 @@ class OraclePPO:
         new = self._dist(self.policy, obs)
         return torch.distributions.kl.kl_divergence(old, new).mean()
 
+    def _update_policy(self, obs_flat, actions_flat, adv_flat, used):
+        """``vpg.py:244-245`` + ``_train_policy`` (``:250-272``)."""
+        S = obs_flat.shape[0]
+        for ids in minibatch_index_stream(S, self.mb, self.epochs):
+            sel = slice(None) if ids is None else ids
+            self.policy_opt.zero_grad()
+            loss = self._policy_loss(obs_flat[sel], actions_flat[sel],
+                                     adv_flat[sel])
+            loss.backward()
+            self.policy_opt.step()
+            if used is not None and ids is not None:
+                used.append(ids)
+
     # -- one iteration -----------------------------------------------------
     def train_once(self, batch, record_minibatches=False):
         """``VPG._train_once`` on an :class:`oracle.batch.OracleEpisodeBatch`.
@@ -174,15 +187,8 @@ class OraclePPO:
         S = obs_flat.shape[0]
         used = {'policy': [], 'vf': []}
         # vpg.py:244-248 -- policy first, all epochs; then the value function.
-        for ids in minibatch_index_stream(S, self.mb, self.epochs):
-            sel = slice(None) if ids is None else ids
-            self.policy_opt.zero_grad()
-            loss = self._policy_loss(obs_flat[sel], actions_flat[sel],
-                                     adv_flat[sel])
-            loss.backward()
-            self.policy_opt.step()
-            if record_minibatches and ids is not None:
-                used['policy'].append(ids)
+        self._update_policy(obs_flat, actions_flat, adv_flat,
+                            used['policy'] if record_minibatches else None)
         for ids in minibatch_index_stream(S, self.mb, self.epochs):
             sel = slice(None) if ids is None else ids
             self.vf_opt.zero_grad()

@@ -420,6 +420,99 @@ def gen_train_once():
     save('train_once', **out)
 
 
+def gen_trpo():
+    """Section 8(f).1: ``_train_once`` through the real TRPO +
+    ConjugateGradientOptimizer (``torch/algos/trpo.py``,
+    ``torch/optimizers/conjugate_gradient_optimizer.py``), with the CG direction
+    and the descent step of every policy step recorded."""
+    from garage.torch.algos import TRPO
+    import garage.torch.optimizers.conjugate_gradient_optimizer as cgo
+    cases = [
+        dict(tag='trpo', kw={}, delta=0.01),
+        dict(tag='trpo_tight', kw={}, delta=1e-4),
+        dict(tag='trpo_reg', delta=0.01,
+             kw=dict(entropy_method='regularized', policy_ent_coeff=0.02)),
+        # one candidate only: the first iteration's full step violates the
+        # constraint and is rejected (parameters restored)
+        dict(tag='trpo_reject', kw={}, delta=0.01, opt=dict(max_backtracks=1)),
+    ]
+    out = {}
+    for case in cases:
+        tag = case['tag']
+        O, A, P, hs = 4, 2, 8, (8, 8)
+        E, mb = 2, 5
+        spec = EnvSpec(akro.Box(-np.inf, np.inf, (O, )),
+                       akro.Box(-np.inf, np.inf, (A, )),
+                       max_episode_length=P)
+        torch.manual_seed(13)
+        rng = np.random.RandomState(13)
+        pol = GaussianMLPPolicy(spec, hidden_sizes=hs)
+        vf = GaussianMLPValueFunction(spec, hidden_sizes=hs)
+        with torch.no_grad():
+            for p in list(pol.parameters()) + list(vf.parameters()):
+                p.add_(torch.randn_like(p) * 0.1)
+        out.update(state_arrays(tag + '_pol0:', pol))
+        out.update(state_arrays(tag + '_vf0:', vf))
+        algo = TRPO(env_spec=spec, policy=pol, value_function=vf, sampler=None,
+                    policy_optimizer=OptimizerWrapper(
+                        (cgo.ConjugateGradientOptimizer,
+                         dict(max_constraint_value=case['delta'],
+                              **case.get('opt', {}))), pol),
+                    vf_optimizer=OptimizerWrapper(
+                        (torch.optim.Adam, dict(lr=2.5e-4)), vf,
+                        max_optimization_epochs=E, minibatch_size=mb),
+                    **case['kw'])
+        rec = ref.TabularRecorder()
+        vpg_mod.tabular = rec
+        gfun.tabular = rec
+        trace = {}
+        real_cg = cgo._conjugate_gradient
+        real_ls = cgo.ConjugateGradientOptimizer._backtracking_line_search
+
+        def spy_cg(f_Ax, b, cg_iters, residual_tol=1e-10):
+            x = real_cg(f_Ax, b, cg_iters, residual_tol)
+            trace['grad'] = b.detach().numpy().copy()
+            trace['step_dir'] = x.detach().numpy().copy()
+            trace['Ax'] = f_Ax(x).detach().numpy().copy()
+            return x
+
+        def spy_ls(self, params, descent_step, f_loss, f_constraint):
+            trace['descent_step'] = descent_step.detach().numpy().copy()
+            return real_ls(self, params, descent_step, f_loss, f_constraint)
+
+        cgo._conjugate_gradient = spy_cg
+        cgo.ConjugateGradientOptimizer._backtracking_line_search = spy_ls
+        try:
+            for it in range(2):
+                lens = [8, 3, 5, 8, 1, 6, 8, 7] if it == 0 else [2, 8, 7, 4, 8]
+                eps = make_ragged_batch(rng, spec, lens, O, A)
+                np.random.seed(200 + it)
+                avg_ret = algo._train_once(it, eps)
+                pre = '%s_it%d_' % (tag, it)
+                out[pre + 'observations'] = eps.observations
+                out[pre + 'actions'] = eps.actions
+                out[pre + 'rewards'] = eps.rewards
+                out[pre + 'lengths'] = eps.lengths
+                out[pre + 'step_types'] = np.asarray(
+                    [int(s) for s in eps.step_types])
+                out[pre + 'np_seed'] = np.asarray(200 + it)
+                out[pre + 'avg_return'] = np.asarray(avg_ret)
+                for k, v in rec.values.items():
+                    out[pre + 'log:' + k] = np.asarray(v)
+                for k, v in trace.items():
+                    out[pre + 'cg:' + k] = v
+                out.update(state_arrays(pre + 'pol:', pol))
+                out.update(state_arrays(pre + 'vf:', vf))
+        finally:
+            cgo._conjugate_gradient = real_cg
+            cgo.ConjugateGradientOptimizer._backtracking_line_search = real_ls
+        out[tag + '_cfg'] = np.asarray([O, A, P, E, mb])
+        out[tag + '_delta'] = np.asarray(case['delta'])
+        out[tag + '_max_backtracks'] = np.asarray(
+            case.get('opt', {}).get('max_backtracks', 15))
+    save('trpo_train_once', **out)
+
+
 def gen_compute_advantage():
     """Item 3: centre / positive variants incl. the single-sample edge."""
     out = {}
@@ -498,6 +591,11 @@ def gen_log_performance():
 
 if __name__ == '__main__':
     print('reference:', garage.__file__)
+    if len(sys.argv) > 1:  # regenerate selected fixtures only, e.g. `trpo`
+        for name in sys.argv[1:]:
+            globals()['gen_' + name]()
+        sys.exit(0)
+    gen_trpo()
     gen_returns()
     gen_advantages()
     gen_padding_and_steptypes()

@@ -405,3 +405,62 @@ def test_golden_log_performance(golden):
         assert np.allclose(und, g[tag + '_undiscounted'])
         for k, v in stats.items():
             assert np.isclose(v, float(g[tag + ':Evaluation/' + k])), k
+
+
+TRPO_CASES = {
+    'trpo': {},
+    'trpo_tight': {},
+    'trpo_reg': dict(entropy_method='regularized', policy_ent_coeff=0.02),
+    'trpo_reject': {},
+}
+
+
+@pytest.mark.parametrize('tag', sorted(TRPO_CASES))
+def test_golden_trpo_train_once(golden, tag):
+    """Two real TRPO ``_train_once`` iterations: CG
+    direction, descent step, accepted step and post-step parameters."""
+    from oracle.trpo import OracleTRPO
+    g = golden('trpo_train_once')
+    O, A, P, E, mb = [int(v) for v in g[tag + '_cfg']]
+    algo = OracleTRPO(_params(g, tag + '_pol0:'), _params(g, tag + '_vf0:'),
+                      max_episode_length=P,
+                      max_constraint_value=float(g[tag + '_delta']),
+                      max_backtracks=int(g[tag + '_max_backtracks']),
+                      max_optimization_epochs=E, minibatch_size=mb,
+                      **TRPO_CASES[tag])
+    for it in range(2):
+        pre = '%s_it%d_' % (tag, it)
+        lens = g[pre + 'lengths']
+        b = ob.OracleEpisodeBatch(
+            observations=g[pre + 'observations'],
+            last_observations=np.zeros((len(lens), O), np.float32),
+            actions=g[pre + 'actions'], rewards=g[pre + 'rewards'],
+            step_types=g[pre + 'step_types'], lengths=lens,
+            max_episode_length=P)
+        np.random.seed(int(g[pre + 'np_seed']))
+        out = algo.train_once(b)
+        tr = algo.cg.trace
+        # (the second iteration starts from parameters that already carry the
+        # first step's CG rounding, ~1e-5)
+        assert np.allclose(tr['grad'], g[pre + 'cg:grad'],
+                           atol=1e-6 if it == 0 else 5e-5)
+        scale = np.abs(g[pre + 'cg:step_dir']).max()
+        assert np.allclose(tr['step_dir'], g[pre + 'cg:step_dir'],
+                           atol=(1e-4 if it == 0 else 2e-3) * scale)
+        # ten fp32 CG iterations amplify last-ulp differences of the gradient
+        # to ~1e-4 of the direction: the tolerance the reference itself has
+        dscale = np.abs(g[pre + 'cg:descent_step']).max()
+        assert np.allclose(tr['descent_step'], g[pre + 'cg:descent_step'],
+                           atol=(5e-4 if it == 0 else 2e-3) * dscale)
+        for mine, theirs in LOG_KEYS.items():
+            assert np.isclose(out[mine], float(g[pre + 'log:' + theirs]),
+                              atol=1e-5 if it == 0 else 1e-4,
+                              rtol=1e-4), (mine, it)
+        pol, vf = algo.state()
+        for k, v in pol.items():
+            assert np.allclose(v, g[pre + 'pol:' + k],
+                               atol=(5e-4 if it == 0 else 2e-3) * dscale), k
+        for k, v in vf.items():
+            assert np.allclose(v, g[pre + 'vf:' + k], atol=1e-6), k
+    if tag == 'trpo_reject':
+        assert algo.cg.trace['accepted'] in (-1, 0)
