@@ -87,6 +87,13 @@ SIGNATURES = {
     'ga_mlp_backward_f32': (c_int, [C.POINTER(MlpDesc), ptr, ptr, c_i64, ptr,
                                     c_i64, ptr, ptr, c_i64, ptr, ptr, c_i64,
                                     c_i64, ptr]),
+    'ga_mlp_jvp_f32': (c_int, [C.POINTER(MlpDesc), ptr, ptr, ptr, c_i64, ptr,
+                               c_i64, ptr, ptr, ptr, c_i64, ptr]),
+    'ga_dot_f32': (c_int, [ptr, ptr, c_i64, ptr, ptr]),
+    'ga_axpby_f32': (c_int, [c_f64, ptr, c_f64, ptr, c_i64, ptr]),
+    'ga_fisher_seed_gaussian_f32': (c_int, [ptr, c_i64, c_i64, c_int, ptr, c_int,
+                                            c_f32, c_int, c_f32, ptr, c_i64,
+                                            ptr]),
     'ga_gemm_nt_f32': (c_int, [ptr, c_i64, ptr, c_i64, ptr, c_i64, c_i64,
                                c_i64, c_i64, ptr]),
     'ga_reduction_workspace_doubles': (c_i64, []),

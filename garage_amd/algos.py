@@ -713,4 +713,226 @@ class PPO(VPG):
         self._algo_id = 0  # clipped surrogate in the loss kernel
 
 
-__all__ = ['VPG', 'PPO']
+class TRPO(VPG):
+    """Trust Region Policy Optimization (``torch/algos/trpo.py:9-144``).
+
+    The policy step is garage's ``ConjugateGradientOptimizer``
+    (``torch/optimizers/conjugate_gradient_optimizer.py``) on the device:
+    gradient of the unclipped surrogate, 10 conjugate-gradient iterations on the
+    KL constraint's Hessian, the step size ``sqrt(2 delta / s^T A s)`` and the
+    backtracking line search.  The reference takes Hessian-vector products by
+    double backward; here ``A v = J^T M (J v) + reg v`` with ``J v`` a tangent
+    forward pass (``ga_mlp_jvp_f32``), ``M`` the Gaussian metric
+    (``ga_fisher_seed_gaussian_f32``) and ``J^T`` the ordinary backward pass --
+    the same matrix, because the step starts at the old policy's parameters,
+    where the KL's gradient with respect to the distribution vanishes and its
+    Hessian is the Fisher matrix.
+    """
+
+    def __init__(self,
+                 env_spec,
+                 policy,
+                 value_function,
+                 sampler,
+                 policy_optimizer=None,
+                 vf_optimizer=None,
+                 num_train_per_epoch=1,
+                 discount=0.99,
+                 gae_lambda=0.98,
+                 center_adv=True,
+                 positive_adv=False,
+                 policy_ent_coeff=0.0,
+                 use_softplus_entropy=False,
+                 stop_entropy_gradient=False,
+                 entropy_method='no_entropy'):
+        from garage_amd.optimizers import ConjugateGradientOptimizer
+        if policy_optimizer is None:
+            policy_optimizer = OptimizerWrapper(
+                (ConjugateGradientOptimizer, dict(max_constraint_value=0.01)),
+                policy)
+        if vf_optimizer is None:
+            vf_optimizer = OptimizerWrapper(
+                (torch.optim.Adam, dict(lr=2.5e-4)), value_function,
+                max_optimization_epochs=10, minibatch_size=64)
+        super().__init__(env_spec=env_spec, policy=policy,
+                         value_function=value_function, sampler=sampler,
+                         policy_optimizer=policy_optimizer,
+                         vf_optimizer=vf_optimizer,
+                         num_train_per_epoch=num_train_per_epoch,
+                         discount=discount, gae_lambda=gae_lambda,
+                         center_adv=center_adv, positive_adv=positive_adv,
+                         policy_ent_coeff=policy_ent_coeff,
+                         use_softplus_entropy=use_softplus_entropy,
+                         stop_entropy_gradient=stop_entropy_gradient,
+                         entropy_method=entropy_method)
+        if policy.kind != 'gaussian':
+            raise NotImplementedError(
+                'garage_amd.algos.TRPO implements the Gaussian MLP policy')
+        hyper = self._policy_optimizer._hyper
+        if hyper.get('kind') != 'cg':
+            raise NotImplementedError(
+                'TRPO needs OptimizerWrapper((ConjugateGradientOptimizer, '
+                '{...}), policy)')
+        if (self._policy_optimizer._minibatch_size is not None
+                or self._policy_optimizer._max_optimization_epochs != 1):
+            # later steps would start away from the old policy, where the KL
+            # Hessian is no longer the Fisher matrix this class multiplies by
+            raise NotImplementedError(
+                'TRPO takes one full-batch policy step per iteration '
+                '(trpo.py:64-66 default wrapper)')
+        self._algo_id = 2  # unclipped surrogate in the loss kernel
+        self.last_cg = {}
+
+    # -- update (vpg.py:230-248 with the constrained policy step) ---------------
+    def _train(self, batch, adv, returns, old_ll):
+        import ctypes as C
+        S = batch.n_samples
+        self._train_policy(batch, adv, old_ll, None)
+        opt, vf = self._vf_optimizer, self._value_function
+        native = (type(self)._train_value_function
+                  is VPG._train_value_function
+                  and (opt.grad_hook is None
+                       or getattr(opt, 'native_comm', None) is not None))
+        if not native:
+            for idx in opt.minibatch_indices(S):
+                self._train_value_function(batch, returns, idx)
+            return
+        a, keep, n_mb = self._update_args(opt, vf, 1, batch, adv, returns,
+                                          old_ll, 0)
+        for perm in opt.epoch_permutations(S):
+            a.perm = None if perm is None else perm.data_ptr()
+            a.step0 = vf.net.adam_steps
+            call('ga_update_epoch', C.byref(a), stream_ptr())
+            vf.net.adam_steps += n_mb
+        del keep
+
+    def _dot(self, a, b):
+        """Host float of ``a . b`` (fp64 accumulation on the device)."""
+        out = torch.empty(1, dtype=torch.float64, device=a.device)
+        call('ga_dot_f32', dptr(a), dptr(b), a.numel(), dptr(out),
+             stream_ptr())
+        return float(out.item())
+
+    def _fisher_vector_product(self, batch, M, vec, out):
+        """``out = A vec``: Hessian of ``mean KL(old || new)`` at new == old,
+        plus ``hvp_reg_coeff * vec`` (conjugate_gradient_optimizer.py:18-66)."""
+        pol = self.policy
+        net = pol.net
+        hyper = self._policy_optimizer._hyper
+        tout = net.jvp(batch.obs_dev, M, vec)
+        dout = net.dout_view(M)
+        has_min, mn, has_max, mx = pol._std_args()
+        call('ga_fisher_seed_gaussian_f32', dptr(tout), tout.stride(0), M,
+             net.out_dim, dptr(net.params[0:1]), has_min, mn, has_max, mx,
+             dptr(dout), dout.stride(0), stream_ptr())
+        net.backward(batch.obs_dev, M, dout)
+        net.reduce_grads()
+        g = net.grads
+        # the log-std block: d2/ds2 of sum_a [s - s_old + exp(2(s_old - s))/2]
+        # = 2 A at s == s_old, through the clamp's pass-through gradient
+        s_raw = float(net.params[0].item())
+        live = getattr(pol, '_learn_std', True)
+        if has_min and s_raw < mn:
+            live = False
+        if has_max and s_raw > mx:
+            live = False
+        g[0:1].copy_(vec[0:1] * (2.0 * net.out_dim if live else 0.0))
+        out.copy_(g)
+        call('ga_axpby_f32', float(hyper['hvp_reg_coeff']), dptr(vec), 1.0,
+             dptr(out), out.numel(), stream_ptr())
+        return out
+
+    def _train_policy(self, batch, adv, old_ll, idx):
+        """``trpo.py:121-144`` + ``ConjugateGradientOptimizer.step``
+        (``conjugate_gradient_optimizer.py:146-186,236-277``)."""
+        assert idx is None
+        if self._comm is not None:
+            raise NotImplementedError(
+                'TRPO is single-GPU in this round (the conjugate-gradient '
+                'vectors would need one all-reduce per Fisher product)')
+        pol = self.policy
+        net = pol.net
+        hyper = self._policy_optimizer._hyper
+        M = batch.n_samples
+        dev = net.device
+        n = net.n_flat
+        # gradient of the surrogate loss (flat_loss_grads)
+        loss0, mean_old, dout = self._policy_loss_pass(batch, adv, old_ll, M,
+                                                       None, want_grad=True)
+        mean_old = mean_old.clone()
+        s_old = pol.clamped_log_std()
+        net.backward(batch.obs_dev, M, dout)
+        net.reduce_grads()
+        if not getattr(pol, '_learn_std', True):
+            net.grads[0:1].zero_()
+        b = net.grads.clone()
+
+        # conjugate gradient (Demmel p. 312), conjugate_gradient_optimizer.py:69-104
+        x = torch.zeros(n, dtype=torch.float32, device=dev)
+        r = b.clone()
+        p = b.clone()
+        z = torch.empty(n, dtype=torch.float32, device=dev)
+        rdotr = self._dot(r, r)
+        for _ in range(int(hyper['cg_iters'])):
+            self._fisher_vector_product(batch, M, p, z)
+            v = rdotr / self._dot(p, z)
+            call('ga_axpby_f32', v, dptr(p), 1.0, dptr(x), n, stream_ptr())
+            call('ga_axpby_f32', -v, dptr(z), 1.0, dptr(r), n, stream_ptr())
+            newrdotr = self._dot(r, r)
+            mu = newrdotr / rdotr
+            call('ga_axpby_f32', 1.0, dptr(r), mu, dptr(p), n, stream_ptr())
+            rdotr = newrdotr
+            if rdotr < 1e-10:
+                break
+        x = torch.nan_to_num(x, nan=0.0, posinf=float('inf'),
+                             neginf=float('-inf'))
+        self._fisher_vector_product(batch, M, x, z)
+        sAs = self._dot(x, z)
+        with np.errstate(all='ignore'):
+            step_size = float(np.sqrt(2.0 * hyper['max_constraint_value'] *
+                                      (1. / (sAs + 1e-8))))
+        if math.isnan(step_size):
+            step_size = 1.
+        descent = x * step_size
+        self.last_cg = dict(grad=b, step_dir=x, descent_step=descent)
+
+        # backtracking line search, conjugate_gradient_optimizer.py:236-277
+        prev = net.params.clone()
+        loss_before = float(loss0.item())
+        accepted = -1
+        loss = constraint = float('nan')
+        for k in range(int(hyper['max_backtracks'])):
+            ratio = float(hyper['backtrack_ratio'])**k
+            net.params.copy_(prev)
+            call('ga_axpby_f32', -ratio, dptr(descent), 1.0,
+                 dptr(net.params), n, stream_ptr())
+            l_new, mean_new, _ = self._policy_loss_pass(batch, adv, old_ll, M,
+                                                        None)
+            loss = float(l_new.item())
+            kl = self._kl_sum(mean_old, s_old, mean_new,
+                              pol.clamped_log_std(), M)
+            constraint = float(kl.item()) / float(M)
+            if (loss < loss_before
+                    and constraint <= hyper['max_constraint_value']):
+                accepted = k
+                break
+        if ((math.isnan(loss) or math.isnan(constraint)
+             or loss >= loss_before
+             or constraint >= hyper['max_constraint_value'])
+                and not hyper['accept_violation']):
+            logger.log('Line search condition violated. Rejecting the step!')
+            if math.isnan(loss):
+                logger.log('Violated because loss is NaN')
+            if math.isnan(constraint):
+                logger.log('Violated because constraint is NaN')
+            if loss >= loss_before:
+                logger.log('Violated because loss not improving')
+            if constraint >= hyper['max_constraint_value']:
+                logger.log('Violated because constraint is violated')
+            net.params.copy_(prev)
+            accepted = -1
+        self.last_cg['accepted'] = accepted
+        return loss0
+
+
+__all__ = ['VPG', 'PPO', 'TRPO']

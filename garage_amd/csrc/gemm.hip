@@ -62,8 +62,9 @@ struct GemmParams {
   int epi;
   const float* bias;     // EPI_BIAS_ACT: per-n bias (may be null)
   int act;               // 0 identity, 1 tanh
-  const float* H;        // EPI_MUL_DTANH: tanh outputs, H[m * ldh + n]
-  int64_t ldh;
+  const float* H;        // EPI_MUL_DTANH (or EPI_BIAS_ACT with H set): tanh
+  int64_t ldh;           // outputs H[m * ldh + n]; the result is scaled by 1 - H^2
+  int accum;             // 1: add the product to what C already holds
   int k_per_split;       // multiple of BK
   int64_t c_split_stride;
   float* colsum;         // optional: sum_k of operand A (or B) -> colsum[line]
@@ -344,9 +345,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_f32_kernel(
         const int m = m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (m >= p.M) continue;
         float v = acc[i][j][r];
+        if (p.accum) v += Cout[(int64_t)m * p.c_rs + (int64_t)n * p.c_cs];
         if (p.epi == EPI_BIAS_ACT) {
           v += bias;
           if (p.act == 1) v = tanh_fast(v);
+          if (p.H) {
+            const float h = p.H[(int64_t)m * p.ldh + n];
+            v *= (1.f - h * h);
+          }
         } else if (p.epi == EPI_MUL_DTANH) {
           const float h = p.H[(int64_t)m * p.ldh + n];
           v *= (1.f - h * h);
@@ -621,6 +627,70 @@ extern "C" int ga_mlp_backward_f32(const ga_mlp_desc* d, const float* params,
         rc = launch_gemm<true, false>(p, 1, stream);
         if (rc) return rc;
       }
+    }
+  }
+  return GA_OK;
+}
+
+// Tangent (forward-mode) pass: with dtheta = `tangent` (flat parameter layout) and
+// the activations of a forward at the same rows in `acts`,
+//   tz_l = in_l dW_l^T + db_l + tin_l W_l^T,   th_l = tz_l * (1 - h_l^2)
+// (in_0 = X, tin_0 = 0); `tout` receives d(output).  This is the J v half of the
+// Fisher-vector product the TRPO policy step solves with
+// (torch/optimizers/conjugate_gradient_optimizer.py:18-66 takes the same product
+// by double backward through the KL constraint).
+extern "C" int ga_mlp_jvp_f32(const ga_mlp_desc* d, const float* params,
+                              const float* tangent, const float* X, int64_t ldx,
+                              const int32_t* row_idx, int64_t M, const float* acts,
+                              float* tacts, float* tout, int64_t ldo,
+                              hipStream_t stream) {
+  int rc = check_desc(d, "ga_mlp_jvp_f32");
+  if (rc) return rc;
+  GA_REQUIRE(params && tangent && X && tout, "ga_mlp_jvp_f32: null pointer");
+  GA_REQUIRE(d->n_layers == 1 || (acts && tacts), "ga_mlp_jvp_f32: workspaces needed");
+  GA_REQUIRE(M > 0 && M < (1ll << 31), "ga_mlp_jvp_f32: bad M");
+  GA_REQUIRE(ldx % 4 == 0 && ldx >= d->dims[0] && ldo >= d->dims[d->n_layers],
+             "ga_mlp_jvp_f32: leading dimensions");
+  GA_REQUIRE(ga_aligned16(params) && ga_aligned16(tangent) && ga_aligned16(X) &&
+                 (!acts || ga_aligned16(acts)) && (!tacts || ga_aligned16(tacts)),
+             "ga_mlp_jvp_f32: pointers must be 16-B aligned");
+  const int L = d->n_layers;
+  for (int l = 0; l < L; ++l) {
+    const bool last = (l == L - 1);
+    const int in_w = d->dims[l], out_w = d->dims[l + 1];
+    float* C = last ? tout : tacts + d->act_off[l];
+    const int64_t ldc = last ? ldo : round4(out_w);
+    const float* H = last ? nullptr : acts + d->act_off[l];
+    // in_l dW_l^T + db_l  (and the tanh' factor when it is the only product)
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    if (l == 0) {
+      p.A = X; p.lda = ldx; p.a_idx = row_idx;
+    } else {
+      p.A = acts + d->act_off[l - 1]; p.lda = round4(in_w);
+    }
+    p.B = tangent + d->w_off[l]; p.ldb = round4(in_w);
+    p.C = C; p.c_rs = ldc; p.c_cs = 1;
+    p.M = (int)M; p.N = out_w; p.K = in_w;
+    p.epi = EPI_BIAS_ACT; p.bias = tangent + d->b_off[l]; p.act = 0;
+    if (l == 0) { p.H = H; p.ldh = ldc; }
+    p.k_per_split = (int)ga_ceil_div(p.K, BK) * BK;
+    rc = launch_gemm<true, true>(p, 1, stream);
+    if (rc) return rc;
+    if (l > 0) {
+      // += tin_l W_l^T, then the tanh' factor
+      GemmParams q;
+      memset(&q, 0, sizeof(q));
+      q.A = tacts + d->act_off[l - 1]; q.lda = round4(in_w);
+      q.B = params + d->w_off[l]; q.ldb = round4(in_w);
+      q.C = C; q.c_rs = ldc; q.c_cs = 1;
+      q.M = (int)M; q.N = out_w; q.K = in_w;
+      q.accum = 1;
+      if (H) { q.epi = EPI_MUL_DTANH; q.H = H; q.ldh = ldc; }
+      else q.epi = EPI_PLAIN;
+      q.k_per_split = (int)ga_ceil_div(q.K, BK) * BK;
+      rc = launch_gemm<true, true>(q, 1, stream);
+      if (rc) return rc;
     }
   }
   return GA_OK;

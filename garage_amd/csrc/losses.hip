@@ -44,7 +44,8 @@ struct PpoLossParams {
   int has_max;
   int64_t M;
   int A;
-  int algo;               // 0 PPO clipped surrogate, 1 VPG (ll * adv)
+  int algo;               // 0 PPO clipped surrogate, 1 VPG (ll * adv),
+                          // 2 TRPO unclipped surrogate (ratio * adv)
   float clip;
   float ent_coeff;        // added to the objective when ent_regularized
   int ent_regularized, ent_softplus, ent_stop_grad;
@@ -83,6 +84,11 @@ __global__ __launch_bounds__(256) void ppo_gaussian_loss_kernel(PpoLossParams p)
     if (p.algo == 1) {
       obj = ll * adv;
       g = adv;
+    } else if (p.algo == 2) {
+      // torch/algos/trpo.py:113-117: likelihood ratio times advantage
+      const float ratio = expf(ll - p.old_ll[src]);
+      obj = ratio * adv;
+      g = obj;
     } else {
       const float ratio = expf(ll - p.old_ll[src]);
       const float lo = 1.f - p.clip, hi = 1.f + p.clip;
@@ -241,6 +247,11 @@ __global__ __launch_bounds__(256) void ppo_categorical_loss_kernel(CatLossParams
     if (p.algo == 1) {
       obj = ll * adv;
       g = adv;
+    } else if (p.algo == 2) {
+      // torch/algos/trpo.py:113-117: likelihood ratio times advantage
+      const float ratio = expf(ll - p.old_ll[src]);
+      obj = ratio * adv;
+      g = obj;
     } else {
       const float ratio = expf(ll - p.old_ll[src]);
       const float lo = 1.f - p.clip, hi = 1.f + p.clip;
@@ -861,5 +872,84 @@ extern "C" int ga_sub_scalar_f32(float* x, int64_t n, const double* scalar,
   hipLaunchKernelGGL(sub_scalar_kernel, dim3(red_blocks(n)), dim3(256), 0, stream, x,
                      n, scalar);
   GA_CHECK_LAUNCH("sub_scalar");
+  return GA_OK;
+}
+
+// ---- vector ops of the constrained (TRPO) policy step ------------------------------
+// torch/optimizers/conjugate_gradient_optimizer.py:69-104,146-186 works on the flat
+// parameter vector (~72 k floats at C3): dot products and axpy-type updates.
+namespace {
+
+// one workgroup, fp64 accumulation in a fixed order: bitwise reproducible
+__global__ __launch_bounds__(1024) void dot_kernel(const float* a, const float* b,
+                                                   int64_t n, double* out) {
+  __shared__ double part[16];
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) s += (double)a[i] * (double)b[i];
+  s = ga_wave_sum(s);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < 16; ++w) t += part[w];
+    *out = t;
+  }
+}
+
+// y = alpha * x + beta * y  (fp32, one fma rounding like torch's addcmul-free form)
+__global__ __launch_bounds__(256) void axpby_kernel(float alpha, const float* x,
+                                                    float beta, float* y, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) y[i] = alpha * x[i] + beta * y[i];
+}
+
+// Gaussian metric seed of the Fisher-vector product: with old == new, the Hessian
+// of mean_i KL(old || new) with respect to the means is 1 / (sigma^2 M)
+// (kl_normal_normal: 0.5 ((mu_o - mu)^2 / sigma^2 + ...)), so
+//   dout[i, j] = tmean[i, j] * exp(-2 s) / M.
+__global__ __launch_bounds__(256) void fisher_seed_kernel(
+    const float* tmean, int64_t ldt, int64_t M, int A, const float* log_std,
+    int has_min, float min_log_std, int has_max, float max_log_std, float* dout,
+    int64_t ldd) {
+  float s = *log_std;
+  if (has_min && s < min_log_std) s = min_log_std;
+  if (has_max && s > max_log_std) s = max_log_std;
+  const float scale = expf(-2.f * s) / (float)M;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= M) return;
+  for (int j = 0; j < (int)ldd; ++j)
+    dout[i * ldd + j] = (j < A) ? tmean[i * ldt + j] * scale : 0.f;
+}
+
+}  // namespace
+
+extern "C" int ga_dot_f32(const float* a, const float* b, int64_t n, double* out,
+                          hipStream_t stream) {
+  GA_REQUIRE(a && b && out && n > 0, "ga_dot_f32: bad arguments");
+  hipLaunchKernelGGL(dot_kernel, dim3(1), dim3(1024), 0, stream, a, b, n, out);
+  GA_CHECK_LAUNCH("dot");
+  return GA_OK;
+}
+
+extern "C" int ga_axpby_f32(double alpha, const float* x, double beta, float* y,
+                            int64_t n, hipStream_t stream) {
+  GA_REQUIRE(x && y && n > 0, "ga_axpby_f32: bad arguments");
+  hipLaunchKernelGGL(axpby_kernel, dim3((unsigned)ga_ceil_div(n, 256)), dim3(256), 0,
+                     stream, (float)alpha, x, (float)beta, y, n);
+  GA_CHECK_LAUNCH("axpby");
+  return GA_OK;
+}
+
+extern "C" int ga_fisher_seed_gaussian_f32(const float* tmean, int64_t ldt, int64_t M,
+                                           int A, const float* log_std, int has_min,
+                                           float min_log_std, int has_max,
+                                           float max_log_std, float* dout, int64_t ldd,
+                                           hipStream_t stream) {
+  GA_REQUIRE(tmean && log_std && dout && M > 0 && A > 0 && ldt >= A && ldd >= A,
+             "ga_fisher_seed_gaussian_f32: bad arguments");
+  hipLaunchKernelGGL(fisher_seed_kernel, dim3((unsigned)ga_ceil_div(M, 256)), dim3(256),
+                     0, stream, tmean, ldt, M, A, log_std, has_min, min_log_std,
+                     has_max, max_log_std, dout, ldd);
+  GA_CHECK_LAUNCH("fisher_seed");
   return GA_OK;
 }

@@ -168,6 +168,21 @@ class FlatMLP:
         self._used_splits = splits
         return splits
 
+    def jvp(self, X, M, tangent, row_idx=None):
+        """``d(output)[M, ld_out]`` for the parameter tangent ``tangent`` (flat
+        layout); needs the activations of a ``forward`` at the same rows."""
+        self._workspace(M)
+        if getattr(self, '_tout', None) is None or \
+                self._tout.numel() < M * self.ld_out:
+            self._tout = torch.zeros(self._cap * self.ld_out,
+                                     dtype=torch.float32, device=self.device)
+        tout = self._tout[:M * self.ld_out].view(M, self.ld_out)
+        call('ga_mlp_jvp_f32', C.byref(self._desc), dptr(self.params),
+             dptr(tangent), dptr(X), X.stride(0), dptr(row_idx), M,
+             dptr(self._acts), dptr(self._dacts), dptr(tout), tout.stride(0),
+             stream_ptr())
+        return tout
+
     def reduce_grads(self, scale=1.0):
         call('ga_reduce_slabs_f32', dptr(self._slabs), self._used_splits,
              self.n_flat, self.n_flat, float(scale), dptr(self.grads),

@@ -11,6 +11,30 @@ import torch
 from garage_amd._lib import call, dptr, stream_ptr
 
 
+class ConjugateGradientOptimizer:
+    """Hyper-parameters of garage's constrained optimizer
+    (``torch/optimizers/conjugate_gradient_optimizer.py:107-145``).
+
+    ``OptimizerWrapper((ConjugateGradientOptimizer,
+    dict(max_constraint_value=0.01)), policy)`` selects the conjugate-gradient /
+    backtracking policy step that :class:`garage_amd.algos.TRPO` runs on the
+    device; this class only carries the settings (same names and defaults).
+    """
+
+    def __init__(self, params=None, max_constraint_value=None, cg_iters=10,
+                 max_backtracks=15, backtrack_ratio=0.8, hvp_reg_coeff=1e-5,
+                 accept_violation=False):
+        del params
+        if max_constraint_value is None:
+            raise TypeError("__init__() missing 1 required positional "
+                            "argument: 'max_constraint_value'")
+        self.state = dict(max_constraint_value=max_constraint_value,
+                          cg_iters=cg_iters, max_backtracks=max_backtracks,
+                          backtrack_ratio=backtrack_ratio,
+                          hvp_reg_coeff=hvp_reg_coeff,
+                          accept_violation=accept_violation)
+
+
 def _parse_optimizer(optimizer):
     """``make_optimizer``: a type, or ``(type, kwargs)``."""
     kwargs = {}
@@ -20,13 +44,17 @@ def _parse_optimizer(optimizer):
     else:
         opt_type = optimizer
     name = getattr(opt_type, '__name__', str(opt_type))
+    if name == 'ConjugateGradientOptimizer':
+        hyper = ConjugateGradientOptimizer(**kwargs).state
+        hyper['kind'] = 'cg'
+        return hyper
     if name != 'Adam':
         raise NotImplementedError(
             'garage_amd fuses torch.optim.Adam; got {}'.format(name))
     if kwargs.get('weight_decay', 0) or kwargs.get('amsgrad', False):
         raise NotImplementedError('weight_decay / amsgrad are not supported')
-    return dict(lr=kwargs.get('lr', 1e-3), betas=kwargs.get('betas',
-                                                            (0.9, 0.999)),
+    return dict(kind='adam', lr=kwargs.get('lr', 1e-3),
+                betas=kwargs.get('betas', (0.9, 0.999)),
                 eps=kwargs.get('eps', 1e-8))
 
 
@@ -142,6 +170,9 @@ class OptimizerWrapper:
     def step(self, **closure):
         """Reduce the gradient slabs, (all-reduce,) Adam."""
         del closure
+        if self._hyper['kind'] != 'adam':
+            raise NotImplementedError(
+                'the conjugate-gradient step is driven by garage_amd.algos.TRPO')
         self.net.reduce_grads(scale=self.dp_grad_scale
                               if self.grad_hook is not None else 1.0)
         if not getattr(self._module, '_learn_std', True):

@@ -84,6 +84,14 @@ int ga_set_fused_forward(int on);
  * gradient, first-layer / head weight gradients) run as HBM-streaming kernels
  * instead of MFMA tiles (default on; 0 = MFMA tiles everywhere, for A/B runs). */
 int ga_set_skinny_kernels(int on);
+/* Forward-mode tangent of the MLP (torch/optimizers/conjugate_gradient_optimizer.py
+ * :18-66 takes the same product by double backward): with dtheta = tangent (flat
+ * parameter layout) and acts = the hidden activations of a forward at the same
+ * rows, tout[M, ldo] = d(output); tacts is a workspace shaped like acts. */
+int ga_mlp_jvp_f32(const ga_mlp_desc* d, const float* params, const float* tangent,
+                   const float* X, int64_t ldx, const int32_t* row_idx, int64_t M,
+                   const float* acts, float* tacts, float* tout, int64_t ldo,
+                   ga_stream_t stream);
 /* split count ga_mlp_backward_f32 should be called with for M rows */
 int64_t ga_mlp_backward_splits(const ga_mlp_desc* d, int64_t M);
 /* dout = dLoss/d(out).  Writes n_splits partial gradient slabs, each laid out
@@ -166,6 +174,19 @@ int ga_adam_step_f32(float* params, const float* grads, float* exp_avg,
 /* ---- advantage centring: VPG._compute_advantage (vpg.py:371-377)
  * stats = device double[4]: sum, count, sum of squared deviations, min.
  * what: 0 -> stats[0..1], 1 -> stats[2] (uses the mean in stats), 2 -> stats[3]. */
+/* ---- constrained (TRPO) policy step: vectors of n_flat floats -----------------
+ * conjugate_gradient_optimizer.py:69-104,146-186.  ga_dot_f32: *out (device
+ * double) = sum a[i] b[i], fp64 accumulation, fixed order.  ga_axpby_f32:
+ * y = alpha x + beta y.  ga_fisher_seed_gaussian_f32: dout = tmean exp(-2 s) / M,
+ * the Gaussian-mean block of the KL Hessian at old == new (s = clamped log-std). */
+int ga_dot_f32(const float* a, const float* b, int64_t n, double* out,
+               ga_stream_t stream);
+int ga_axpby_f32(double alpha, const float* x, double beta, float* y, int64_t n,
+                 ga_stream_t stream);
+int ga_fisher_seed_gaussian_f32(const float* tmean, int64_t ldt, int64_t M, int A,
+                                const float* log_std, int has_min, float min_log_std,
+                                int has_max, float max_log_std, float* dout,
+                                int64_t ldd, ga_stream_t stream);
 int ga_stats_f32(const float* x, int64_t n, int what, double* stats,
                  double* workspace, ga_stream_t stream);
 int ga_adv_center_f32(float* x, int64_t n, const double* stats, float eps,

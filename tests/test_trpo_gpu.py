@@ -1,0 +1,213 @@
+"""TRPO on the GPU: the constrained policy step against
+goldens of the real ``garage.torch.algos.TRPO`` + ``ConjugateGradientOptimizer``
+and against the oracle on a larger batch."""
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+from test_ppo_gpu import LOG_KEYS, _host_batch, _sd, _spec
+
+pytestmark = pytest.mark.gpu
+
+TRPO_CASES = {
+    'trpo': {},
+    'trpo_tight': {},
+    'trpo_reg': dict(entropy_method='regularized', policy_ent_coeff=0.02),
+    'trpo_reject': {},
+}
+
+
+def _flat_no_pad(net, buf):
+    """Flat vector in the reference's ``parameters()`` order (no padding)."""
+    return np.concatenate([v.detach().cpu().numpy().reshape(-1)
+                           for _, v in net.named_views(buf)])
+
+
+def _make(g, tag, O, A, P, E, mb, **kw):
+    from garage_amd.algos import TRPO
+    from garage_amd.optimizers import (ConjugateGradientOptimizer,
+                                       OptimizerWrapper)
+    from garage_amd.policies import GaussianMLPPolicy, GaussianMLPValueFunction
+    spec = _spec(O, A, P)
+    pol = GaussianMLPPolicy(spec, hidden_sizes=(8, 8))
+    vf = GaussianMLPValueFunction(spec, hidden_sizes=(8, 8))
+    pol.load_state_dict(_sd(g, tag + '_pol0:'))
+    vf.load_state_dict(_sd(g, tag + '_vf0:'))
+    algo = TRPO(env_spec=spec, policy=pol, value_function=vf, sampler=None,
+                policy_optimizer=OptimizerWrapper(
+                    (ConjugateGradientOptimizer,
+                     dict(max_constraint_value=float(g[tag + '_delta']),
+                          max_backtracks=int(g[tag + '_max_backtracks']))),
+                    pol),
+                vf_optimizer=OptimizerWrapper(
+                    (torch.optim.Adam, dict(lr=2.5e-4)), vf,
+                    max_optimization_epochs=E, minibatch_size=mb),
+                **kw)
+    return spec, pol, vf, algo
+
+
+@pytest.mark.parametrize('tag', sorted(TRPO_CASES))
+def test_trpo_train_once_matches_real_reference(golden, tag):
+    g = golden('trpo_train_once')
+    O, A, P, E, mb = [int(v) for v in g[tag + '_cfg']]
+    spec, pol, vf, algo = _make(g, tag, O, A, P, E, mb, **TRPO_CASES[tag])
+    for it in range(2):
+        pre = '%s_it%d_' % (tag, it)
+        batch = _host_batch(spec, g, pre, O)
+        np.random.seed(int(g[pre + 'np_seed']))
+        algo._train_once(it, batch)
+        cg = algo.last_cg
+        # same tolerances as the oracle's own test against these goldens: ten
+        # fp32 CG iterations amplify rounding to ~1e-4 of the direction, and the
+        # second iteration starts from parameters that carry the first's
+        grad = _flat_no_pad(pol.net, cg['grad'])
+        assert np.allclose(grad, g[pre + 'cg:grad'],
+                           atol=2e-6 if it == 0 else 5e-5)
+        sd = _flat_no_pad(pol.net, cg['step_dir'])
+        scale = np.abs(g[pre + 'cg:step_dir']).max()
+        assert np.allclose(sd, g[pre + 'cg:step_dir'],
+                           atol=(5e-4 if it == 0 else 4e-3) * scale)
+        ds = _flat_no_pad(pol.net, cg['descent_step'])
+        dscale = np.abs(g[pre + 'cg:descent_step']).max()
+        assert np.allclose(ds, g[pre + 'cg:descent_step'],
+                           atol=(1e-3 if it == 0 else 4e-3) * dscale)
+        for mine, theirs in LOG_KEYS.items():
+            want = float(g[pre + 'log:' + theirs])
+            assert np.isclose(algo.last_tabular[mine], want,
+                              atol=2e-5 if it == 0 else 2e-4,
+                              rtol=1e-3), (mine, it, algo.last_tabular[mine],
+                                           want)
+        for k, v in pol.state_dict().items():
+            assert np.allclose(v.numpy(), g[pre + 'pol:' + k],
+                               atol=(1e-3 if it == 0 else 4e-3) * dscale), k
+        for k, v in vf.state_dict().items():
+            assert np.allclose(v.numpy(), g[pre + 'vf:' + k], atol=2e-6), k
+    if tag == 'trpo_reject':
+        pass  # first iteration rejected: parameters equal the golden's (above)
+
+
+def test_fisher_vector_product_matches_double_backward():
+    """``A v`` (tangent forward, Gaussian metric, backward) against the
+    reference's Hessian-vector product by double backward (oracle) on the same
+    parameters and observations."""
+    from garage_amd._dtypes import Box, EnvSpec  # noqa: F401
+    from garage_amd.algos import TRPO
+    from garage_amd.policies import GaussianMLPPolicy, GaussianMLPValueFunction
+    from oracle import networks as nets
+    from oracle.trpo import build_hessian_vector_product
+    O, A, P, M = 11, 3, 16, 700
+    spec = _spec(O, A, P)
+    torch.manual_seed(3)
+    pol = GaussianMLPPolicy(spec, hidden_sizes=(64, 32))
+    vf = GaussianMLPValueFunction(spec, hidden_sizes=(8, ))
+    algo = TRPO(env_spec=spec, policy=pol, value_function=vf, sampler=None)
+    rng = np.random.RandomState(0)
+    obs = rng.randn(M, O).astype(np.float32)
+    from garage_amd.engine import pad_rows
+
+    class B:
+        obs_dev = pad_rows(obs)
+        n_samples = M
+
+    net = pol.net
+    net.forward(B.obs_dev, M)  # activations at the current parameters
+    # a tangent with zero padding, as every CG vector has
+    vec = torch.zeros(net.n_flat, device=net.device)
+    for _, v in net.named_views(vec):
+        v.copy_(torch.from_numpy(rng.randn(*v.shape).astype(np.float32)))
+    out = torch.empty_like(vec)
+    algo._fisher_vector_product(B, M, vec, out)
+    got = _flat_no_pad(net, out)
+    # oracle: double backward through mean KL(old || new) at new == old
+    params = OrderedDict((k, v.clone()) for k, v in pol.state_dict().items())
+    old = OrderedDict((k, v.clone()) for k, v in params.items())
+    keys = nets.trainable_keys(params)
+    for k in keys:
+        params[k].requires_grad_(True)
+    x = torch.from_numpy(obs)
+
+    def f_constraint():
+        with torch.no_grad():
+            d_old = nets.gaussian_dist(old, nets.POLICY_PREFIX, x)
+        d_new = nets.gaussian_dist(params, nets.POLICY_PREFIX, x)
+        return torch.distributions.kl.kl_divergence(d_old, d_new).mean()
+
+    f_Ax = build_hessian_vector_product(f_constraint,
+                                        [params[k] for k in keys], 1e-5)
+    v_ref = torch.from_numpy(_flat_no_pad(net, vec))
+    want = f_Ax(v_ref).detach().numpy()
+    assert np.allclose(got, want, atol=2e-5 * max(1.0, np.abs(want).max()),
+                       rtol=1e-4)
+
+
+def test_trpo_iteration_matches_oracle_larger_batch():
+    """One TRPO iteration on ~3000 samples, 2 hidden layers of 64: post-step
+    parameters, logged scalars and the accepted backtracking index against the
+    oracle (torch CPU double backward)."""
+    from garage_amd._dtypes import EpisodeBatch, StepType
+    from garage_amd.algos import TRPO
+    from garage_amd.optimizers import (ConjugateGradientOptimizer,
+                                       OptimizerWrapper)
+    from garage_amd.policies import GaussianMLPPolicy, GaussianMLPValueFunction
+    from oracle import batch as ob
+    from oracle.trpo import OracleTRPO
+    O, A, P = 9, 4, 32
+    spec = _spec(O, A, P)
+    torch.manual_seed(5)
+    rng = np.random.RandomState(5)
+    pol = GaussianMLPPolicy(spec, hidden_sizes=(64, 64))
+    vf = GaussianMLPValueFunction(spec, hidden_sizes=(64, 64))
+    lens = rng.randint(5, P + 1, size=150)
+    lens[::7] = P
+    S = int(lens.sum())
+    st = []
+    for L in lens:
+        t = [1] * L
+        t[0] = 0
+        t[-1] = 3 if L == P else 2
+        st += t
+    obs = rng.randn(S, O).astype(np.float32)
+    acts = rng.randn(S, A).astype(np.float32)
+    rew = rng.randn(S)
+    oracle = OracleTRPO(OrderedDict(pol.state_dict()),
+                        OrderedDict(vf.state_dict()), max_episode_length=P,
+                        max_optimization_epochs=2, minibatch_size=512)
+    algo = TRPO(env_spec=spec, policy=pol, value_function=vf, sampler=None,
+                policy_optimizer=OptimizerWrapper(
+                    (ConjugateGradientOptimizer,
+                     dict(max_constraint_value=0.01)), pol),
+                vf_optimizer=OptimizerWrapper(
+                    (torch.optim.Adam, dict(lr=2.5e-4)), vf,
+                    max_optimization_epochs=2, minibatch_size=512))
+    b = ob.OracleEpisodeBatch(observations=obs,
+                              last_observations=np.zeros((len(lens), O),
+                                                         np.float32),
+                              actions=acts, rewards=rew,
+                              step_types=np.asarray(st), lengths=lens,
+                              max_episode_length=P)
+    np.random.seed(9)
+    want = oracle.train_once(b)
+    batch = EpisodeBatch(env_spec=spec, episode_infos={}, observations=obs,
+                         last_observations=np.zeros((len(lens), O), np.float32),
+                         actions=acts, rewards=rew, env_infos={},
+                         agent_infos={},
+                         step_types=np.asarray([StepType(s) for s in st],
+                                               dtype=object),
+                         lengths=lens.astype('l'))
+    np.random.seed(9)
+    algo._train_once(0, batch)
+    assert algo.last_cg['accepted'] == oracle.cg.trace['accepted']
+    dscale = np.abs(oracle.cg.trace['descent_step']).max()
+    ds = _flat_no_pad(pol.net, algo.last_cg['descent_step'])
+    assert np.allclose(ds, oracle.cg.trace['descent_step'], atol=2e-3 * dscale)
+    for k in ('policy/LossBefore', 'policy/LossAfter', 'policy/KL',
+              'policy/Entropy', 'vf/LossBefore', 'vf/LossAfter'):
+        assert np.isclose(algo.last_tabular[k], want[k], atol=2e-5,
+                          rtol=1e-3), (k, algo.last_tabular[k], want[k])
+    wpol, wvf = oracle.state()
+    for k, v in pol.state_dict().items():
+        assert np.allclose(v.numpy(), wpol[k], atol=2e-3 * dscale), k
+    for k, v in vf.state_dict().items():
+        assert np.allclose(v.numpy(), wvf[k], atol=5e-6), k
