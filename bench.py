@@ -72,7 +72,7 @@ def load_traffic():
         return json.load(f).get('kernels', {})
 
 
-def build_engine(cfg, comm, seed=1):
+def build_engine(cfg, comm, seed=1, algo_name='ppo'):
     from garage_amd.algos import PPO
     from garage_amd.distributed import shard_algo
     from garage_amd.envs import SyntheticVecEnv
@@ -97,6 +97,24 @@ def build_engine(cfg, comm, seed=1):
     S = n * T
     mb = S // HYPER['minibatches_per_epoch']
     opt = (torch.optim.Adam, dict(lr=HYPER['lr']))
+    if algo_name == 'trpo':
+        # one conjugate-gradient policy step on the full
+        # batch + the same value-function passes (not the headline metric)
+        from garage_amd.algos import TRPO
+        from garage_amd.optimizers import ConjugateGradientOptimizer
+        algo = TRPO(env_spec=env.spec, policy=pol, value_function=vf,
+                    sampler=sampler,
+                    policy_optimizer=OptimizerWrapper(
+                        (ConjugateGradientOptimizer,
+                         dict(max_constraint_value=0.01)), pol),
+                    vf_optimizer=OptimizerWrapper(
+                        opt, vf, max_optimization_epochs=HYPER['epochs'],
+                        minibatch_size=mb, permutation='device',
+                        seed=2 * seed + 1 + 1000 * rank),
+                    discount=HYPER['discount'],
+                    gae_lambda=HYPER['gae_lambda'])
+        shard_algo(algo, comm)
+        return algo, sampler, pol, S
     algo = PPO(env_spec=env.spec, policy=pol, value_function=vf,
                sampler=sampler,
                policy_optimizer=OptimizerWrapper(
@@ -206,6 +224,9 @@ def main():
     ap.add_argument('--cpu-envs', type=int, default=1024,
                     help='envs of the bounded CPU-baseline sample (0: skip)')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--algo', default='ppo', choices=['ppo', 'trpo'],
+                    help='trpo: the section-8f.1 widening (conjugate-gradient '
+                    'policy step), reported under its own metric name')
     ap.add_argument('--no-overlap', action='store_true',
                     help='run the policy and value-function passes one after '
                     'the other on one stream (isolated per-kernel timings)')
@@ -219,7 +240,7 @@ def main():
         print('warning: --gpus {} but WORLD_SIZE {}'.format(args.gpus, world),
               file=sys.stderr)
     cfg = CONFIGS[args.config]
-    algo, sampler, pol, S = build_engine(cfg, comm)
+    algo, sampler, pol, S = build_engine(cfg, comm, algo_name=args.algo)
     algo.overlap_updates = not args.no_overlap
 
     def sync():
@@ -262,7 +283,8 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = S * world * args.steps / elapsed
     line = {
-        'metric': 'env-steps/sec (whole node) PPO 4096 envs',
+        'metric': 'env-steps/sec (whole node) PPO 4096 envs'
+        if args.algo == 'ppo' else 'env-steps/sec (whole node) TRPO 4096 envs',
         'value': value,
         'unit': 'env-steps/s',
         'n_gpus': world,
@@ -276,7 +298,9 @@ def main():
         'data': 'synthetic',
         'config': {
             'workload': '{}: obs {} act {}, {} envs/GPU x T={}, '
-                        'MLP{} policy + value, PPO E={} x {} minibatches, '
+                        'MLP{} policy + value, ' + ('PPO' if args.algo == 'ppo' else
+                                                    'TRPO (CG policy step) + value') +
+                        ' E={} x {} minibatches, '
                         'gamma {} lambda {} clip {} Adam lr {}, device '
                         'minibatch permutation, policy/value passes {}'.format(
                             cfg['name'], cfg['obs_dim'], cfg['act_dim'],
@@ -363,7 +387,8 @@ def main():
                  avg_launch_us=r['total_ms'] * 1e3 / r['launches'])
             for r in rows[7:9] if r['launches'] > 0
         ]
-    if args.cpu_envs > 0 and world == 1:
+    if args.cpu_envs > 0 and world == 1 and args.algo == 'ppo' \
+            and not cfg.get('discrete'):
         line['cpu_baseline'] = cpu_baseline(cfg, args.cpu_envs)
     print(json.dumps(line))
 
