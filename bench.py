@@ -45,15 +45,14 @@ CPU_THREADS = int(os.environ.get('GARAGE_AMD_CPU_THREADS', '16'))
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
 
-# garage_amd/csrc/prof.h kinds.  The 128x128 kinds cover the mask-free
-# (<...,32,true>, every C3 launch) and the masked (<...,32,false>) instantiation.
+# garage_amd/csrc/prof.h kinds (kernel names as rocprofv3 prints them)
 KIND_NAMES = [
-    'gemm_f32_kernel<128,128,2,4,true,true,32,true> (forward)',
-    'gemm_f32_kernel<128,128,2,4,true,false,32,true> (data grad)',
-    'gemm_f32_kernel<128,128,2,4,false,false,32,true> (weight grad)',
-    'gemm_f32_kernel<128,32,4,1,true,true,32,false> (forward, narrow)',
-    'gemm_f32_kernel<128,32,4,1,true,false,32,false> (data grad, narrow)',
-    'gemm_f32_kernel<128,32,4,1,false,false,32,false> (weight grad, narrow)',
+    'gemm_f32_kernel<128,128,2,4,true,true,32> (forward)',
+    'gemm_f32_kernel<128,128,2,4,true,false,32> (data grad)',
+    'gemm_f32_kernel<128,128,2,4,false,false,32> (weight grad)',
+    'gemm_f32_kernel<128,32,4,1,true,true,32> (forward, narrow)',
+    'gemm_f32_kernel<128,32,4,1,true,false,32> (data grad, narrow)',
+    'gemm_f32_kernel<128,32,4,1,false,false,32> (weight grad, narrow)',
     'gae_scan_kernel',
     'skinny_fwd_kernel (first-layer forward / head data grad; work = bytes)',
     'skinny_wgrad_kernel (first-layer / head weight grad; work = bytes)',

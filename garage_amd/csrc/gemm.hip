@@ -29,15 +29,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BK = 32;
 constexpr int PAD = 4;
-// LDS stages per operand tile.  2 stages (one barrier per k-step) is no faster
-// than 1 (two barriers) at the K = 256 shapes of this workload, and 1 stage
-// halves the LDS footprint (37 KB), which lets the workgroups of the policy and
-// the value-function update chains co-reside on a CU when they run on two
-// streams (measured: 512 -> 413 us per policy+value minibatch pair).
-#ifndef GA_GEMM_STAGES
-#define GA_GEMM_STAGES 1
-#endif
-constexpr int STAGES = GA_GEMM_STAGES;
+// One LDS stage per operand tile (37 KB per 128x128 workgroup): a second stage
+// (one barrier per k-step instead of two) measured no faster at the K = 256 shapes
+// of this workload, and the small footprint lets the workgroups of the policy and
+// the value-function update chains co-reside on a CU when they run on two streams.
 
 enum Epilogue { EPI_BIAS_ACT = 0, EPI_MUL_DTANH = 1, EPI_PLAIN = 2 };
 
@@ -185,63 +180,26 @@ struct TileLoader {
   }
 };
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KC, bool B_KC,
-          int BKT = BK, bool FULL = false>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_f32_kernel(
-    GemmParams p) {
-  constexpr int NT = 64 * WAVES_M * WAVES_N;  // threads per workgroup
-  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
-  constexpr int TM = WM / 32, TN = WN / 32;
-  // row-contiguous operands: [BK][BR + PAD]; k-contiguous ones: [BR][BK + PAD]
+// The k-loop of one workgroup: global -> registers -> LDS -> MFMA.  FULL selects the
+// mask-free loader (the caller has checked that this workgroup's tiles are
+// entirely inside the matrices and that its k range is a multiple of BKT).
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KC, bool B_KC, int BKT,
+          bool FULL, int TM, int TN>
+__device__ __forceinline__ void gemm_mainloop(const GemmParams& p, float* lds,
+                                              f32x16 (&acc)[TM][TN], float& csum,
+                                              bool do_colsum, int m0, int n0,
+                                              int kbeg, int kend, int wm0, int wn0) {
+  constexpr int NT = 64 * WAVES_M * WAVES_N;
   constexpr int LDA_S = BM + PAD, LDB_S = BN + PAD, LDK = BKT + PAD;
   constexpr int A_FLOATS = A_KC ? BM * LDK : BKT * LDA_S;
-  constexpr int B_FLOATS = B_KC ? BN * LDK : BKT * LDB_S;
-  // two LDS stages: tile s+1 is written (3/4 of the way through the MFMAs of
-  // tile s) into the stage nobody reads, so each k-step needs ONE barrier and the
-  // ds_writes issue under the matrix pipe instead of between barriers
-  __shared__ __attribute__((aligned(16))) float lds[STAGES * (A_FLOATS + B_FLOATS)];
-
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int wm0 = (wave / WAVES_N) * WM;
-  const int wn0 = (wave % WAVES_N) * WN;
-  // logical block from the linear id (XCD-aware order, common.h): with one split
-  // the n blocks of an m block share its A tile; with split-K every block of a
-  // split shares the split's A and B rows
-  int bx, by, bz;
-  if (p.gz == 1) {
-    ga_xcd_group((int)blockIdx.x, p.gx, p.gy, &bx, &by);
-    bz = 0;
-  } else {
-    int mem;
-    ga_xcd_group((int)blockIdx.x, p.gz, p.gx * p.gy, &bz, &mem);
-    bx = mem % p.gx;
-    by = mem / p.gx;
-  }
-  const int m0 = bx * BM;
-  const int n0 = by * BN;
-  const int split = bz;
-  const int kbeg = split * p.k_per_split;
-  const int kend = min(p.K, kbeg + p.k_per_split);
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  float csum = 0.f;  // colsum accumulator (threads < BM or < BN)
-  const bool do_colsum =
-      p.colsum != nullptr &&
-      (p.colsum_of_b ? (bx == 0) : (by == 0));
-
   TileLoader<BM, A_KC, NT, BKT, FULL> la;
   TileLoader<BN, B_KC, NT, BKT, FULL> lb;
   const int a_span = A_KC ? p.K : p.M;  // valid floats along the contiguous axis
   const int b_span = B_KC ? p.K : p.N;
   const int nk = (kend - kbeg + BKT - 1) / BKT;
+  float* As = lds;
+  float* Bs = lds + A_FLOATS;
   if (nk > 0) {
     la.init(p.a_idx, m0, p.M, kbeg, kend);
     lb.init(p.b_idx, n0, p.N, kbeg, kend);
@@ -249,8 +207,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_f32_kernel(
     lb.load(p.B, p.ldb, n0, kbeg, b_span);
     la.prefetch_lines(p.a_idx, kbeg + BKT, kend);
     lb.prefetch_lines(p.b_idx, kbeg + BKT, kend);
-    la.store(lds, m0, p.M, kbeg, kend);
-    lb.store(lds + A_FLOATS, n0, p.N, kbeg, kend);
+    la.store(As, m0, p.M, kbeg, kend);
+    lb.store(Bs, n0, p.N, kbeg, kend);
   }
   __syncthreads();
 
@@ -266,10 +224,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_f32_kernel(
       la.prefetch_lines(p.a_idx, k_next + BKT, kend);
       lb.prefetch_lines(p.b_idx, k_next + BKT, kend);
     }
-    const float* As = lds + (STAGES == 2 ? (s & 1) : 0) * (A_FLOATS + B_FLOATS);
-    const float* Bs = As + A_FLOATS;
-    float* An = lds + (STAGES == 2 ? ((s + 1) & 1) : 0) * (A_FLOATS + B_FLOATS);
-    float* Bn = An + A_FLOATS;
     // Groups of 4 MFMAs over 8 physical k: lane half h feeds k = 8g + 4h + q
     // to step q (any k <-> slot map is valid as long as A and B agree), so a
     // k-contiguous operand is ONE ds_read_b128 per 4 MFMAs.
@@ -308,10 +262,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_f32_kernel(
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[j][q],
                                                              acc[i][j], 0, 0, 0);
-      if (STAGES == 2 && g == BKT / 8 - 2 && more) {
-        la.store(An, m0, p.M, k_next, kend);
-        lb.store(Bn, n0, p.N, k_next, kend);
-      }
     }
     if (do_colsum) {
       const float* T = p.colsum_of_b ? Bs : As;
@@ -323,12 +273,72 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_f32_kernel(
       }
     }
     __syncthreads();
-    if (STAGES == 1 && more) {
-      la.store(An, m0, p.M, k_next, kend);
-      lb.store(Bn, n0, p.N, k_next, kend);
+    if (more) {
+      la.store(As, m0, p.M, k_next, kend);
+      lb.store(Bs, n0, p.N, k_next, kend);
       __syncthreads();
     }
   }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KC, bool B_KC,
+          int BKT = BK>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_f32_kernel(
+    GemmParams p) {
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  // row-contiguous operands: [BK][BR + PAD]; k-contiguous ones: [BR][BK + PAD]
+  constexpr int LDA_S = BM + PAD, LDB_S = BN + PAD, LDK = BKT + PAD;
+  constexpr int A_FLOATS = A_KC ? BM * LDK : BKT * LDA_S;
+  constexpr int B_FLOATS = B_KC ? BN * LDK : BKT * LDB_S;
+  __shared__ __attribute__((aligned(16))) float lds[A_FLOATS + B_FLOATS];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int wm0 = (wave / WAVES_N) * WM;
+  const int wn0 = (wave % WAVES_N) * WN;
+  // logical block from the linear id (XCD-aware order, common.h): with one split
+  // the n blocks of an m block share its A tile; with split-K every block of a
+  // split shares the split's A and B rows
+  int bx, by, bz;
+  if (p.gz == 1) {
+    ga_xcd_group((int)blockIdx.x, p.gx, p.gy, &bx, &by);
+    bz = 0;
+  } else {
+    int mem;
+    ga_xcd_group((int)blockIdx.x, p.gz, p.gx * p.gy, &bz, &mem);
+    bx = mem % p.gx;
+    by = mem / p.gx;
+  }
+  const int m0 = bx * BM;
+  const int n0 = by * BN;
+  const int split = bz;
+  const int kbeg = split * p.k_per_split;
+  const int kend = min(p.K, kbeg + p.k_per_split);
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float csum = 0.f;  // colsum accumulator (threads < BM or < BN)
+  const bool do_colsum =
+      p.colsum != nullptr &&
+      (p.colsum_of_b ? (bx == 0) : (by == 0));
+
+  // interior workgroups (every one at the C3 shapes, all but the last row / column
+  // block and the last split otherwise) take the mask-free loader
+  const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N) && kend > kbeg &&
+                    ((kend - kbeg) % BKT == 0);
+  if (full)
+    gemm_mainloop<BM, BN, WAVES_M, WAVES_N, A_KC, B_KC, BKT, true>(
+        p, lds, acc, csum, do_colsum, m0, n0, kbeg, kend, wm0, wn0);
+  else
+    gemm_mainloop<BM, BN, WAVES_M, WAVES_N, A_KC, B_KC, BKT, false>(
+        p, lds, acc, csum, do_colsum, m0, n0, kbeg, kend, wm0, wn0);
 
   // ---- epilogue: D(row, col): col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   float* Cout = p.C + (int64_t)split * p.c_split_stride;
@@ -393,15 +403,8 @@ int launch_gemm(const GemmParams& p_in, int splits, hipStream_t stream) {
     ga_prof_events(GA_PROF_GEMM_NT_128 + mode, flops, &e0, &e1);
     // 8 waves (64x32 each): two workgroups per CU put 4 waves on every SIMD, so
     // the matrix pipe has work while other waves sit at the barrier / vmcnt
-    // interior-only launches (every C3 update GEMM) skip the edge masks
-    const bool full = p.M % 128 == 0 && p.N % 128 == 0 && p.K % BK == 0 &&
-                      p.k_per_split % BK == 0 && p.K % p.k_per_split == 0;
-    if (full)
-      hipExtLaunchKernelGGL((gemm_f32_kernel<128, 128, 2, 4, A_KC, B_KC, BK, true>),
-                            grid, dim3(512), 0, stream, e0, e1, 0, p);
-    else
-      hipExtLaunchKernelGGL((gemm_f32_kernel<128, 128, 2, 4, A_KC, B_KC>), grid,
-                            dim3(512), 0, stream, e0, e1, 0, p);
+    hipExtLaunchKernelGGL((gemm_f32_kernel<128, 128, 2, 4, A_KC, B_KC>), grid,
+                          dim3(512), 0, stream, e0, e1, 0, p);
   }
   GA_CHECK_LAUNCH("gemm_f32");
   return GA_OK;
