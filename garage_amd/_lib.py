@@ -154,6 +154,7 @@ SIGNATURES = {
     'ga_update_epoch': (c_int, [C.POINTER(UpdateArgs), ptr]),
     'ga_update_epoch_pair': (c_int, [C.POINTER(UpdateArgs), ptr,
                                      C.POINTER(UpdateArgs), ptr]),
+    'ga_set_allreduce_hook': (None, [ptr]),
     'ga_comm_unique_id': (c_int, [ptr]),
     'ga_comm_init_rank': (ptr, [ptr, c_int, c_int]),
     'ga_comm_allreduce_sum_f32': (c_int, [ptr, ptr, c_i64, ptr]),

@@ -349,6 +349,12 @@ int ga_update_epoch_pair(const ga_update_args* a, ga_stream_t stream_a,
  * reference has no collective on this path).
  * ga_comm_unique_id fills 128 bytes on rank 0 (HOST pointer) to be broadcast by
  * the caller; ga_comm_init_rank returns an opaque handle. */
+/* The all-reduce ga_update_epoch* calls on args->comm between the slab reduction
+ * and Adam: fn(comm, buf, n, stream) sums buf over the ranks in place, returns 0.
+ * ga_comm_init_rank installs RCCL's; a caller with another transport (or a test
+ * standing in for the second rank) installs its own. */
+typedef int (*ga_allreduce_fn)(void* comm, float* buf, int64_t n, void* stream);
+void ga_set_allreduce_hook(ga_allreduce_fn fn);
 int ga_comm_unique_id(void* id128_host);
 void* ga_comm_init_rank(const void* id128_host, int rank, int world);
 int ga_comm_allreduce_sum_f32(void* comm, float* buf, int64_t n, ga_stream_t stream);

@@ -138,3 +138,101 @@ def test_two_rank_ppo_equals_single_process_oracle():
                   'vf/LossBefore', 'vf/LossAfter'):
             assert np.isclose(got['tab'][k], want[k], atol=2e-5, rtol=2e-5), \
                 (rank, k, got['tab'][k], want[k])
+
+
+class _TwinComm:
+    """Stands in for a second rank that holds an identical shard: sums double,
+    minima stay, counts are listed twice."""
+    world_size = 2
+    rank = 0
+    group = None
+
+    def all_reduce(self, tensor, op='sum'):
+        if op == 'sum':
+            tensor.mul_(2)
+        return tensor
+
+    def all_gather_int(self, value, device=None):
+        return [int(value), int(value)]
+
+    def broadcast(self, tensor, src=0):
+        return tensor
+
+    def barrier(self):
+        pass
+
+
+def _twin_algo(native, seed=0):
+    """PPO whose gradient exchange goes through the C++ epoch loop's all-reduce
+    hook (``native``) or through the Python minibatch loop's ``grad_hook``."""
+    import ctypes as C
+
+    from garage_amd import _lib
+    from garage_amd._dtypes import Box, EnvSpec
+    from garage_amd.algos import PPO
+    from garage_amd.optimizers import OptimizerWrapper
+    from garage_amd.policies import GaussianMLPPolicy, GaussianMLPValueFunction
+    spec = EnvSpec(Box(-np.inf, np.inf, (O, )), Box(-np.inf, np.inf, (A, )),
+                   max_episode_length=P)
+    torch.manual_seed(seed)
+    pol = GaussianMLPPolicy(spec, hidden_sizes=(16, 16))
+    vf = GaussianMLPValueFunction(spec, hidden_sizes=(16, 16))
+    opt = (torch.optim.Adam, dict(lr=1e-3))
+    algo = PPO(env_spec=spec, policy=pol, value_function=vf, sampler=None,
+               policy_optimizer=OptimizerWrapper(opt, pol, 2, 16,
+                                                 permutation='device', seed=5),
+               vf_optimizer=OptimizerWrapper(opt, vf, 2, 16,
+                                             permutation='device', seed=6))
+    comm = _TwinComm()
+    algo._comm = comm
+    keep = []
+    for o in (algo._policy_optimizer, algo._vf_optimizer):
+        o.grad_hook = comm.all_reduce
+        if native:
+
+            class Handle:
+                handle = C.c_void_p(1)  # opaque to the hook below
+                world_size = 2
+
+            o.native_comm = Handle()
+    if native:
+        lib = _lib.load()
+
+        @C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+        def twin_sum(_comm, buf, n, stream):
+            # buf <- buf + buf: the sum over two ranks with identical gradients
+            return lib.ga_axpby_f32(1.0, C.c_void_p(buf), 1.0, C.c_void_p(buf),
+                                    n, C.c_void_p(stream))
+
+        lib.ga_set_allreduce_hook(twin_sum)
+        keep.append(twin_sum)
+    return spec, pol, vf, algo, keep
+
+
+@pytest.mark.parametrize('overlap', [True, False])
+def test_native_dp_branch_equals_python_loop_with_a_twin_rank(overlap):
+    """The data-parallel branch of ``ga_update_epoch*`` (scaled slab reduction
+    -> all-reduce hook -> Adam, on one or two streams) against the Python
+    minibatch loop with the same exchange: same kernels, same bits."""
+    from garage_amd._dtypes import EpisodeBatch, StepType
+    d = _make_shard(0)
+    outs = []
+    for native in (True, False):
+        spec, pol, vf, algo, keep = _twin_algo(native)
+        algo.overlap_updates = overlap
+        st = np.asarray([StepType(int(s)) for s in d['step_types']],
+                        dtype=object)
+        batch = EpisodeBatch(env_spec=spec, episode_infos={},
+                             observations=d['observations'],
+                             last_observations=d['last_observations'],
+                             actions=d['actions'], rewards=d['rewards'],
+                             env_infos={}, agent_infos={}, step_types=st,
+                             lengths=d['lengths'])
+        assert algo._native_update_ok() == native
+        algo._train_once(0, batch)
+        outs.append((pol.net.params.clone(), vf.net.params.clone(),
+                     dict(algo.last_tabular)))
+        del keep
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1])
+    assert outs[0][2] == outs[1][2]
