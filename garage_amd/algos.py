@@ -659,7 +659,8 @@ class VPG:
     def __getstate__(self):
         state = self.__dict__.copy()
         state['_old_policy'] = self._old_policy.params.cpu().numpy()
-        state.pop('last_tensors', None)
+        for k in ('last_tensors', 'last_cg', '_side_stream'):
+            state.pop(k, None)  # device handles / scratch, rebuilt on demand
         state['_comm'] = None
         return state
 

@@ -626,11 +626,27 @@ class GpuVecSampler:
     def __getstate__(self):
         state = self.__dict__.copy()
         state['_workers'] = None  # local_sampler.py:207-217
+        # what a worker carries from one rollout to the next: the Philox step
+        # counter of the action noise and which envs have an episode in flight
+        # (only those are reset at the next rollout, vec_worker.py:122-126), so
+        # that a resumed run (trainer.py:263-341) continues like the
+        # uninterrupted one
+        state['_worker_state'] = [
+            dict(global_step=getattr(w, '_global_step', 0),
+                 ep_t=None if getattr(w, '_ep_t', None) is None else
+                 w._ep_t.cpu().numpy())
+            for w in self._workers]
         return state
 
     def __setstate__(self, state):
+        saved = state.pop('_worker_state', None)
         self.__dict__.update(state)
         self._build_workers()
+        for w, st in zip(self._workers, saved or []):
+            w._global_step = st['global_step']
+            if st['ep_t'] is not None:
+                w._ep_t = torch.from_numpy(st['ep_t']).to(w.device)
+                w._needs_env_reset = False  # the env came back with its state
 
 
 __all__ = ['WorkerFactory', 'GpuVecWorker', 'GpuFragmentWorker',
