@@ -111,6 +111,15 @@ SIGNATURES = {
                                       ptr, ptr, ptr]),
     'ga_gaussian_nll_loss_f32': (c_int, [ptr, c_i64, ptr, ptr, ptr, c_i64, ptr,
                                          ptr, ptr, c_i64, c_i64, ptr, ptr]),
+    'ga_head_loss_supported': (c_int, [c_int, c_int]),
+    'ga_set_fused_head_loss': (c_int, [c_int]),
+    'ga_head_ppo_gaussian_loss_f32': (c_int, [
+        ptr, c_i64, ptr, c_i64, ptr, c_int, ptr, c_i64, ptr, c_i64, ptr, ptr,
+        ptr, ptr, c_int, c_f32, c_int, c_f32, c_i64, c_int, c_int, c_f32, c_f32,
+        c_int, ptr, c_i64, ptr, ptr, ptr, c_i64, c_i64, ptr, ptr]),
+    'ga_head_gaussian_nll_loss_f32': (c_int, [
+        ptr, c_i64, ptr, ptr, c_int, ptr, c_i64, ptr, ptr, ptr, c_i64, ptr,
+        c_i64, ptr, ptr, c_i64, c_i64, ptr, ptr]),
     'ga_gaussian_kl_f32': (c_int, [ptr, ptr, c_i64, c_i64, c_int, c_f32, c_f32,
                                    ptr, ptr, ptr]),
     'ga_reduce_slabs_f32': (c_int, [ptr, c_i64, c_i64, c_i64, c_f32, ptr, ptr]),

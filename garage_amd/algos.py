@@ -163,7 +163,12 @@ class VPG:
             saved, net.params = net.params, params
         obs = batch.obs_dev if obs is None else obs
         try:
-            if head is None:
+            # training passes compute the head layer inside the loss kernel,
+            # exactly as the native epoch loop does (same kernels, same bits)
+            fused = (want_grad and head is None and pol.kind == 'gaussian'
+                     and ent_out is None and getattr(self, 'fuse_head', False)
+                     and net.head_fusable())
+            if head is None and not fused:
                 head = net.forward(obs, M, row_idx=idx)
             dout = net.dout_view(M) if want_grad else None
             loss = torch.empty(1, dtype=torch.float32, device=net.device)
@@ -171,7 +176,20 @@ class VPG:
             slabs = dptr(net._slabs) if want_grad else None
             splits = int(net._splits) if want_grad else 0
             ws = dptr(reduction_workspace(net.device))
-            if pol.kind == 'gaussian':
+            if fused:
+                H, Wh, bh = net.forward_hidden(obs, M, row_idx=idx)
+                head = net.out_view(M)
+                has_min, mn, has_max, mx = pol._std_args()
+                call('ga_head_ppo_gaussian_loss_f32', dptr(H), H.stride(0),
+                     dptr(Wh), H.stride(0), dptr(bh), int(net.dims[-2]),
+                     dptr(head), head.stride(0), dptr(batch.actions_dev),
+                     batch.actions_dev.stride(0), dptr(old_ll), dptr(adv),
+                     dptr(idx), dptr(net.params[0:1]), has_min, mn, has_max,
+                     mx, M, net.out_dim, algo, float(self._lr_clip_range),
+                     float(self._policy_ent_coeff), self._ent_flags(),
+                     dptr(dout), dout.stride(0), dptr(ll_out), dptr(loss),
+                     slabs, net.n_flat, splits, ws, stream_ptr())
+            elif pol.kind == 'gaussian':
                 has_min, mn, has_max, mx = pol._std_args()
                 call('ga_ppo_gaussian_loss_f32', dptr(head), head.stride(0),
                      dptr(batch.actions_dev), batch.actions_dev.stride(0),
@@ -199,10 +217,21 @@ class VPG:
                          v=None):
         vf = self._value_function
         net = vf.net
-        if v is None:
-            v = net.forward(batch.obs_dev, M, row_idx=idx)
         dout = net.dout_view(M) if want_grad else None
         loss = torch.empty(1, dtype=torch.float32, device=net.device)
+        if (want_grad and v is None and getattr(self, 'fuse_head', False)
+                and net.head_fusable()):
+            H, Wh, bh = net.forward_hidden(batch.obs_dev, M, row_idx=idx)
+            v = net.out_view(M)
+            call('ga_head_gaussian_nll_loss_f32', dptr(H), H.stride(0),
+                 dptr(Wh), dptr(bh), int(net.dims[-2]), dptr(v), v.stride(0),
+                 dptr(returns), dptr(idx), dptr(net.params[0:1]), M,
+                 dptr(dout), dout.stride(0), dptr(loss), dptr(net._slabs),
+                 net.n_flat, int(net._splits),
+                 dptr(reduction_workspace(net.device)), stream_ptr())
+            return loss, v, dout
+        if v is None:
+            v = net.forward(batch.obs_dev, M, row_idx=idx)
         call('ga_gaussian_nll_loss_f32', dptr(v), v.stride(0), dptr(returns),
              dptr(idx), dptr(net.params[0:1]), M, dptr(dout), dptr(loss),
              dptr(net._slabs) if want_grad else None, net.n_flat,
@@ -476,6 +505,10 @@ class VPG:
         """``ga_update_args`` of one network (kept alive by the caller)."""
         from garage_amd import _lib
         import ctypes as C
+        # head layer inside the loss kernel (opt-in; same switch as the Python
+        # minibatch loop so both produce the same bits)
+        _lib.load().ga_set_fused_head_loss(
+            int(bool(getattr(self, 'fuse_head', False))))
         net = module.net
         S = batch.n_samples
         mb = opt.local_minibatch_size(S)

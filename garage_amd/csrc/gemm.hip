@@ -480,16 +480,18 @@ extern "C" int ga_mlp_forward_f32(const ga_mlp_desc* d, const float* params,
                                   float* out, int64_t ldo, hipStream_t stream) {
   int rc = check_desc(d, "ga_mlp_forward_f32");
   if (rc) return rc;
-  GA_REQUIRE(params && X && out, "ga_mlp_forward_f32: null pointer");
+  GA_REQUIRE(params && X, "ga_mlp_forward_f32: null pointer");
+  // out == NULL: hidden layers only (the head is fused into the loss kernel)
+  GA_REQUIRE(out || d->n_layers >= 2, "ga_mlp_forward_f32: nothing to compute");
   GA_REQUIRE(d->n_layers == 1 || acts, "ga_mlp_forward_f32: acts workspace needed");
   GA_REQUIRE(M >= 0 && M < (1ll << 31), "ga_mlp_forward_f32: bad M");
   GA_REQUIRE(ldx % 4 == 0 && ldx >= d->dims[0], "ga_mlp_forward_f32: ldx %lld",
              (long long)ldx);
-  GA_REQUIRE(ldo >= d->dims[d->n_layers], "ga_mlp_forward_f32: ldo too small");
+  GA_REQUIRE(!out || ldo >= d->dims[d->n_layers], "ga_mlp_forward_f32: ldo too small");
   GA_REQUIRE(ga_aligned16(params) && ga_aligned16(X) && (!acts || ga_aligned16(acts)),
              "ga_mlp_forward_f32: pointers must be 16-B aligned");
   if (M == 0) return GA_OK;
-  if (g_fused_forward && ga_policy_step_fused_supported(d))
+  if (out && g_fused_forward && ga_policy_step_fused_supported(d))
     return ga_mlp_forward_fused_f32(d, params, X, ldx, row_idx, M, acts, out, ldo,
                                     stream);
   const int L = d->n_layers;
@@ -504,6 +506,7 @@ extern "C" int ga_mlp_forward_f32(const ga_mlp_desc* d, const float* params,
     p.B = params + d->w_off[l];
     p.ldb = round4(d->dims[l]);
     const bool last = (l == L - 1);
+    if (last && !out) break;
     p.C = last ? out : acts + d->act_off[l];
     p.c_rs = last ? ldo : round4(d->dims[l + 1]);
     p.c_cs = 1;

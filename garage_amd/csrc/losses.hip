@@ -490,15 +490,30 @@ struct AdamParams {
   float eps;
 };
 
+// One element of torch.optim.Adam's single-tensor step with fused multiply-add
+// contraction switched off (HIP's __fmul_rn / __fadd_rn are plain operators, so
+// the compiler would otherwise be free to contract differently in each kernel):
+// the stand-alone kernel and the slab-reduction + Adam kernel produce the same
+// bits, which are those of one rounding per torch operation.
+__device__ __forceinline__ void adam_update(const AdamParams& a, float g, float& p,
+                                            float& m, float& v) {
+#pragma clang fp contract(off)
+  const float diff = g - m;
+  m = fmaf(a.lerp_w, diff, m);             // exp_avg.lerp_(grad, 1 - beta1): torch's
+                                           // lerp is one fused multiply-add
+  const float gg = (a.one_minus_beta2 * g) * g;
+  v = v * a.beta2 + gg;                    // mul_(beta2).addcmul_(g, g, 1 - beta2)
+  const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+  const float num = a.neg_step_size * m;
+  p = p + num / denom;                     // addcdiv_(exp_avg, denom, -step_size)
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(AdamParams a) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= a.n) return;
-  const float g = a.g[i];
-  float m = a.m[i], v = a.v[i];
-  m = m + a.lerp_w * (g - m);                 // exp_avg.lerp_(grad, 1 - beta1)
-  v = v * a.beta2 + a.one_minus_beta2 * g * g;  // mul_(beta2).addcmul_(g, g, 1-beta2)
-  const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
-  a.p[i] = a.p[i] + (a.neg_step_size * m) / denom;  // addcdiv_
+  float p = a.p[i], m = a.m[i], v = a.v[i];
+  adam_update(a, a.g[i], p, m, v);
+  a.p[i] = p;
   a.m[i] = m;
   a.v[i] = v;
 }
@@ -549,12 +564,7 @@ __global__ __launch_bounds__(256) void reduce_adam_kernel(const float* slabs,
   float pp[4] = {p4.x, p4.y, p4.z, p4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w},
         vv[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    mm[j] = mm[j] + a.lerp_w * (g[j] - mm[j]);
-    vv[j] = vv[j] * a.beta2 + a.one_minus_beta2 * g[j] * g[j];
-    const float denom = sqrtf(vv[j]) / a.bc2_sqrt + a.eps;
-    pp[j] = pp[j] + (a.neg_step_size * mm[j]) / denom;
-  }
+  for (int j = 0; j < 4; ++j) adam_update(a, g[j], pp[j], mm[j], vv[j]);
   *reinterpret_cast<float4*>(a.p + i4) = make_float4(pp[0], pp[1], pp[2], pp[3]);
   *reinterpret_cast<float4*>(a.m + i4) = make_float4(mm[0], mm[1], mm[2], mm[3]);
   *reinterpret_cast<float4*>(a.v + i4) = make_float4(vv[0], vv[1], vv[2], vv[3]);
@@ -951,5 +961,347 @@ extern "C" int ga_fisher_seed_gaussian_f32(const float* tmean, int64_t ldt, int6
                      0, stream, tmean, ldt, M, A, log_std, has_min, min_log_std,
                      has_max, max_log_std, dout, ldd);
   GA_CHECK_LAUNCH("fisher_seed");
+  return GA_OK;
+}
+
+// ---- head layer fused into the loss ------------------------------------------------
+// In a minibatch step the network's last linear layer (hidden -> action means, or
+// hidden -> value) feeds nothing but the loss.  These kernels compute it in the
+// loss kernel: 16 lanes own one row of the last hidden activations (16-B loads, a
+// whole row coalesced), the head weights sit in LDS, the A dot products are
+// reduced over the 16 lanes with xor shuffles, and the per-row loss / gradient
+// seed is the same arithmetic as ppo_gaussian_loss_kernel / gaussian_nll_kernel.
+// One pass over the [rows x hidden] matrix replaces the narrow GEMM launch, the
+// round trip of its output and the loss launch.
+namespace {
+
+struct HeadLayer {
+  const float* H;       // [M, ldh] last hidden activations (minibatch rows)
+  int64_t ldh;
+  const float* W;       // [A][ldw], k contiguous
+  int64_t ldw;
+  const float* bias;    // [A]
+  int K;                // hidden width, a multiple of 64
+  float* out;           // optional [M, ldo] head outputs
+  int64_t ldo;
+};
+
+constexpr int HL_THREADS = 256;
+
+__device__ __forceinline__ float group16_sum(float v) {
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 4, 64);
+  v += __shfl_xor(v, 8, 64);
+  return v;
+}
+
+// Rows per 16-lane group and block iteration: all their loads are issued before
+// any arithmetic (two dependent global-memory latencies per 64 rows: the gathered
+// row ids, then everything else).
+template <int KV>
+struct HeadRows {
+  static constexpr int R = KV <= 4 ? 4 : 2;
+};
+
+// head outputs of one row from its activations h[KV] -> rowbuf[0..A) (LDS)
+template <int KV>
+__device__ __forceinline__ void head_row(const HeadLayer& L, int A, const float* wlds,
+                                         const float4 (&h)[KV], int64_t row, bool live,
+                                         int gl, float* rowbuf) {
+  for (int a = 0; a < A; ++a) {
+    float s = 0.f;
+#pragma unroll
+    for (int v = 0; v < KV; ++v) {
+      const float4 w =
+          *reinterpret_cast<const float4*>(wlds + a * L.K + 4 * gl + 64 * v);
+      s = fmaf(h[v].x, w.x, s);
+      s = fmaf(h[v].y, w.y, s);
+      s = fmaf(h[v].z, w.z, s);
+      s = fmaf(h[v].w, w.w, s);
+    }
+    s = group16_sum(s) + wlds[A * L.K + a];
+    if (gl == 0) {
+      rowbuf[a] = s;
+      if (L.out && live) L.out[row * L.ldo + a] = s;
+    }
+  }
+}
+
+// W[A][K] and bias[A] -> LDS
+__device__ __forceinline__ void stage_head(const HeadLayer& L, int A, float* wlds) {
+  for (int i = threadIdx.x; i < A * L.K / 4; i += HL_THREADS) {
+    const int a = (4 * i) / L.K, k = (4 * i) % L.K;
+    *reinterpret_cast<float4*>(wlds + 4 * i) =
+        *reinterpret_cast<const float4*>(L.W + (int64_t)a * L.ldw + k);
+  }
+  for (int a = threadIdx.x; a < A; a += HL_THREADS) wlds[A * L.K + a] = L.bias[a];
+}
+
+template <int KV>
+__global__ __launch_bounds__(HL_THREADS) void head_ppo_gaussian_kernel(HeadLayer L,
+                                                                       PpoLossParams p) {
+  constexpr int R = HeadRows<KV>::R;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* wlds = smem;                                  // [A][K] + bias[A]
+  float* rows = smem + p.A * L.K + ((p.A + 3) & ~3);   // [16 groups][R][A]
+  __shared__ double red[4];
+  stage_head(L, p.A, wlds);
+  __syncthreads();
+  float s = *p.log_std;
+  if (p.has_min && s < p.min_log_std) s = p.min_log_std;
+  if (p.has_max && s > p.max_log_std) s = p.max_log_std;
+  const float inv_var = expf(-2.f * s);
+  const float lognorm = s + (float)HALF_LOG_2PI;
+  const float invM = 1.f / (float)p.M;
+  const int gl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  double obj_sum = 0.0, ds_sum = 0.0;
+  // whole 16 R-row chunks so that every lane of a wave stays in the shuffles
+  const int64_t n_chunk = (p.M + 16 * R - 1) / (16 * R);
+  for (int64_t c = blockIdx.x; c < n_chunk; c += gridDim.x) {
+    int64_t irow[R], src[R];
+    bool live[R];
+    float4 h[R][KV];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      irow[r] = (c * R + r) * 16 + rg;
+      live[r] = irow[r] < p.M;
+      const int64_t row = live[r] ? irow[r] : p.M - 1;
+      src[r] = p.idx ? (int64_t)p.idx[row] : row;
+#pragma unroll
+      for (int v = 0; v < KV; ++v)
+        h[r][v] = *reinterpret_cast<const float4*>(L.H + row * L.ldh + 4 * gl + 64 * v);
+    }
+    float advr[R], oldr[R], actr[R][4];  // lane gl holds action dims gl, gl+16, ..
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      advr[r] = p.adv[src[r]];
+      oldr[r] = (p.algo == 1) ? 0.f : p.old_ll[src[r]];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int j = gl + 16 * t;
+        actr[r][t] = (j < p.A) ? p.actions[src[r] * p.lda + j] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float* rowbuf = rows + (rg * R + r) * p.A;
+      const int64_t row = live[r] ? irow[r] : p.M - 1;
+      head_row<KV>(L, p.A, wlds, h[r], row, live[r], gl, rowbuf);
+      // the 16 lanes of a group are in one wave: lane 0's LDS writes become
+      // visible to the group after the wave-level fence
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      float ll_part = 0.f, q_part = 0.f, dj[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int j = gl + 16 * t;
+        dj[t] = 0.f;
+        if (j < p.A) {
+          const float d = actr[r][t] - rowbuf[j];
+          const float z = d * d * inv_var;
+          dj[t] = d;
+          q_part += z;
+          ll_part += -0.5f * z - lognorm;
+        }
+      }
+      const float q = group16_sum(q_part);
+      const float ll = group16_sum(ll_part);
+      const float adv = advr[r];
+      float obj, g;
+      if (p.algo == 1) {
+        obj = ll * adv;
+        g = adv;
+      } else if (p.algo == 2) {
+        const float ratio = expf(ll - oldr[r]);
+        obj = ratio * adv;
+        g = obj;
+      } else {
+        const float ratio = expf(ll - oldr[r]);
+        const float lo = 1.f - p.clip, hi = 1.f + p.clip;
+        const float rc = fminf(fmaxf(ratio, lo), hi);
+        const float s1 = ratio * adv, s2 = rc * adv;
+        obj = fminf(s1, s2);
+        const float g1 = adv * ratio;
+        const float g2 = (ratio >= lo && ratio <= hi) ? adv * ratio : 0.f;
+        g = (s1 < s2) ? g1 : ((s1 > s2) ? g2 : 0.5f * (g1 + g2));
+      }
+      if (live[r]) {
+        if (p.ll_out && gl == 0) p.ll_out[irow[r]] = ll;
+        if (p.dmean) {
+          const float scale = -g * invM * inv_var;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int j = gl + 16 * t;
+            if (j < p.A) p.dmean[irow[r] * p.ldm + j] = scale * dj[t];
+          }
+        }
+        if (gl == 0) {
+          obj_sum += (double)obj;
+          ds_sum += (double)(-g * (q - (float)p.A));
+        }
+      }
+    }
+  }
+  const double o = ga_block_sum_256(obj_sum, red);
+  const double d = ga_block_sum_256(ds_sum, red);
+  if (threadIdx.x == 0) {
+    p.partials[2 * blockIdx.x + 0] = o;
+    p.partials[2 * blockIdx.x + 1] = d;
+  }
+}
+
+template <int KV>
+__global__ __launch_bounds__(HL_THREADS) void head_gaussian_nll_kernel(HeadLayer L,
+                                                                       NllParams p) {
+  constexpr int R = HeadRows<KV>::R;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* wlds = smem;                 // [1][K] + bias
+  float* rows = smem + L.K + 4;       // [16 groups][R]
+  __shared__ double red[4];
+  stage_head(L, 1, wlds);
+  __syncthreads();
+  const float s = *p.log_std;
+  const float inv_var = expf(-2.f * s);
+  const float invM = 1.f / (float)p.M;
+  const int gl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  double nll = 0.0, ds = 0.0;
+  const int64_t n_chunk = (p.M + 16 * R - 1) / (16 * R);
+  for (int64_t c = blockIdx.x; c < n_chunk; c += gridDim.x) {
+    int64_t irow[R];
+    bool live[R];
+    float4 h[R][KV];
+    float retr[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      irow[r] = (c * R + r) * 16 + rg;
+      live[r] = irow[r] < p.M;
+      const int64_t row = live[r] ? irow[r] : p.M - 1;
+      const int64_t src = p.idx ? (int64_t)p.idx[row] : row;
+#pragma unroll
+      for (int v = 0; v < KV; ++v)
+        h[r][v] = *reinterpret_cast<const float4*>(L.H + row * L.ldh + 4 * gl + 64 * v);
+      retr[r] = p.returns[src];
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float* rowbuf = rows + rg * R + r;
+      const int64_t row = live[r] ? irow[r] : p.M - 1;
+      head_row<KV>(L, 1, wlds, h[r], row, live[r], gl, rowbuf);
+      if (live[r] && gl == 0) {
+        const float d = retr[r] - rowbuf[0];
+        const float z = d * d * inv_var;
+        nll += (double)(0.5f * z + s + (float)HALF_LOG_2PI);
+        ds += (double)(1.f - z);
+        if (p.dv) p.dv[irow[r] * p.ldv] = -d * inv_var * invM;
+      }
+    }
+  }
+  const double a = ga_block_sum_256(nll, red);
+  const double b = ga_block_sum_256(ds, red);
+  if (threadIdx.x == 0) {
+    p.partials[2 * blockIdx.x + 0] = a;
+    p.partials[2 * blockIdx.x + 1] = b;
+  }
+}
+
+inline int head_blocks(int64_t M) {
+  int64_t b = (M + 63) / 64;  // rows per workgroup
+  if (b < 1) b = 1;
+  if (b > RED_BLOCKS) b = RED_BLOCKS;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" int ga_head_loss_supported(int hidden_width, int A) {
+  return (hidden_width == 64 || hidden_width == 128 || hidden_width == 256 ||
+          hidden_width == 512) && A >= 1 && A <= 64 &&
+         (int64_t)A * hidden_width * 4 <= 60 * 1024;
+}
+
+extern "C" int ga_head_ppo_gaussian_loss_f32(
+    const float* H, int64_t ldh, const float* W, int64_t ldw, const float* bias,
+    int hidden_width, float* mean_out, int64_t ldm, const float* actions, int64_t lda,
+    const float* old_ll, const float* adv, const int32_t* idx, const float* log_std,
+    int has_min, float min_log_std, int has_max, float max_log_std, int64_t M, int A,
+    int algo, float clip, float ent_coeff, int ent_flags, float* dmean, int64_t ldd,
+    float* ll_out, float* loss_out, float* grad_slab0, int64_t slab_stride,
+    int64_t n_splits, double* workspace, hipStream_t stream) {
+  GA_REQUIRE(H && W && bias && actions && adv && log_std && loss_out && workspace,
+             "ga_head_ppo_gaussian_loss_f32: null pointer");
+  GA_REQUIRE(ga_head_loss_supported(hidden_width, A),
+             "ga_head_ppo_gaussian_loss_f32: unsupported head %d x %d", A, hidden_width);
+  GA_REQUIRE(algo == 1 || old_ll, "ga_head_ppo_gaussian_loss_f32: PPO needs old_ll");
+  GA_REQUIRE(M > 0 && ldh >= hidden_width && ldh % 4 == 0 && ldw >= hidden_width &&
+                 ldw % 4 == 0 && lda >= A && (!dmean || ldd >= A) &&
+                 (!mean_out || ldm >= A) && ga_aligned16(H) && ga_aligned16(W),
+             "ga_head_ppo_gaussian_loss_f32: bad sizes / alignment");
+  HeadLayer L;
+  L.H = H; L.ldh = ldh; L.W = W; L.ldw = ldw; L.bias = bias; L.K = hidden_width;
+  L.out = mean_out; L.ldo = ldm;
+  PpoLossParams p;
+  p.mean = nullptr; p.ldm = ldd; p.actions = actions; p.lda = lda; p.old_ll = old_ll;
+  p.adv = adv; p.idx = idx; p.log_std = log_std; p.min_log_std = min_log_std;
+  p.has_min = has_min; p.max_log_std = max_log_std; p.has_max = has_max; p.M = M;
+  p.A = A; p.algo = algo; p.clip = clip; p.ent_coeff = ent_coeff;
+  p.ent_regularized = ent_flags & 1; p.ent_softplus = (ent_flags >> 1) & 1;
+  p.ent_stop_grad = (ent_flags >> 2) & 1;
+  p.dmean = dmean; p.ll_out = ll_out; p.partials = workspace;
+  const int nb = head_blocks(M);
+  const unsigned lds =
+      (unsigned)((A * hidden_width + ((A + 3) & ~3) + 16 * 4 * A) * sizeof(float));
+  switch (hidden_width / 64) {
+    case 1: hipLaunchKernelGGL(head_ppo_gaussian_kernel<1>, dim3(nb), dim3(HL_THREADS), lds, stream, L, p); break;
+    case 2: hipLaunchKernelGGL(head_ppo_gaussian_kernel<2>, dim3(nb), dim3(HL_THREADS), lds, stream, L, p); break;
+    case 4: hipLaunchKernelGGL(head_ppo_gaussian_kernel<4>, dim3(nb), dim3(HL_THREADS), lds, stream, L, p); break;
+    default: hipLaunchKernelGGL(head_ppo_gaussian_kernel<8>, dim3(nb), dim3(HL_THREADS), lds, stream, L, p); break;
+  }
+  GA_CHECK_LAUNCH("head_ppo_gaussian");
+  PpoFinalizeParams f;
+  f.partials = workspace; f.nblocks = nb; f.log_std = log_std;
+  f.min_log_std = min_log_std; f.max_log_std = max_log_std; f.has_min = has_min;
+  f.has_max = has_max; f.M = M; f.A = A; f.ent_coeff = ent_coeff;
+  f.ent_regularized = p.ent_regularized; f.ent_softplus = p.ent_softplus;
+  f.ent_stop_grad = p.ent_stop_grad; f.loss_out = loss_out;
+  f.grad_slab0 = grad_slab0; f.slab_stride = slab_stride; f.n_splits = n_splits;
+  hipLaunchKernelGGL(ppo_gaussian_finalize_kernel, dim3(1), dim3(64), 0, stream, f);
+  GA_CHECK_LAUNCH("ppo_gaussian_finalize");
+  return GA_OK;
+}
+
+extern "C" int ga_head_gaussian_nll_loss_f32(
+    const float* H, int64_t ldh, const float* W, const float* bias, int hidden_width,
+    float* v_out, int64_t ldv_out, const float* returns, const int32_t* idx,
+    const float* log_std, int64_t M, float* dv, int64_t ldd, float* loss_out,
+    float* grad_slab0, int64_t slab_stride, int64_t n_splits, double* workspace,
+    hipStream_t stream) {
+  GA_REQUIRE(H && W && bias && returns && log_std && loss_out && workspace,
+             "ga_head_gaussian_nll_loss_f32: null pointer");
+  GA_REQUIRE(ga_head_loss_supported(hidden_width, 1),
+             "ga_head_gaussian_nll_loss_f32: unsupported hidden width %d", hidden_width);
+  GA_REQUIRE(M > 0 && ldh >= hidden_width && ldh % 4 == 0 && (!dv || ldd >= 1) &&
+                 (!v_out || ldv_out >= 1) && ga_aligned16(H) && ga_aligned16(W),
+             "ga_head_gaussian_nll_loss_f32: bad sizes / alignment");
+  HeadLayer L;
+  L.H = H; L.ldh = ldh; L.W = W; L.ldw = hidden_width; L.bias = bias;
+  L.K = hidden_width; L.out = v_out; L.ldo = ldv_out;
+  NllParams p;
+  p.v = nullptr; p.ldv = ldd; p.returns = returns; p.idx = idx; p.log_std = log_std;
+  p.M = M; p.dv = dv; p.partials = workspace;
+  const int nb = head_blocks(M);
+  const unsigned lds = (unsigned)((hidden_width + 4 + 16 * 4) * sizeof(float));
+  switch (hidden_width / 64) {
+    case 1: hipLaunchKernelGGL(head_gaussian_nll_kernel<1>, dim3(nb), dim3(HL_THREADS), lds, stream, L, p); break;
+    case 2: hipLaunchKernelGGL(head_gaussian_nll_kernel<2>, dim3(nb), dim3(HL_THREADS), lds, stream, L, p); break;
+    case 4: hipLaunchKernelGGL(head_gaussian_nll_kernel<4>, dim3(nb), dim3(HL_THREADS), lds, stream, L, p); break;
+    default: hipLaunchKernelGGL(head_gaussian_nll_kernel<8>, dim3(nb), dim3(HL_THREADS), lds, stream, L, p); break;
+  }
+  GA_CHECK_LAUNCH("head_gaussian_nll");
+  hipLaunchKernelGGL(gaussian_nll_finalize_kernel, dim3(1), dim3(64), 0, stream,
+                     (const double*)workspace, nb, M, loss_out, grad_slab0,
+                     slab_stride, n_splits);
+  GA_CHECK_LAUNCH("gaussian_nll_finalize");
   return GA_OK;
 }

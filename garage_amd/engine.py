@@ -155,6 +155,26 @@ class FlatMLP:
              out.stride(0), stream_ptr())
         return out
 
+    def head_fusable(self):
+        """Can the last layer be computed inside the loss kernel
+        (``ga_head_*_loss_f32``)?"""
+        return (len(self.dims) >= 3 and bool(_lib.load().ga_head_loss_supported(
+            int(self.dims[-2]), int(self.dims[-1]))))
+
+    def forward_hidden(self, X, M, row_idx=None):
+        """Hidden layers only; returns ``(H, ldh)`` of the last hidden layer,
+        plus the device addresses of the head's weights and bias."""
+        self._workspace(M)
+        assert X.dtype == torch.float32 and X.stride(-1) == 1
+        call('ga_mlp_forward_f32', C.byref(self._desc), dptr(self.params),
+             dptr(X), X.stride(0), dptr(row_idx), M, dptr(self._acts), None,
+             self.ld_out, stream_ptr())
+        L = len(self.dims) - 1
+        ldh = round4(self.dims[-2])
+        off = self.act_off[L - 2] * self._cap
+        H = self._acts[off:off + M * ldh].view(M, ldh)
+        return H, self.params[self.w_off[L - 1]:], self.params[self.b_off[L - 1]:]
+
     def backward(self, X, M, dout, row_idx=None):
         """Slabs <- gradient of everything but the log-std slot."""
         ldx = X.stride(0)

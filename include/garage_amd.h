@@ -150,6 +150,29 @@ int ga_gaussian_nll_loss_f32(const float* v, int64_t ldv, const float* returns,
                              float* dv, float* loss_out, float* grad_slab0,
                              int64_t slab_stride, int64_t n_splits, double* workspace,
                              ga_stream_t stream);
+/* The head layer fused into the loss: H[M, ldh] are the last hidden activations,
+ * W[A][ldw] / bias[A] the head's weights (torch/modules/gaussian_mlp_module.py
+ * :288-305 output layer).  Same loss, gradient seed (dmean / dv, row stride ldd)
+ * and log-std gradient as the unfused entry points above; mean_out / v_out
+ * optionally receive the head outputs.  Supported shapes: ga_head_loss_supported.
+ * ga_set_fused_head_loss(1) makes ga_update_epoch* use them (default 0: measured
+ * equal to the head GEMM + loss kernel pair at the C3 minibatch). */
+int ga_head_loss_supported(int hidden_width, int A);
+int ga_set_fused_head_loss(int on);
+int ga_head_ppo_gaussian_loss_f32(
+    const float* H, int64_t ldh, const float* W, int64_t ldw, const float* bias,
+    int hidden_width, float* mean_out, int64_t ldm, const float* actions, int64_t lda,
+    const float* old_ll, const float* adv, const int32_t* idx, const float* log_std,
+    int has_min, float min_log_std, int has_max, float max_log_std, int64_t M, int A,
+    int algo, float clip, float ent_coeff, int ent_flags, float* dmean, int64_t ldd,
+    float* ll_out, float* loss_out, float* grad_slab0, int64_t slab_stride,
+    int64_t n_splits, double* workspace, ga_stream_t stream);
+int ga_head_gaussian_nll_loss_f32(
+    const float* H, int64_t ldh, const float* W, const float* bias, int hidden_width,
+    float* v_out, int64_t ldv_out, const float* returns, const int32_t* idx,
+    const float* log_std, int64_t M, float* dv, int64_t ldd, float* loss_out,
+    float* grad_slab0, int64_t slab_stride, int64_t n_splits, double* workspace,
+    ga_stream_t stream);
 /* sum over rows of KL(old || new), VPG._compute_kl_constraint (vpg.py:381-406) */
 int ga_gaussian_kl_f32(const float* mean_old, const float* mean_new, int64_t ld,
                        int64_t M, int A, float log_std_old, float log_std_new,

@@ -240,6 +240,100 @@ def test_streaming_layer_kernels_match_mfma_tiles(dev, shape):
                               rtol=1e-5), M
 
 
+@pytest.mark.parametrize('hidden,A', [(64, 2), (128, 1), (256, 6), (512, 17)])
+@pytest.mark.parametrize('algo', [0, 1, 2])
+def test_head_fused_into_loss_matches_unfused(dev, hidden, A, algo):
+    """``ga_head_ppo_gaussian_loss_f32`` / ``ga_head_gaussian_nll_loss_f32`` (the
+    head layer computed inside the loss kernel) against head GEMM + loss kernel:
+    means / values, loss, gradient seed, log-likelihoods and the log-std slot."""
+    from garage_amd._lib import call, dptr, stream_ptr
+    from garage_amd.engine import FlatMLP, pad_rows, reduction_workspace
+    rng = np.random.RandomState(hidden + A + algo)
+    O, n_rows = 9, 1500
+    net = FlatMLP(O, A, (32, hidden), dev)
+    net.params.copy_(torch.from_numpy(
+        (rng.randn(net.n_flat) * 0.2).astype(np.float32)))
+    for l in range(3):
+        w = net.params[net.w_off[l]:net.b_off[l]].view(net.dims[l + 1], -1)
+        w[:, net.dims[l]:] = 0
+    net.params[0] = -0.3
+    X = pad_rows(rng.randn(n_rows, O).astype(np.float32))
+    act = pad_rows(rng.randn(n_rows, A).astype(np.float32))
+    adv = torch.from_numpy(rng.randn(n_rows).astype(np.float32)).to(dev)
+    ret = torch.from_numpy(rng.randn(n_rows).astype(np.float32)).to(dev)
+    ws = reduction_workspace(dev)
+    for M, gather in ((1000, True), (37, False), (1, False)):
+        idx = None
+        if gather:
+            idx = torch.from_numpy(
+                rng.permutation(n_rows)[:M].astype(np.int32)).to(dev)
+        net._workspace(M)
+        splits = int(net._splits)
+        # old log-likelihoods: the current ones plus noise (ratios around 1)
+        mean = net.forward(X, M, row_idx=idx).clone()
+        old_ll = torch.empty(n_rows, device=dev)
+        rows = idx.long() if gather else torch.arange(M, device=dev)
+        d = act[rows, :A] - mean[:, :A]
+        s = float(net.params[0])
+        ll = (-0.5 * d * d * np.exp(-2 * s) - s - 0.9189385332).sum(1)
+        old_ll[rows] = ll + 0.1 * torch.randn(M, device=dev)
+        res = []
+        for fused in (False, True):
+            net._slabs.zero_()
+            dout = net.dout_view(M)
+            dout.zero_()
+            loss = torch.zeros(1, device=dev)
+            ll_out = torch.zeros(M, device=dev)
+            if A == 1 and algo == 0:  # the value function's NLL head
+                if fused:
+                    H, Wh, bh = net.forward_hidden(X, M, row_idx=idx)
+                    v = net.out_view(M)
+                    v.zero_()
+                    call('ga_head_gaussian_nll_loss_f32', dptr(H), H.stride(0),
+                         dptr(Wh), dptr(bh), hidden, dptr(v), v.stride(0),
+                         dptr(ret), dptr(idx), dptr(net.params[0:1]), M,
+                         dptr(dout), dout.stride(0), dptr(loss),
+                         dptr(net._slabs), net.n_flat, splits, dptr(ws),
+                         stream_ptr())
+                else:
+                    v = net.forward(X, M, row_idx=idx)
+                    call('ga_gaussian_nll_loss_f32', dptr(v), v.stride(0),
+                         dptr(ret), dptr(idx), dptr(net.params[0:1]), M,
+                         dptr(dout), dptr(loss), dptr(net._slabs), net.n_flat,
+                         splits, dptr(ws), stream_ptr())
+                head = v
+            else:
+                args = (dptr(act), act.stride(0), dptr(old_ll), dptr(adv),
+                        dptr(idx), dptr(net.params[0:1]), 1, -1.0, 0, 0.0, M,
+                        A, algo, 0.2, 0.01, 1)
+                if fused:
+                    H, Wh, bh = net.forward_hidden(X, M, row_idx=idx)
+                    head = net.out_view(M)
+                    head.zero_()
+                    call('ga_head_ppo_gaussian_loss_f32', dptr(H), H.stride(0),
+                         dptr(Wh), H.stride(0), dptr(bh), hidden, dptr(head),
+                         head.stride(0), *args, dptr(dout), dout.stride(0),
+                         dptr(ll_out), dptr(loss), dptr(net._slabs),
+                         net.n_flat, splits, dptr(ws), stream_ptr())
+                else:
+                    head = net.forward(X, M, row_idx=idx)
+                    call('ga_ppo_gaussian_loss_f32', dptr(head),
+                         head.stride(0), *args, dptr(dout), dptr(ll_out),
+                         dptr(loss), dptr(net._slabs), net.n_flat, splits,
+                         dptr(ws), stream_ptr())
+            res.append((head[:, :A].clone(), loss.clone(),
+                        dout[:, :A].clone(), ll_out.clone(),
+                        net._slabs[0].clone()))
+        (h0, l0, d0, ll0, s0), (h1, l1, d1, ll1, s1) = res
+        hs = max(1.0, float(h0.abs().max()))
+        assert torch.allclose(h0, h1, atol=5e-6 * hs), (M, 'head')
+        assert torch.allclose(l0, l1, rtol=2e-5, atol=1e-6), (M, l0, l1)
+        ds = max(1e-6, float(d0.abs().max()))
+        assert torch.allclose(d0, d1, atol=2e-4 * ds), (M, 'dout')
+        assert torch.allclose(ll0, ll1, rtol=1e-5, atol=2e-4), (M, 'll')
+        assert torch.allclose(s0, s1, rtol=2e-4, atol=1e-6), (M, s0, s1)
+
+
 def _ppo_oracle_loss(pol, obs, act, old_ll, adv, clip, algo='ppo', ent=None):
     from oracle import networks as nets
     dist = nets.gaussian_dist(pol, '_module.', obs)
