@@ -77,6 +77,7 @@ SIGNATURES = {
     'ga_gae_scan_f32': (c_int, [ptr, ptr, ptr, ptr, ptr, c_i64, c_i64, c_i64,
                                 c_i64, c_int, c_int, c_f64, c_f64, c_f32,
                                 c_f32, ptr, ptr, ptr]),
+    'ga_set_gae_fixed_fast_path': (c_int, [c_int]),
     'ga_mlp_forward_f32': (c_int, [C.POINTER(MlpDesc), ptr, ptr, c_i64, ptr,
                                    c_i64, ptr, ptr, c_i64, ptr]),
     'ga_mlp_forward_fused_f32': (c_int, [C.POINTER(MlpDesc), ptr, ptr, c_i64,

@@ -51,6 +51,10 @@ int ga_gae_scan_f32(const float* rewards, const float* values, const float* bonu
                     int max_episode_length, double discount, double gae_lambda,
                     float v0, float bonus_const, float* adv, float* ret,
                     ga_stream_t stream);
+/* Rows that are whole episodes of exactly max_episode_length steps (mode 1, no
+ * per-step bonus, T <= 256) take a constant-decay fast path; 0 forces the general
+ * kernel (A/B runs, tests). */
+int ga_set_gae_fixed_fast_path(int on);
 
 /* ---- MLP forward / backward (fp32 MFMA GEMMs) -------------------------------
  * Replaces MLPModule / MultiHeadedMLPModule.forward

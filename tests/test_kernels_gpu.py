@@ -116,6 +116,28 @@ def test_gae_scan_rollout_buffer_tails(dev):
             assert np.allclose(ret[i, t:t + L], want_ret, rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize('n,T', [(1, 4), (7, 64), (300, 128), (33, 200),
+                                 (4096, 256)])
+def test_gae_scan_fixed_horizon_fast_path_equals_general_kernel(dev, n, T):
+    """Whole episodes of exactly P steps take the constant-decay kernel; the
+    general (segmented, padded-tail aware) kernel must give the same numbers."""
+    from garage_amd import _lib
+    from garage_amd.engine import gae_scan
+    lib = _lib.load()
+    g = torch.Generator(device='cpu').manual_seed(T + n)
+    r = torch.randn(n, T, generator=g).to(dev)
+    v = torch.randn(n, T, generator=g).to(dev)
+    out = {}
+    for on in (0, 1):
+        lib.ga_set_gae_fixed_fast_path(on)
+        out[on] = gae_scan(r, v, discount=0.99, gae_lambda=0.97,
+                           max_episode_length=T, v0=0.3, bonus_const=0.05)
+    lib.ga_set_gae_fixed_fast_path(1)
+    for a, b in zip(out[0], out[1]):
+        scale = max(1.0, float(a.abs().max()))
+        assert torch.allclose(a, b, atol=2e-7 * scale, rtol=0), (n, T)
+
+
 def test_gemm_nt(dev):
     from garage_amd._lib import call, dptr, stream_ptr
     rng = np.random.RandomState(1)
