@@ -51,6 +51,15 @@ class RecordArgs(C.Structure):
                 ('terminal_only', c_i32)]
 
 
+class NormArgs(C.Structure):
+    """``ga_norm_args``."""
+    _fields_ = [('normalize_obs', c_i32), ('normalize_reward', c_i32),
+                ('obs_mean', ptr), ('obs_var', ptr), ('obs_alpha', c_f64),
+                ('reward_mean', ptr), ('reward_var', ptr),
+                ('reward_alpha', c_f64), ('reward_scale', c_f64),
+                ('raw_obs', ptr), ('raw_next_obs', ptr)]
+
+
 class UpdateArgs(C.Structure):
     """``ga_update_args``."""
     _fields_ = [('desc', C.POINTER(MlpDesc)), ('params', ptr), ('grads', ptr),
@@ -137,6 +146,8 @@ SIGNATURES = {
                                   c_i64, ptr, ptr, ptr]),
     'ga_obs_normalize_f64': (c_int, [c_i64, c_int, ptr, c_i64, ptr, ptr, c_f64,
                                      ptr, ptr]),
+    'ga_obs_normalize_from_f64': (c_int, [c_i64, c_int, ptr, ptr, c_i64, ptr,
+                                          ptr, c_f64, ptr, ptr]),
     'ga_reward_normalize_f64': (c_int, [c_i64, ptr, ptr, ptr, c_f64, c_f64,
                                         c_int, ptr]),
     'ga_policy_head_sample': (c_int, [C.POINTER(HeadArgs), ptr]),
@@ -147,10 +158,15 @@ SIGNATURES = {
     'ga_synth_env_step_record': (c_int, [C.POINTER(SynthEnv),
                                          C.POINTER(RecordArgs), ptr, c_i64, ptr,
                                          ptr]),
+    'ga_synth_env_step_record_norm': (c_int, [C.POINTER(SynthEnv),
+                                              C.POINTER(RecordArgs),
+                                              C.POINTER(NormArgs), ptr, c_i64,
+                                              ptr, ptr]),
     'ga_rollout_synth_steps': (c_int, [C.POINTER(MlpDesc), ptr,
                                        C.POINTER(HeadArgs),
                                        C.POINTER(SynthEnv),
-                                       C.POINTER(RecordArgs), ptr, ptr, c_i64,
+                                       C.POINTER(RecordArgs), ptr, ptr,
+                                       C.POINTER(NormArgs), ptr, ptr, c_i64,
                                        ptr]),
     'ga_pack_episodes': (c_int, [ptr, c_i64, c_i64, c_i64, ptr, ptr, ptr, ptr,
                                  ptr]),

@@ -139,24 +139,45 @@ __global__ __launch_bounds__(256) void synth_step_kernel(
 // variance (float64 state, alpha = 0.001 by default); the mean is updated first,
 // the variance uses the NEW mean, and the value is normalised with the updated
 // statistics.  One thread per env; rows with mask == 0 are left untouched.
-__global__ __launch_bounds__(256) void obs_normalize_kernel(
-    int64_t n, int obs_dim, float* obs, int64_t ldo, double* mean, double* var,
-    double alpha, const uint8_t* mask) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  if (mask && !mask[i]) return;
-  float* o = obs + i * ldo;
-  double* m = mean + i * obs_dim;
-  double* v = var + i * obs_dim;
+__device__ __forceinline__ void obs_normalize_one(const float* src, float* dst,
+                                                  double* m, double* v, int obs_dim,
+                                                  double alpha) {
   for (int j = 0; j < obs_dim; ++j) {
-    const double x = (double)o[j];
+    const double x = (double)src[j];
     const double mn = (1.0 - alpha) * m[j] + alpha * x;
     const double d = x - mn;
     const double vn = (1.0 - alpha) * v[j] + alpha * (d * d);
     m[j] = mn;
     v[j] = vn;
-    o[j] = (float)((x - mn) / (sqrt(vn) + 1e-8));
+    dst[j] = (float)((x - mn) / (sqrt(vn) + 1e-8));
   }
+}
+
+__device__ __forceinline__ float reward_normalize_one(float reward, double* mean,
+                                                      double* var, double alpha,
+                                                      double scale, int normalize) {
+  double r = (double)reward;
+  if (normalize) {  // normalized_env.py:126-132,153-164
+    const double mn = (1.0 - alpha) * *mean + alpha * r;
+    const double d = r - mn;
+    const double vn = (1.0 - alpha) * *var + alpha * (d * d);
+    *mean = mn;
+    *var = vn;
+    r = r / (sqrt(vn) + 1e-8);
+  }
+  return (float)(r * scale);
+}
+
+// src == dst normalises in place; otherwise the raw rows stay untouched (the
+// wrapped env keeps its own, un-normalised, state)
+__global__ __launch_bounds__(256) void obs_normalize_kernel(
+    int64_t n, int obs_dim, const float* src, float* dst, int64_t ldo, double* mean,
+    double* var, double alpha, const uint8_t* mask) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  if (mask && !mask[i]) return;
+  obs_normalize_one(src + i * ldo, dst + i * ldo, mean + i * obs_dim,
+                    var + i * obs_dim, obs_dim, alpha);
 }
 
 __global__ __launch_bounds__(256) void reward_normalize_kernel(
@@ -164,16 +185,9 @@ __global__ __launch_bounds__(256) void reward_normalize_kernel(
     int normalize) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  double r = (double)reward[i];
-  if (normalize) {  // normalized_env.py:126-132,153-164
-    const double mn = (1.0 - alpha) * mean[i] + alpha * r;
-    const double d = r - mn;
-    const double vn = (1.0 - alpha) * var[i] + alpha * (d * d);
-    mean[i] = mn;
-    var[i] = vn;
-    r = r / (sqrt(vn) + 1e-8);
-  }
-  reward[i] = (float)(r * scale);
+  reward[i] = reward_normalize_one(reward[i], normalize ? mean + i : nullptr,
+                                   normalize ? var + i : nullptr, alpha, scale,
+                                   normalize);
 }
 
 // ---- action heads --------------------------------------------------------------
@@ -354,17 +368,44 @@ __global__ __launch_bounds__(256) void record_step_kernel(RecordParams p) {
   record_counts(p, i < p.n ? record_one(p, i) : 0);
 }
 
-// env step -> bookkeeping -> reset of the envs that finished, one thread per env
-// and one launch (the three stages only touch env i's own state).
+struct NormParams {
+  int norm_obs, norm_reward, scale_reward;
+  double* obs_mean;   // [n, obs_dim]
+  double* obs_var;
+  double obs_alpha;
+  double* rew_mean;   // [n]
+  double* rew_var;
+  double rew_alpha, rew_scale;
+};
+
+// env step -> (NormalizedEnv statistics + normalisation) -> bookkeeping -> reset
+// of the envs that finished, one thread per env and one launch (every stage only
+// touches env i's own state).  `raw_obs` / `raw_next` are the env's own
+// observations; p.next_obs is what the policy sees next and what is recorded as
+// the terminal observation -- the same buffer as raw_next without normalisation.
 __global__ __launch_bounds__(256) void synth_step_record_kernel(
-    SynthEnv e, RecordParams p, const float* actions, int64_t lda, const float* obs,
-    float* next_obs, float* reward, uint8_t* step_type) {
+    SynthEnv e, RecordParams p, NormParams nm, const float* actions, int64_t lda,
+    const float* raw_obs, float* raw_next, float* seen_next, float* reward,
+    uint8_t* step_type) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   int ended_len = 0;
   if (i < e.n) {
-    synth_step_one(e, i, actions, lda, obs, next_obs, p.ldo, reward, step_type);
+    synth_step_one(e, i, actions, lda, raw_obs, raw_next, p.ldo, reward, step_type);
+    if (nm.norm_obs)  // normalized_env.py:134-151: statistics first, then the value
+      obs_normalize_one(raw_next + i * p.ldo, seen_next + i * p.ldo,
+                        nm.obs_mean + i * p.obs_dim, nm.obs_var + i * p.obs_dim,
+                        p.obs_dim, nm.obs_alpha);
+    if (nm.norm_reward || nm.scale_reward)
+      reward[i] = reward_normalize_one(reward[i], nm.rew_mean + i, nm.rew_var + i,
+                                       nm.rew_alpha, nm.rew_scale, nm.norm_reward);
     ended_len = record_one(p, i);
-    if (ended_len > 0) synth_reset_one(e, i, next_obs, p.ldo);
+    if (ended_len > 0) {
+      synth_reset_one(e, i, raw_next, p.ldo);
+      if (nm.norm_obs)
+        obs_normalize_one(raw_next + i * p.ldo, seen_next + i * p.ldo,
+                          nm.obs_mean + i * p.obs_dim, nm.obs_var + i * p.obs_dim,
+                          p.obs_dim, nm.obs_alpha);
+    }
   }
   record_counts(p, ended_len);
 }
@@ -619,10 +660,19 @@ extern "C" int ga_record_step(const ga_record_args* a, hipStream_t stream) {
   return GA_OK;
 }
 
-extern "C" int ga_synth_env_step_record(const ga_synth_env* env,
-                                        const ga_record_args* a, const float* actions,
-                                        int64_t lda, const float* obs,
-                                        hipStream_t stream) {
+struct ga_norm_args {
+  int32_t normalize_obs, normalize_reward;
+  double* obs_mean; double* obs_var; double obs_alpha;
+  double* reward_mean; double* reward_var; double reward_alpha, reward_scale;
+  const float* raw_obs;  // the wrapped env's own current observations
+  float* raw_next_obs;   // ... and where its next observations go
+};
+
+extern "C" int ga_synth_env_step_record_norm(const ga_synth_env* env,
+                                             const ga_record_args* a,
+                                             const ga_norm_args* norm,
+                                             const float* actions, int64_t lda,
+                                             const float* obs, hipStream_t stream) {
   int rc = check_env(env, "ga_synth_env_step_record");
   if (rc) return rc;
   GA_REQUIRE(a && a->reward && a->step_type && a->next_obs && a->ep_t && a->rew_buf &&
@@ -645,11 +695,41 @@ extern "C" int ga_synth_env_step_record(const ga_synth_env* env,
   p.st_buf = a->st_buf; p.tail_buf = a->tail_buf; p.lastobs_buf = a->lastobs_buf;
   p.done = a->done; p.step_eps = a->step_eps; p.step_samples = a->step_samples;
   p.terminal_only = a->terminal_only;
+  NormParams nm;
+  memset(&nm, 0, sizeof(nm));
+  const float* raw_obs = obs;
+  float* raw_next = (float*)a->next_obs;
+  if (norm) {
+    nm.norm_obs = norm->normalize_obs != 0;
+    nm.norm_reward = norm->normalize_reward != 0;
+    nm.scale_reward = norm->reward_scale != 1.0;
+    nm.obs_mean = norm->obs_mean; nm.obs_var = norm->obs_var;
+    nm.obs_alpha = norm->obs_alpha; nm.rew_mean = norm->reward_mean;
+    nm.rew_var = norm->reward_var; nm.rew_alpha = norm->reward_alpha;
+    nm.rew_scale = norm->reward_scale;
+    GA_REQUIRE(!nm.norm_obs || (nm.obs_mean && nm.obs_var && norm->raw_obs &&
+                                norm->raw_next_obs),
+               "ga_synth_env_step_record_norm: observation statistics / raw buffers");
+    GA_REQUIRE(!nm.norm_reward || (nm.rew_mean && nm.rew_var),
+               "ga_synth_env_step_record_norm: reward statistics");
+    if (nm.norm_obs) {
+      raw_obs = norm->raw_obs;
+      raw_next = norm->raw_next_obs;
+    }
+  }
   hipLaunchKernelGGL(synth_step_record_kernel, dim3((unsigned)ga_ceil_div(a->n, 256)),
-                     dim3(256), 0, stream, to_dev(env), p, actions, lda, obs,
-                     (float*)a->next_obs, (float*)a->reward, (uint8_t*)a->step_type);
+                     dim3(256), 0, stream, to_dev(env), p, nm, actions, lda, raw_obs,
+                     raw_next, (float*)a->next_obs, (float*)a->reward,
+                     (uint8_t*)a->step_type);
   GA_CHECK_LAUNCH("synth_step_record");
   return GA_OK;
+}
+
+extern "C" int ga_synth_env_step_record(const ga_synth_env* env,
+                                        const ga_record_args* a, const float* actions,
+                                        int64_t lda, const float* obs,
+                                        hipStream_t stream) {
+  return ga_synth_env_step_record_norm(env, a, nullptr, actions, lda, obs, stream);
 }
 
 extern "C" int ga_pack_episodes(const uint16_t* tail_buf, int64_t n, int64_t Tcap,
@@ -736,15 +816,25 @@ extern "C" int ga_permutation_i32(int64_t n, uint64_t key, int32_t* out,
   return GA_OK;
 }
 
+extern "C" int ga_obs_normalize_from_f64(int64_t n, int obs_dim, const float* src,
+                                         float* dst, int64_t ldo, double* mean,
+                                         double* var, double alpha,
+                                         const uint8_t* mask, hipStream_t stream) {
+  GA_REQUIRE(src && dst && mean && var, "ga_obs_normalize_from_f64: null pointer");
+  GA_REQUIRE(n > 0 && obs_dim > 0 && ldo >= obs_dim,
+             "ga_obs_normalize_from_f64: bad sizes");
+  hipLaunchKernelGGL(obs_normalize_kernel, dim3((unsigned)ga_ceil_div(n, 256)),
+                     dim3(256), 0, stream, n, obs_dim, src, dst, ldo, mean, var, alpha,
+                     mask);
+  GA_CHECK_LAUNCH("obs_normalize");
+  return GA_OK;
+}
+
 extern "C" int ga_obs_normalize_f64(int64_t n, int obs_dim, float* obs, int64_t ldo,
                                     double* mean, double* var, double alpha,
                                     const uint8_t* mask, hipStream_t stream) {
-  GA_REQUIRE(obs && mean && var, "ga_obs_normalize_f64: null pointer");
-  GA_REQUIRE(n > 0 && obs_dim > 0 && ldo >= obs_dim, "ga_obs_normalize_f64: bad sizes");
-  hipLaunchKernelGGL(obs_normalize_kernel, dim3((unsigned)ga_ceil_div(n, 256)),
-                     dim3(256), 0, stream, n, obs_dim, obs, ldo, mean, var, alpha, mask);
-  GA_CHECK_LAUNCH("obs_normalize");
-  return GA_OK;
+  return ga_obs_normalize_from_f64(n, obs_dim, obs, obs, ldo, mean, var, alpha, mask,
+                                   stream);
 }
 
 extern "C" int ga_reward_normalize_f64(int64_t n, float* reward, double* mean,

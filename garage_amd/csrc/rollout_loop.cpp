@@ -15,10 +15,17 @@ extern "C" int ga_rollout_synth_steps(const ga_mlp_desc* desc, const float* para
                                       const ga_head_args* head,
                                       const ga_synth_env* env,
                                       const ga_record_args* rec, float* obs_a,
-                                      float* obs_b, int64_t n_steps,
+                                      float* obs_b, const ga_norm_args* norm,
+                                      float* raw_a, float* raw_b, int64_t n_steps,
                                       ga_stream_t stream) {
   if (!desc || !params || !head || !env || !rec || !obs_a || !obs_b) {
     ga_set_error("ga_rollout_synth_steps: null pointer");
+    return -1;
+  }
+  const bool norm_obs = norm && norm->normalize_obs;
+  if (norm_obs && (!raw_a || !raw_b)) {
+    ga_set_error("ga_rollout_synth_steps: observation normalisation needs the raw "
+                 "observation buffers");
     return -1;
   }
   if (n_steps < 0 || head->col + n_steps > head->Tcap) {
@@ -31,8 +38,12 @@ extern "C" int ga_rollout_synth_steps(const ga_mlp_desc* desc, const float* para
   }
   float* cur = obs_a;
   float* nxt = obs_b;
+  float* raw_cur = raw_a;
+  float* raw_nxt = raw_b;
   ga_head_args h = *head;
   ga_record_args r = *rec;
+  ga_norm_args nm;
+  if (norm) nm = *norm;
   for (int64_t s = 0; s < n_steps; ++s) {
     h.col = head->col + s;
     h.step = head->step + (uint32_t)s;
@@ -42,11 +53,19 @@ extern "C" int ga_rollout_synth_steps(const ga_mlp_desc* desc, const float* para
     // env step -> bookkeeping -> reset of the finished envs: one launch
     r.col = h.col;
     r.next_obs = nxt;
-    rc = ga_synth_env_step_record(env, &r, h.action, h.lda, cur, stream);
+    if (norm) {
+      nm.raw_obs = raw_cur;
+      nm.raw_next_obs = raw_nxt;
+    }
+    rc = ga_synth_env_step_record_norm(env, &r, norm ? &nm : nullptr, h.action, h.lda,
+                                       cur, stream);
     if (rc) return rc;
     float* t = cur;
     cur = nxt;
     nxt = t;
+    t = raw_cur;
+    raw_cur = raw_nxt;
+    raw_nxt = t;
   }
   return 0;
 }

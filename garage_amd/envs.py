@@ -57,6 +57,11 @@ class VecEnv:
         """Make ``next_obs`` the current observation (buffer swap)."""
         self.obs, self.next_obs = self.next_obs, self.obs
 
+    def hold(self):
+        """Carry the current observations over as the next ones (before a
+        partial ``reset_where``: rows that are not reset keep their state)."""
+        self.next_obs.copy_(self.obs)
+
     def reset_all(self):
         raise NotImplementedError
 
@@ -180,30 +185,47 @@ class NormalizedVecEnv(VecEnv):
         self._obs_var = torch.ones(n, O, dtype=torch.float64, device=dev)
         self._reward_mean = torch.zeros(n, dtype=torch.float64, device=dev)
         self._reward_var = torch.ones(n, dtype=torch.float64, device=dev)
+        # the wrapped env keeps its own (raw) observations -- its dynamics must
+        # not see the normalised ones, exactly as the inner env of the
+        # reference's wrapper does not; the policy reads these
+        if self._normalize_obs:
+            self._obs = torch.zeros_like(env.obs)
+            self._next_obs = torch.zeros_like(env.next_obs)
 
-    # the wrapped env owns the buffers; expose them under the protocol names
-    obs = property(lambda self: self._env.obs)
-    next_obs = property(lambda self: self._env.next_obs)
+    # buffers under the protocol names: normalised copies when observations are
+    # normalised, else the wrapped env's own
+    obs = property(lambda self: self._obs if self._normalize_obs
+                   else self._env.obs)
+    next_obs = property(lambda self: self._next_obs if self._normalize_obs
+                        else self._env.next_obs)
     reward = property(lambda self: self._env.reward)
     step_type = property(lambda self: self._env.step_type)
     env_id0 = property(lambda self: getattr(self._env, 'env_id0', 0))
 
     def advance(self):
         self._env.advance()
-
-    def _norm(self, buf, mask=None):
         if self._normalize_obs:
-            call('ga_obs_normalize_f64', self.n_envs, self.obs_dim, dptr(buf),
-                 buf.stride(0), dptr(self._obs_mean), dptr(self._obs_var),
-                 self._obs_alpha, dptr(mask), stream_ptr())
+            self._obs, self._next_obs = self._next_obs, self._obs
+
+    def hold(self):
+        self._env.hold()
+        if self._normalize_obs:
+            self._next_obs.copy_(self._obs)
+
+    def _norm(self, src, dst, mask=None):
+        if self._normalize_obs:
+            call('ga_obs_normalize_from_f64', self.n_envs, self.obs_dim,
+                 dptr(src), dptr(dst), src.stride(0), dptr(self._obs_mean),
+                 dptr(self._obs_var), self._obs_alpha, dptr(mask),
+                 stream_ptr())
 
     def reset_all(self):
         self._env.reset_all()
-        self._norm(self._env.obs)
+        self._norm(self._env.obs, self.obs)
 
     def step_all(self, actions):
         self._env.step_all(actions)
-        self._norm(self._env.next_obs)
+        self._norm(self._env.next_obs, self.next_obs)
         if self._normalize_reward or self._scale_reward != 1.0:
             call('ga_reward_normalize_f64', self.n_envs,
                  dptr(self._env.reward), dptr(self._reward_mean),
@@ -213,7 +235,23 @@ class NormalizedVecEnv(VecEnv):
 
     def reset_where(self, done):
         self._env.reset_where(done)
-        self._norm(self._env.next_obs, done)
+        self._norm(self._env.next_obs, self.next_obs, done)
+
+    def norm_args(self):
+        """``ga_norm_args`` for the fused env-step kernel (raw buffers are
+        filled in by the caller)."""
+        from garage_amd import _lib
+        a = _lib.NormArgs()
+        a.normalize_obs = int(self._normalize_obs)
+        a.normalize_reward = int(self._normalize_reward)
+        a.obs_mean, a.obs_var = (self._obs_mean.data_ptr(),
+                                 self._obs_var.data_ptr())
+        a.obs_alpha = self._obs_alpha
+        a.reward_mean, a.reward_var = (self._reward_mean.data_ptr(),
+                                       self._reward_var.data_ptr())
+        a.reward_alpha, a.reward_scale = (self._reward_alpha,
+                                          self._scale_reward)
+        return a
 
     def close(self):
         self._env.close()

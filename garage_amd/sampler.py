@@ -185,7 +185,7 @@ class GpuVecWorker:
         else:
             # only environments with progress are reset (vec_worker.py:122-126)
             progress = (self._ep_t > 0).to(torch.uint8)
-            self.env.next_obs.copy_(self.env.obs)
+            self.env.hold()
             self.env.reset_where(progress)
             self.env.advance()
             self._ep_t.zero_()
@@ -267,17 +267,23 @@ class GpuVecWorker:
     def _native_steps(self, b, col, n_steps):
         """``n_steps`` steps enqueued by ``ga_rollout_synth_steps`` (synthetic
         env, fused policy step, device RNG); False when not applicable."""
-        from garage_amd.envs import SyntheticVecEnv
+        from garage_amd.envs import NormalizedVecEnv, SyntheticVecEnv
         env = self.env
-        if (n_steps <= 0 or type(env) is not SyntheticVecEnv
+        inner, norm = env, None
+        if type(env) is NormalizedVecEnv:  # statistics fused into the env step
+            inner, norm = env._env, env.norm_args()
+        if (n_steps <= 0 or type(inner) is not SyntheticVecEnv
                 or self._noise_fn is not None or not self._fused_ok()):
             return False
         a = self._head_args(b, col, True)
         r = self._record_args(b, col)
+        raw = norm is not None and norm.normalize_obs
         call('ga_rollout_synth_steps', C.byref(self.agent.net._desc),
-             dptr(self.agent.net.params), C.byref(a), C.byref(env._c),
-             C.byref(r), dptr(env.obs), dptr(env.next_obs), n_steps,
-             stream_ptr())
+             dptr(self.agent.net.params), C.byref(a), C.byref(inner._c),
+             C.byref(r), dptr(env.obs), dptr(env.next_obs),
+             None if norm is None else C.byref(norm),
+             dptr(inner.obs) if raw else None,
+             dptr(inner.next_obs) if raw else None, n_steps, stream_ptr())
         if n_steps % 2:
             env.advance()
         self._global_step += n_steps

@@ -246,6 +246,11 @@ int ga_synth_env_step(const ga_synth_env* env, const float* actions, int64_t lda
 int ga_obs_normalize_f64(int64_t n, int obs_dim, float* obs, int64_t ldo,
                          double* mean, double* var, double alpha,
                          const uint8_t* mask, ga_stream_t stream);
+/* The same from src into dst: the wrapped env keeps its own (raw) observations,
+ * as the inner env of the reference's NormalizedEnv does. */
+int ga_obs_normalize_from_f64(int64_t n, int obs_dim, const float* src, float* dst,
+                              int64_t ldo, double* mean, double* var, double alpha,
+                              const uint8_t* mask, ga_stream_t stream);
 int ga_reward_normalize_f64(int64_t n, float* reward, double* mean, double* var,
                             double alpha, double scale, int normalize,
                             ga_stream_t stream);
@@ -296,16 +301,40 @@ int ga_record_step(const ga_record_args* args, ga_stream_t stream);
 int ga_synth_env_step_record(const ga_synth_env* env, const ga_record_args* rec,
                              const float* actions, int64_t lda, const float* obs,
                              ga_stream_t stream);
+/* ... with NormalizedEnv's observation / reward normalisation fused in (the
+ * north star's "fused obs-normalise"): the env steps on its raw observations
+ * (raw_obs -> raw_next_obs), the moving statistics are updated and
+ * rec->next_obs receives the normalised observation the policy sees next -- for
+ * the step's observation (recorded as the terminal one where an episode ends)
+ * and again for the first observation of a new episode, in that order, as
+ * envs/normalized_env.py:134-151 does.  norm == NULL: no normalisation. */
+typedef struct ga_norm_args {
+  int32_t normalize_obs, normalize_reward;
+  double* obs_mean;      /* [n, obs_dim] float64 moving mean */
+  double* obs_var;
+  double obs_alpha;
+  double* reward_mean;   /* [n] */
+  double* reward_var;
+  double reward_alpha, reward_scale;
+  const float* raw_obs;  /* [n, ldo] the wrapped env's current observations */
+  float* raw_next_obs;   /* [n, ldo] where its next observations go */
+} ga_norm_args;
+int ga_synth_env_step_record_norm(const ga_synth_env* env, const ga_record_args* rec,
+                                  const ga_norm_args* norm, const float* actions,
+                                  int64_t lda, const float* obs, ga_stream_t stream);
 
 /* n_steps consecutive vectorised steps (fused policy step, synthetic env step,
  * bookkeeping, reset of finished envs) starting at head->col / head->step,
  * alternating the observation buffers obs_a (current) / obs_b; after an odd
  * number of steps the current observations are in obs_b.  The while-loop body of
  * VecWorker.rollout (sampler/default_worker.py:176-186 + vec_worker.py:176-204)
- * enqueued natively. */
+ * enqueued natively.  With norm != NULL (NormalizedEnv around the synthetic env)
+ * obs_a / obs_b hold the normalised observations and raw_a / raw_b, alternating
+ * the same way, the env's own. */
 int ga_rollout_synth_steps(const ga_mlp_desc* desc, const float* params,
                            const ga_head_args* head, const ga_synth_env* env,
                            const ga_record_args* rec, float* obs_a, float* obs_b,
+                           const ga_norm_args* norm, float* raw_a, float* raw_b,
                            int64_t n_steps, ga_stream_t stream);
 
 /* EpisodeBatch.concatenate in completion order (sampler/vec_worker.py:206-219,

@@ -41,7 +41,12 @@ def test_normalised_rollout_runs_through_the_sampler():
                            normalize_obs=True, scale_reward=0.5)
     dev = env.device
     norms = [NormalizedObs(O) for _ in range(n)]
+    # non-zero actions: the reward depends on the env's own observation, which
+    # must stay the raw one inside the wrapper (normalized_env.py:134-151 steps
+    # the inner env, then normalises what it returned)
     act = torch.zeros(n, 4, device=dev)
+    act[:, 0] = 0.7
+    act[:, 1] = -0.4
     raw.reset_all()
     env.reset_all()
     want = np.stack([norms[i](raw.obs[i, :O].cpu().numpy()) for i in range(n)])

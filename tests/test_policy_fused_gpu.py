@@ -64,12 +64,13 @@ def test_fused_step_matches_per_layer_path(discrete, O, A, hidden, n):
         assert np.allclose(a.rewards, b.rewards, atol=2e-6)
 
 
+@pytest.mark.parametrize('normalize', [False, True])
 @pytest.mark.parametrize('ragged', [False, True])
-def test_native_rollout_loop_equals_python_driven_steps(ragged):
+def test_native_rollout_loop_equals_python_driven_steps(ragged, normalize):
     """ga_rollout_synth_steps enqueues the same launches as GpuVecWorker._step:
     with the device RNG both give bit-identical batches, twice in a row (the
     second call exercises the partial reset and the odd/even buffer parity)."""
-    from garage_amd.envs import SyntheticVecEnv
+    from garage_amd.envs import NormalizedVecEnv, SyntheticVecEnv
     from garage_amd.policies import GaussianMLPPolicy
     from garage_amd.sampler import GpuVecSampler, GpuVecWorker
 
@@ -83,6 +84,10 @@ def test_native_rollout_loop_equals_python_driven_steps(ragged):
     for cls in (GpuVecWorker, PythonSteps):
         torch.manual_seed(4)
         env = SyntheticVecEnv(n, O, A, P, min_len=3 if ragged else None, seed=8)
+        if normalize:  # statistics + normalisation fused into the env step
+            env = NormalizedVecEnv(env, normalize_obs=True,
+                                   normalize_reward=True, scale_reward=0.5,
+                                   obs_alpha=0.05, reward_alpha=0.05)
         pol = GaussianMLPPolicy(env.spec, hidden_sizes=(32, 32))
         sampler = GpuVecSampler(pol, env, max_episode_length=P, n_workers=1,
                                 seed=3, worker_class=cls,
@@ -95,6 +100,7 @@ def test_native_rollout_loop_equals_python_driven_steps(ragged):
         assert np.array_equal(a.actions, b.actions)
         assert np.array_equal(a.rewards, b.rewards)
         assert np.array_equal(a.last_observations, b.last_observations)
+        assert np.isfinite(a.observations).all() and a.lengths.sum() > 0
         assert np.array_equal([int(s) for s in a.step_types],
                               [int(s) for s in b.step_types])
 
