@@ -472,6 +472,111 @@ class VPG:
         self._normalise_advantages(flat)
         return flat
 
+    # -- the reference's evaluation helpers, same names and argument order ----
+    # (vpg.py:295-347,381-455; ppo.py:96-132; trpo.py:93-119).  They take host or
+    # device tensors, run the same kernels as the training path and return
+    # device tensors WITHOUT autograd history: gradients exist only inside
+    # _train_policy / _train_value_function, so callers that differentiate
+    # through these (MAML's inner loop) are out of scope.
+    class _Rows:
+        """The two fields of a batch the loss pass reads."""
+
+        def __init__(self, obs_dev, actions_dev):
+            self.obs_dev, self.actions_dev = obs_dev, actions_dev
+
+    def _rows(self, obs, actions=None):
+        obs = torch.as_tensor(obs)
+        lead = tuple(obs.shape[:-1]) if obs.dim() > 1 else (obs.shape[0], )
+        O = self.policy.net.in_dim
+        obs_dev = pad_rows(obs.reshape(-1, O))
+        act_dev = None
+        if actions is not None:
+            actions = torch.as_tensor(actions)
+            act_dev = pad_rows(actions.reshape(obs_dev.shape[0], -1))
+        return self._Rows(obs_dev, act_dev), obs_dev.shape[0], lead
+
+    def _log_likelihoods(self, rows, M, params=None):
+        ll = torch.empty(M, dtype=torch.float32, device=self.policy.device)
+        zeros = torch.zeros(M, dtype=torch.float32, device=self.policy.device)
+        self._policy_loss_pass(rows, zeros, None, M, None, params=params,
+                               ll_out=ll)
+        return ll
+
+    def _compute_objective(self, advantages, obs, actions, rewards):
+        """``vpg.py:434-455`` (``ppo.py:96-132`` / ``trpo.py:93-119`` by
+        ``_algo_id``): per-sample objective values, shape ``(M,)``."""
+        del rewards
+        rows, M, _ = self._rows(obs, actions)
+        adv = torch.as_tensor(advantages).to(self.policy.device,
+                                             torch.float32).reshape(-1)
+        new_ll = self._log_likelihoods(rows, M)
+        if self._algo_id == 1:
+            return new_ll * adv
+        old_ll = self._log_likelihoods(rows, M, params=self._old_policy.params)
+        ratio = (new_ll - old_ll).exp()
+        if self._algo_id == 2:
+            return ratio * adv
+        clipped = torch.clamp(ratio, min=1 - self._lr_clip_range,
+                              max=1 + self._lr_clip_range)
+        return torch.min(ratio * adv, clipped * adv)
+
+    def _compute_policy_entropy(self, obs):
+        """``vpg.py:408-432``: entropies with the leading shape of ``obs``."""
+        rows, M, lead = self._rows(obs)
+        dev = self.policy.device
+        if self.policy.kind == 'gaussian':
+            return torch.full(lead, self._entropy_value(), dtype=torch.float32,
+                              device=dev)
+        ent = torch.empty(M, dtype=torch.float32, device=dev)
+        rows.actions_dev = torch.zeros(M, 4, dtype=torch.float32, device=dev)
+        self._policy_loss_pass(rows, torch.zeros(M, device=dev), None, M, None,
+                               ent_out=ent)
+        return ent.reshape(lead)
+
+    def _compute_loss_with_adv(self, obs, actions, rewards, advantages):
+        """``vpg.py:324-347``: the scalar the policy step minimises."""
+        del rewards
+        rows, M, _ = self._rows(obs, actions)
+        adv = torch.as_tensor(advantages).to(self.policy.device,
+                                             torch.float32).reshape(-1)
+        old_ll = None
+        if self._algo_id != 1:
+            old_ll = self._log_likelihoods(rows, M,
+                                           params=self._old_policy.params)
+        loss, _, _ = self._policy_loss_pass(rows, adv.contiguous(), old_ll, M,
+                                            None)
+        return loss[0]
+
+    def _compute_loss(self, obs, actions, rewards, valids, baselines):
+        """``vpg.py:295-322`` on padded ``(N, P, ...)`` inputs."""
+        from garage_amd.functions import filter_valids
+        obs, actions = torch.as_tensor(obs), torch.as_tensor(actions)
+        rewards = torch.as_tensor(rewards)
+        obs_flat = torch.cat(filter_valids(obs, valids))
+        actions_flat = torch.cat(filter_valids(actions, valids))
+        rewards_flat = torch.cat(filter_valids(rewards, valids))
+        adv = self._compute_advantage(rewards, valids, baselines)
+        return self._compute_loss_with_adv(obs_flat, actions_flat,
+                                           rewards_flat, adv)
+
+    def _compute_kl_constraint(self, obs):
+        """``vpg.py:381-406``: mean KL(old || new) over every row of ``obs``."""
+        rows, M, _ = self._rows(obs)
+        pol = self.policy
+        net = pol.net
+        saved, net.params = net.params, self._old_policy.params
+        try:
+            head_old = net.forward(rows.obs_dev, M).clone()
+        finally:
+            net.params = saved
+        head_new = net.forward(rows.obs_dev, M)
+        s_old = s_new = 0.0
+        if pol.kind == 'gaussian':
+            s_old = self._clamped(self._old_policy.params)
+            s_new = pol.clamped_log_std()
+        kl = self._kl_sum(head_old, s_old, head_new, s_new, M)
+        return (kl[0] / M).to(torch.float32)
+
     # -- the update (vpg.py:230-293) -------------------------------------------
     def _train(self, batch, adv, returns, old_ll):
         S = batch.n_samples
