@@ -921,6 +921,7 @@ class TRPO(VPG):
                 '(trpo.py:64-66 default wrapper)')
         self._algo_id = 2  # unclipped surrogate in the loss kernel
         self.last_cg = {}
+        self._trpo_share = 1.0  # this rank's share of the global batch
 
     # -- update (vpg.py:230-248 with the constrained policy step) ---------------
     def _train(self, batch, adv, returns, old_ll):
@@ -965,8 +966,13 @@ class TRPO(VPG):
              net.out_dim, dptr(net.params[0:1]), has_min, mn, has_max, mx,
              dptr(dout), dout.stride(0), stream_ptr())
         net.backward(batch.obs_dev, M, dout)
-        net.reduce_grads()
+        # the seed divides by this rank's M: rescale to the global batch, then
+        # sum the ranks' J^T M J v (vec is replicated, so every rank ends up
+        # with the same product)
+        net.reduce_grads(scale=self._trpo_share)
         g = net.grads
+        if self._comm is not None:
+            self._comm.all_reduce(g, 'sum')
         # the log-std block: d2/ds2 of sum_a [s - s_old + exp(2(s_old - s))/2]
         # = 2 A at s == s_old, through the clamp's pass-through gradient
         s_raw = float(net.params[0].item())
@@ -985,25 +991,31 @@ class TRPO(VPG):
         """``trpo.py:121-144`` + ``ConjugateGradientOptimizer.step``
         (``conjugate_gradient_optimizer.py:146-186,236-277``)."""
         assert idx is None
-        if self._comm is not None:
-            raise NotImplementedError(
-                'TRPO is single-GPU in this round (the conjugate-gradient '
-                'vectors would need one all-reduce per Fisher product)')
         pol = self.policy
         net = pol.net
         hyper = self._policy_optimizer._hyper
         M = batch.n_samples
         dev = net.device
         n = net.n_flat
+        # data parallel: this rank's share of the global batch (1.0 alone); the
+        # global mean loss / gradient / KL are share-weighted sums over ranks
+        share, M_glob = 1.0, M
+        if self._comm is not None:
+            counts = self._comm.all_gather_int(M, device=dev)
+            M_glob = int(sum(counts))
+            share = M / float(M_glob)
+        self._trpo_share = share
         # gradient of the surrogate loss (flat_loss_grads)
         loss0, mean_old, dout = self._policy_loss_pass(batch, adv, old_ll, M,
                                                        None, want_grad=True)
         mean_old = mean_old.clone()
         s_old = pol.clamped_log_std()
         net.backward(batch.obs_dev, M, dout)
-        net.reduce_grads()
+        net.reduce_grads(scale=share)
         if not getattr(pol, '_learn_std', True):
             net.grads[0:1].zero_()
+        if self._comm is not None:
+            self._comm.all_reduce(net.grads, 'sum')
         b = net.grads.clone()
 
         # conjugate gradient (Demmel p. 312), conjugate_gradient_optimizer.py:69-104
@@ -1037,7 +1049,15 @@ class TRPO(VPG):
 
         # backtracking line search, conjugate_gradient_optimizer.py:236-277
         prev = net.params.clone()
-        loss_before = float(loss0.item())
+
+        def global_mean(local_mean):
+            if self._comm is None:
+                return float(local_mean.item())
+            t = local_mean.double().reshape(1) * share
+            self._comm.all_reduce(t, 'sum')
+            return float(t.item())
+
+        loss_before = global_mean(loss0)
         accepted = -1
         loss = constraint = float('nan')
         for k in range(int(hyper['max_backtracks'])):
@@ -1047,10 +1067,11 @@ class TRPO(VPG):
                  dptr(net.params), n, stream_ptr())
             l_new, mean_new, _ = self._policy_loss_pass(batch, adv, old_ll, M,
                                                         None)
-            loss = float(l_new.item())
+            loss = global_mean(l_new)
             kl = self._kl_sum(mean_old, s_old, mean_new,
                               pol.clamped_log_std(), M)
-            constraint = float(kl.item()) / float(M)
+            self._allreduce(kl)
+            constraint = float(kl.item()) / float(M_glob)
             if (loss < loss_before
                     and constraint <= hyper['max_constraint_value']):
                 accepted = k
