@@ -296,14 +296,14 @@ def main():
         'dtype': 'f32',
         'data': 'synthetic',
         'config': {
-            'workload': '{}: obs {} act {}, {} envs/GPU x T={}, '
-                        'MLP{} policy + value, ' + ('PPO' if args.algo == 'ppo' else
-                                                    'TRPO (CG policy step) + value') +
-                        ' E={} x {} minibatches, '
-                        'gamma {} lambda {} clip {} Adam lr {}, device '
-                        'minibatch permutation, policy/value passes {}'.format(
+            'workload': ('{}: obs {} act {}, {} envs/GPU x T={}, '
+                         'MLP{} policy + value, {} E={} x {} minibatches, '
+                         'gamma {} lambda {} clip {} Adam lr {}, device '
+                         'minibatch permutation, policy/value passes {}').format(
                             cfg['name'], cfg['obs_dim'], cfg['act_dim'],
                             cfg['n_envs'], cfg['T'], cfg['hidden'],
+                            'PPO' if args.algo == 'ppo' else
+                            'TRPO (CG policy step) + value',
                             HYPER['epochs'], HYPER['minibatches_per_epoch'],
                             HYPER['discount'], HYPER['gae_lambda'],
                             HYPER['lr_clip_range'], HYPER['lr'],
