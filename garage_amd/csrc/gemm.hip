@@ -397,6 +397,15 @@ int launch_gemm(const GemmParams& p_in, int splits, hipStream_t stream) {
     // latency-bound shapes and measured no better than 32: one workgroup per CU)
     hipExtLaunchKernelGGL((gemm_f32_kernel<128, 32, 4, 1, A_KC, B_KC>), grid,
                           dim3(256), 0, stream, e0, e1, 0, p);
+  } else if (p.N <= 64) {
+    // 33..64 wide outputs (the 64-unit layers of the CartPole-shaped config): a
+    // 128x128 tile would be half empty and give M/128 workgroups; 64x64 tiles
+    // (4 waves, one 32x32 accumulator each) give 4x as many
+    p.gx = (int)ga_ceil_div(p.M, 64); p.gy = 1; p.gz = splits;
+    dim3 grid((unsigned)(p.gx * p.gy * p.gz));
+    ga_prof_events(GA_PROF_GEMM_NT_128 + mode, flops, &e0, &e1);
+    hipExtLaunchKernelGGL((gemm_f32_kernel<64, 64, 2, 2, A_KC, B_KC>), grid, dim3(256),
+                          0, stream, e0, e1, 0, p);
   } else {
     p.gx = (int)ga_ceil_div(p.M, 128); p.gy = (int)ga_ceil_div(p.N, 128); p.gz = splits;
     dim3 grid((unsigned)(p.gx * p.gy * p.gz));
@@ -528,12 +537,16 @@ extern "C" int ga_mlp_forward_f32(const ga_mlp_desc* d, const float* params,
 }
 
 extern "C" int64_t ga_mlp_backward_splits(const ga_mlp_desc* d, int64_t M) {
-  (void)d;
   // Rows of the batch each weight-gradient workgroup reduces before writing a
   // slab: large enough to amortise the slab write, small enough to fill 256 CUs.
   // 256 rows per slab: the widest layer (256x256 -> 2x2 tiles) then launches
   // 4 * M/256 workgroups, i.e. 512 at the C3 minibatch of 32768 rows.
   int64_t s = ga_ceil_div(M, 256);
+  // nets whose layers are all <= 64 wide have one weight-gradient tile per split:
+  // 128-row slabs double the workgroups (their slabs are a few KB each)
+  bool small = true;
+  for (int l = 0; l <= d->n_layers; ++l) small = small && d->dims[l] <= 64;
+  if (small) s = ga_ceil_div(M, 128);
   if (s < 1) s = 1;
   if (s > 128) s = 128;
   return s;
