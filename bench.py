@@ -223,6 +223,9 @@ def main():
     ap.add_argument('--cpu-envs', type=int, default=1024,
                     help='envs of the bounded CPU-baseline sample (0: skip)')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--fuse-head', action='store_true',
+                    help='compute the head layer inside the loss kernel '
+                    '(opt-in; measured neutral at C3)')
     ap.add_argument('--algo', default='ppo', choices=['ppo', 'trpo'],
                     help='trpo: the section-8f.1 widening (conjugate-gradient '
                     'policy step), reported under its own metric name')
@@ -241,6 +244,7 @@ def main():
     cfg = CONFIGS[args.config]
     algo, sampler, pol, S = build_engine(cfg, comm, algo_name=args.algo)
     algo.overlap_updates = not args.no_overlap
+    algo.fuse_head = bool(args.fuse_head)
 
     def sync():
         if comm is not None:
