@@ -14,10 +14,16 @@
 // base (garage_amd pads obs / weights / activations accordingly), so all
 // global traffic is 16-B vector loads; ragged edges are masked, not branched.
 //
-// Operand tiles live in LDS as [BK][BR + 4] (k-major, +4 floats keeps rows
-// 16-B aligned and the per-instruction 32-lane reads on distinct banks): the
-// MFMA A operand of lane l is tile[2*kk + (l >> 5)][row0 + (l & 31)] and B is
-// read the same way, one ds_read_b32 each.
+// Operand tiles keep their memory orientation in LDS.  A k-contiguous operand is
+// stored [BR][BK + 4] (one ds_write_b128 per loaded vector) and feeds four MFMAs
+// from one ds_read_b128: lane l of a 32x32x2 MFMA holds row l & 31 and, in MFMA q
+// of group g, k = 8g + 4(l >> 5) + q -- any k <-> slot map is valid as long as A
+// and B agree.  A row-contiguous operand is stored [BK][BR + 4] and read with one
+// ds_read_b32 per MFMA under the same map.  The +4 floats keep rows 16-B aligned
+// and the 32-lane reads of an instruction on distinct banks (SQ_LDS_BANK_CONFLICT
+// = 0 by PMC).  Tile shapes: 128x128 (8 waves, two workgroups per CU), 64x64 for
+// 33..64-wide outputs, 128x32 for narrow ones; the products with a dimension
+// <= 32 that stream a whole activation matrix go to skinny.hip instead.
 #include "common.h"
 #include <hip/hip_ext.h>
 
