@@ -59,8 +59,10 @@ def init_gaussian_mlp(rng, prefix, in_dim, out_dim, hidden_sizes,
 
 
 def trainable_keys(params):
-    """Everything but the registered buffer (``min_std_param``)."""
-    return [k for k in params if not k.endswith('min_std_param')]
+    """Everything but the registered buffers (``min_std_param``,
+    ``max_std_param`` and, with ``learn_std=False``, ``init_std``)."""
+    return [k for k in params
+            if not k.endswith(('min_std_param', 'max_std_param', '.init_std'))]
 
 
 def n_hidden(params, prefix):
@@ -85,10 +87,16 @@ def mlp_mean(params, prefix, x):
 def gaussian_dist(params, prefix, x):
     """``GaussianMLPBaseModule.forward`` (``gaussian_mlp_module.py:158-192``)."""
     mean = mlp_mean(params, prefix, x)
-    log_std = torch.zeros(*mean.shape) + params[prefix + '_init_std']
-    key = prefix + 'min_std_param'
-    if key in params:
-        log_std = log_std.clamp(min=params[key].item())
+    # learn_std=False registers the log-std as the buffer ``init_std`` instead of
+    # the parameter ``_init_std`` (gaussian_mlp_module.py:124-130)
+    std_key = prefix + ('_init_std' if prefix + '_init_std' in params
+                        else 'init_std')
+    log_std = torch.zeros(*mean.shape) + params[std_key]
+    lo, hi = prefix + 'min_std_param', prefix + 'max_std_param'
+    if lo in params or hi in params:  # gaussian_mlp_module.py:171-176
+        log_std = log_std.clamp(
+            min=params[lo].item() if lo in params else None,
+            max=params[hi].item() if hi in params else None)
     return Independent(Normal(mean, log_std.exp()), 1)
 
 

@@ -513,6 +513,61 @@ def gen_trpo():
     save('trpo_train_once', **out)
 
 
+def gen_policy_options():
+    """``GaussianMLPPolicy`` std options through two real PPO iterations:
+    fixed std, an active max clamp, an active min clamp, a small learned std
+    (``torch/modules/gaussian_mlp_module.py:124-137,158-192``)."""
+    cases = [
+        dict(tag='fixed_std', pol=dict(learn_std=False, init_std=0.7)),
+        dict(tag='max_clamp', pol=dict(max_std=0.5, init_std=1.0)),
+        dict(tag='min_clamp', pol=dict(min_std=0.2, init_std=0.1)),
+        dict(tag='init_small', pol=dict(init_std=0.3)),
+    ]
+    out = {}
+    for case in cases:
+        tag = case['tag']
+        O, A, P, hs = 4, 2, 8, (8, 8)
+        E, mb = 2, 5
+        spec = EnvSpec(akro.Box(-np.inf, np.inf, (O, )),
+                       akro.Box(-np.inf, np.inf, (A, )),
+                       max_episode_length=P)
+        torch.manual_seed(17)
+        rng = np.random.RandomState(17)
+        pol = GaussianMLPPolicy(spec, hidden_sizes=hs, **case['pol'])
+        vf = GaussianMLPValueFunction(spec, hidden_sizes=hs)
+        out.update(state_arrays(tag + '_pol0:', pol))
+        out.update(state_arrays(tag + '_vf0:', vf))
+        algo = PPO(env_spec=spec, policy=pol, value_function=vf, sampler=None,
+                   policy_optimizer=OptimizerWrapper(
+                       (torch.optim.Adam, dict(lr=2.5e-3)), pol,
+                       max_optimization_epochs=E, minibatch_size=mb),
+                   vf_optimizer=OptimizerWrapper(
+                       (torch.optim.Adam, dict(lr=2.5e-3)), vf,
+                       max_optimization_epochs=E, minibatch_size=mb))
+        rec = ref.TabularRecorder()
+        vpg_mod.tabular = rec
+        gfun.tabular = rec
+        for it in range(2):
+            lens = [8, 3, 5, 8, 1, 6] if it == 0 else [2, 8, 7, 4]
+            eps = make_ragged_batch(rng, spec, lens, O, A)
+            np.random.seed(300 + it)
+            algo._train_once(it, eps)
+            pre = '%s_it%d_' % (tag, it)
+            out[pre + 'observations'] = eps.observations
+            out[pre + 'actions'] = eps.actions
+            out[pre + 'rewards'] = eps.rewards
+            out[pre + 'lengths'] = eps.lengths
+            out[pre + 'step_types'] = np.asarray(
+                [int(s) for s in eps.step_types])
+            out[pre + 'np_seed'] = np.asarray(300 + it)
+            for k, v in rec.values.items():
+                out[pre + 'log:' + k] = np.asarray(v)
+            out.update(state_arrays(pre + 'pol:', pol))
+            out.update(state_arrays(pre + 'vf:', vf))
+        out[tag + '_cfg'] = np.asarray([O, A, P, E, mb])
+    save('policy_options', **out)
+
+
 def gen_compute_advantage():
     """Item 3: centre / positive variants incl. the single-sample edge."""
     out = {}
@@ -596,6 +651,7 @@ if __name__ == '__main__':
             globals()['gen_' + name]()
         sys.exit(0)
     gen_trpo()
+    gen_policy_options()
     gen_returns()
     gen_advantages()
     gen_padding_and_steptypes()

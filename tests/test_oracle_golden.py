@@ -464,3 +464,37 @@ def test_golden_trpo_train_once(golden, tag):
             assert np.allclose(v, g[pre + 'vf:' + k], atol=1e-6), k
     if tag == 'trpo_reject':
         assert algo.cg.trace['accepted'] in (-1, 0)
+
+
+POLICY_OPTION_CASES = ['fixed_std', 'init_small', 'max_clamp', 'min_clamp']
+
+
+@pytest.mark.parametrize('tag', POLICY_OPTION_CASES)
+def test_golden_policy_std_options(golden, tag):
+    """Two real PPO iterations per ``GaussianMLPPolicy`` std option: fixed std
+    (a buffer, not a parameter), active max / min clamps (zero gradient through
+    the clamp), a small learned std."""
+    g = golden('policy_options')
+    O, A, P, E, mb = [int(v) for v in g[tag + '_cfg']]
+    algo = OraclePPO(_params(g, tag + '_pol0:'), _params(g, tag + '_vf0:'),
+                     max_episode_length=P, max_optimization_epochs=E,
+                     minibatch_size=mb, policy_lr=2.5e-3, vf_lr=2.5e-3)
+    for it in range(2):
+        pre = '%s_it%d_' % (tag, it)
+        lens = g[pre + 'lengths']
+        b = ob.OracleEpisodeBatch(
+            observations=g[pre + 'observations'],
+            last_observations=np.zeros((len(lens), O), np.float32),
+            actions=g[pre + 'actions'], rewards=g[pre + 'rewards'],
+            step_types=g[pre + 'step_types'], lengths=lens,
+            max_episode_length=P)
+        np.random.seed(int(g[pre + 'np_seed']))
+        out = algo.train_once(b)
+        for mine, theirs in LOG_KEYS.items():
+            assert np.isclose(out[mine], float(g[pre + 'log:' + theirs]),
+                              atol=1e-5, rtol=1e-5), (mine, it)
+        pol, vf = algo.state()
+        for k, v in pol.items():
+            assert np.allclose(v, g[pre + 'pol:' + k], atol=1e-6), k
+        for k, v in vf.items():
+            assert np.allclose(v, g[pre + 'vf:' + k], atol=1e-6), k

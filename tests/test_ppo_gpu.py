@@ -577,3 +577,53 @@ def test_reference_named_evaluation_helpers(algo_name):
                                         torch.from_numpy(base), True, False)
         want = oracle._policy_loss(tobs, tact, adv_ref)
     assert np.isclose(float(got), float(want), atol=2e-5, rtol=1e-4)
+
+
+POLICY_OPTIONS = {
+    'fixed_std': dict(learn_std=False, init_std=0.7),
+    'max_clamp': dict(max_std=0.5, init_std=1.0),
+    'min_clamp': dict(min_std=0.2, init_std=0.1),
+    'init_small': dict(init_std=0.3),
+}
+
+
+@pytest.mark.parametrize('tag', sorted(POLICY_OPTIONS))
+def test_policy_std_options_match_real_reference(golden, tag):
+    """``GaussianMLPPolicy(learn_std / init_std / min_std / max_std)`` through two
+    real PPO iterations (tests/golden/policy_options.npz): fixed std is a buffer
+    and never moves, an active clamp passes no gradient, state_dict keys follow
+    the reference (``init_std`` vs ``_init_std``, ``max_std_param``)."""
+    from garage_amd.algos import PPO
+    from garage_amd.optimizers import OptimizerWrapper
+    from garage_amd.policies import GaussianMLPPolicy, GaussianMLPValueFunction
+    g = golden('policy_options')
+    O, A, P, E, mb = [int(v) for v in g[tag + '_cfg']]
+    spec = _spec(O, A, P)
+    pol = GaussianMLPPolicy(spec, hidden_sizes=(8, 8), **POLICY_OPTIONS[tag])
+    vf = GaussianMLPValueFunction(spec, hidden_sizes=(8, 8))
+    want_keys = sorted(k[len(tag + '_pol0:'):] for k in g.files
+                       if k.startswith(tag + '_pol0:'))
+    assert sorted(pol.state_dict().keys()) == want_keys
+    pol.load_state_dict(_sd(g, tag + '_pol0:'))
+    vf.load_state_dict(_sd(g, tag + '_vf0:'))
+    algo = PPO(env_spec=spec, policy=pol, value_function=vf, sampler=None,
+               policy_optimizer=OptimizerWrapper(
+                   (torch.optim.Adam, dict(lr=2.5e-3)), pol,
+                   max_optimization_epochs=E, minibatch_size=mb),
+               vf_optimizer=OptimizerWrapper(
+                   (torch.optim.Adam, dict(lr=2.5e-3)), vf,
+                   max_optimization_epochs=E, minibatch_size=mb))
+    for it in range(2):
+        pre = '%s_it%d_' % (tag, it)
+        batch = _host_batch(spec, g, pre, O)
+        np.random.seed(int(g[pre + 'np_seed']))
+        algo._train_once(it, batch)
+        for mine, theirs in LOG_KEYS.items():
+            want = float(g[pre + 'log:' + theirs])
+            assert np.isclose(algo.last_tabular[mine], want, atol=1e-5,
+                              rtol=1e-5), (mine, it, algo.last_tabular[mine],
+                                           want)
+        for k, v in pol.state_dict().items():
+            assert np.allclose(v.numpy(), g[pre + 'pol:' + k], atol=2e-6), k
+        for k, v in vf.state_dict().items():
+            assert np.allclose(v.numpy(), g[pre + 'vf:' + k], atol=2e-6), k
