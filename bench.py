@@ -53,7 +53,7 @@ KIND_NAMES = [
     'gemm_f32_kernel<128,32,4,1,true,true,32> (forward, narrow)',
     'gemm_f32_kernel<128,32,4,1,true,false,32> (data grad, narrow)',
     'gemm_f32_kernel<128,32,4,1,false,false,32> (weight grad, narrow)',
-    'gae_scan_fixed_kernel / gae_scan_kernel',
+    'gae_scan_fixed_kernel / gae_scan_rows_kernel / gae_scan_kernel',
     'skinny_fwd_kernel (first-layer forward / head data grad; work = bytes)',
     'skinny_wgrad_kernel (first-layer / head weight grad; work = bytes)',
 ]

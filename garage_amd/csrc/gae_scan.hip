@@ -313,6 +313,138 @@ __global__ __launch_bounds__(256) void gae_scan_fixed_kernel(FixedScanParams p) 
   }
 }
 
+// The same constant-decay scan for ragged whole-episode rows (mode 1, packed with
+// offsets or padded with T < P): a row's only special step is its last one, and
+// what enters it from the zero-padded tail -- bootstrap value V(0-obs) and the
+// closed-form carry C0(P - L) -- is a constant added to that
+// step's offset, after which every step decays like any other.  Rows may start
+// at any float (packed batches): the four steps of a lane are then loaded and
+// stored one by one (still coalesced across the lanes).
+struct RowsScanParams {
+  const float* rew;
+  const float* val;
+  const int64_t* offsets;  // n_rows + 1 row starts, or null: row * ld, length T
+  int64_t n_rows, T, ld;
+  int lpr, P;
+  double gamma, c, gamma_ret, bonus_const, v0;
+  double cpow[6], gpow[6];
+  float* adv;
+  float* ret;
+};
+
+__global__ __launch_bounds__(256) void gae_scan_rows_kernel(RowsScanParams p) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lpr = p.lpr;
+  const int sub = lane & (lpr - 1);
+  const int64_t row = wave * (64 / lpr) + lane / lpr;
+  const bool row_ok = row < p.n_rows;
+  int64_t start = 0;
+  int len = 0;
+  if (row_ok) {
+    if (p.offsets) {
+      start = p.offsets[row];
+      len = (int)(p.offsets[row + 1] - start);
+    } else {
+      start = row * p.ld;
+      len = (int)p.T;
+    }
+  }
+  const int i0 = 4 * sub;
+  const int nv = max(0, min(4, len - i0));  // valid steps of this lane
+  float rf[4] = {0.f, 0.f, 0.f, 0.f}, vf[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool vec = nv == 4 && ((start + i0) & 3) == 0;
+  if (vec) {
+    const float4 r4 = *reinterpret_cast<const float4*>(p.rew + start + i0);
+    const float4 v4 = *reinterpret_cast<const float4*>(p.val + start + i0);
+    rf[0] = r4.x; rf[1] = r4.y; rf[2] = r4.z; rf[3] = r4.w;
+    vf[0] = v4.x; vf[1] = v4.y; vf[2] = v4.z; vf[3] = v4.w;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (j < nv) {
+        rf[j] = p.rew[start + i0 + j];
+        vf[j] = p.val[start + i0 + j];
+      }
+    }
+  }
+  float vr = __shfl_down(vf[0], 1, lpr);
+  if (sub == lpr - 1) vr = 0.f;
+  // the row's last step: what the padded tail hands it (only that lane computes)
+  double end_add = 0.0;
+  const bool has_end = nv > 0 && i0 + nv == len;
+  if (has_end) {
+    const int m = p.P - len;
+    if (m > 0) {
+      const double pad_delta = p.bonus_const + (p.gamma - 1.0) * p.v0;
+      double cm1 = 1.0, base = p.c;
+      for (int e = m - 1; e > 0; e >>= 1) {
+        if (e & 1) cm1 *= base;
+        base *= base;
+      }
+      const double geo =
+          (p.c == 1.0) ? (double)(m - 1) : (1.0 - cm1) / (1.0 - p.c);
+      const double c0 = pad_delta * geo + cm1 * (p.bonus_const - p.v0);
+      end_add = p.gamma * p.v0 + p.c * c0;
+    }
+  }
+  double r[4], xa[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    r[j] = (double)rf[j];
+    const bool valid = j < nv;
+    const bool last = has_end && j == nv - 1;
+    const double vn = last ? 0.0 : (double)(j == 3 ? vr : vf[j < 3 ? j + 1 : 3]);
+    xa[j] = valid ? (r[j] + p.bonus_const) + p.gamma * vn - (double)vf[j] +
+                        (last ? end_add : 0.0)
+                  : 0.0;
+    if (!valid) r[j] = 0.0;
+  }
+  double ax = xa[3], gx = r[3];
+#pragma unroll
+  for (int j = 2; j >= 0; --j) {
+    ax = xa[j] + p.c * ax;
+    gx = r[j] + p.gamma_ret * gx;
+  }
+  // steps right of the row's end are zero maps with zero offsets: a lane that
+  // holds the end must not pass anything on from them (they are zero already)
+  int s = 0;
+  for (int o = 1; o < lpr; o <<= 1, ++s) {
+    const double nax = shfl_down_d(ax, o, lpr), ngx = shfl_down_d(gx, o, lpr);
+    if (sub + o < lpr) {
+      ax = ax + p.cpow[s] * nax;
+      gx = gx + p.gpow[s] * ngx;
+    }
+  }
+  double ya = shfl_down_d(ax, 1, lpr), yg = shfl_down_d(gx, 1, lpr);
+  if (sub + 1 >= lpr) {
+    ya = 0.0;
+    yg = 0.0;
+  }
+  float oa[4], og[4];
+#pragma unroll
+  for (int j = 3; j >= 0; --j) {
+    ya = xa[j] + p.c * ya;
+    yg = r[j] + p.gamma_ret * yg;
+    oa[j] = (float)ya;
+    og[j] = (float)yg;
+  }
+  if (vec) {
+    *reinterpret_cast<float4*>(p.adv + start + i0) =
+        make_float4(oa[0], oa[1], oa[2], oa[3]);
+    *reinterpret_cast<float4*>(p.ret + start + i0) =
+        make_float4(og[0], og[1], og[2], og[3]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (j < nv) {
+        p.adv[start + i0 + j] = oa[j];
+        p.ret[start + i0 + j] = og[j];
+      }
+    }
+  }
+}
+
 }  // namespace
 
 static int g_fixed_fast_path = 1;
@@ -384,6 +516,30 @@ extern "C" int ga_gae_scan_f32(const float* rewards, const float* values,
     hipEvent_t e0 = nullptr, e1 = nullptr;
     ga_prof_events(GA_PROF_GAE_SCAN, 16.0 * (double)n_rows * (double)T, &e0, &e1);
     hipExtLaunchKernelGGL(gae_scan_fixed_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                          stream, e0, e1, 0, f);
+    GA_CHECK_LAUNCH("ga_gae_scan_f32");
+    return GA_OK;
+  }
+  // ragged whole-episode rows of at most 256 steps: the same scheme with the
+  // padded tail's contribution folded into each row's last step
+  if (g_fixed_fast_path && mode == 1 && !bonus && max_len <= 256) {
+    RowsScanParams f;
+    f.rew = rewards; f.val = values; f.offsets = offsets; f.n_rows = n_rows; f.T = T;
+    f.ld = ld; f.lpr = lpr; f.P = max_episode_length; f.gamma = p.gamma; f.c = p.c;
+    f.gamma_ret = p.gamma_ret; f.bonus_const = p.bonus_const; f.v0 = p.v0;
+    f.adv = adv; f.ret = ret;
+    double cd = ((p.c * p.c) * p.c) * p.c, gd = ((discount * discount) * discount) * discount;
+    for (int k = 0; k < 6; ++k) {
+      f.cpow[k] = cd;
+      f.gpow[k] = gd;
+      cd *= cd;
+      gd *= gd;
+    }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ga_prof_events(GA_PROF_GAE_SCAN,
+                   16.0 * (offsets ? (double)prof_steps : (double)n_rows * (double)T),
+                   &e0, &e1);
+    hipExtLaunchKernelGGL(gae_scan_rows_kernel, dim3((unsigned)blocks), dim3(256), 0,
                           stream, e0, e1, 0, f);
     GA_CHECK_LAUNCH("ga_gae_scan_f32");
     return GA_OK;

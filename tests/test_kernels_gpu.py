@@ -138,6 +138,40 @@ def test_gae_scan_fixed_horizon_fast_path_equals_general_kernel(dev, n, T):
         assert torch.allclose(a, b, atol=2e-7 * scale, rtol=0), (n, T)
 
 
+@pytest.mark.parametrize('P', [40, 256])
+def test_gae_scan_ragged_fast_path_equals_general_kernel(dev, P):
+    """Packed ragged whole-episode rows (arbitrary, unaligned starts; V(0) != 0 in
+    the padded tail; a constant reward bonus) and padded rows shorter than P:
+    the constant-decay kernel against the general segmented one."""
+    from garage_amd import _lib
+    from garage_amd.engine import gae_scan
+    lib = _lib.load()
+    rng = np.random.RandomState(P)
+    lens = rng.randint(1, P + 1, size=777)
+    lens[:5] = [1, 2, 3, P, P]
+    off = np.concatenate([[0], np.cumsum(lens)])
+    S = int(off[-1])
+    g = torch.Generator(device='cpu').manual_seed(P)
+    r = torch.randn(S, generator=g).to(dev)
+    v = torch.randn(S, generator=g).to(dev)
+    offsets = torch.from_numpy(off).to(dev)
+    r2 = torch.randn(50, P - 8, generator=g).to(dev)   # padded rows, L = P - 8
+    v2 = torch.randn(50, P - 8, generator=g).to(dev)
+    out = {}
+    for on in (0, 1):
+        lib.ga_set_gae_fixed_fast_path(on)
+        a = gae_scan(r, v, discount=0.99, gae_lambda=0.97, max_episode_length=P,
+                     offsets=offsets, max_len=int(lens.max()), v0=0.37,
+                     bonus_const=0.05)
+        b = gae_scan(r2, v2, discount=0.99, gae_lambda=0.97,
+                     max_episode_length=P, v0=-0.6)
+        out[on] = [t.clone() for t in a + b]
+    lib.ga_set_gae_fixed_fast_path(1)
+    for x, y in zip(out[0], out[1]):
+        scale = max(1.0, float(x.abs().max()))
+        assert torch.allclose(x, y, atol=3e-7 * scale, rtol=0), P
+
+
 def test_gemm_nt(dev):
     from garage_amd._lib import call, dptr, stream_ptr
     rng = np.random.RandomState(1)
