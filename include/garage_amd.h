@@ -40,7 +40,9 @@ const char* ga_last_error(void);
  *   mode 0: rows are env slices of the (n_rows, T) rollout buffer, row stride
  *           ld; tail[i] = episode length at an episode's last step, else 0.
  *   mode 1: every row is one episode (packed batch via offsets[n_rows+1] with
- *           max_len = longest row, or a padded (N, P) batch with offsets = NULL).
+ *           max_len >= the longest row -- a contract: rows are scanned in one
+ *           pass of max_len steps when max_len <= 256 -- or a padded (N, P)
+ *           batch with offsets = NULL).
  * v0 = value of the all-zero observation (content of padded baselines);
  * bonus / bonus_const = per-step / constant reward bonus added for the
  * advantages only (entropy_method='max', vpg.py:158-160).
@@ -51,8 +53,9 @@ int ga_gae_scan_f32(const float* rewards, const float* values, const float* bonu
                     int max_episode_length, double discount, double gae_lambda,
                     float v0, float bonus_const, float* adv, float* ret,
                     ga_stream_t stream);
-/* Rows that are whole episodes of exactly max_episode_length steps (mode 1, no
- * per-step bonus, T <= 256) take a constant-decay fast path; 0 forces the general
+/* Whole-episode rows (mode 1) of at most 256 steps without a per-step bonus take
+ * constant-decay fast paths (fixed horizon: aligned rows of exactly
+ * max_episode_length steps; otherwise the ragged variant); 0 forces the general
  * kernel (A/B runs, tests). */
 int ga_set_gae_fixed_fast_path(int on);
 
