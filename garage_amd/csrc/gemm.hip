@@ -348,6 +348,73 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_f32_kernel(
 
   // ---- epilogue: D(row, col): col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   float* Cout = p.C + (int64_t)split * p.c_split_stride;
+#ifndef GA_NO_TR_EPILOGUE
+  // Interior 128x128 tiles of a row-major C go through LDS, half a tile (64 rows)
+  // at a time in the operand stages that are free now: a lane then owns 4
+  // adjacent columns of a row, so stores (and the H / C loads of the fused
+  // epilogues) are 16-B accesses and a wave instruction covers two whole 512-B
+  // row segments instead of two 128-B ones.
+  if (BM == 128 && BN == 128 && full && p.c_cs == 1 && (p.c_rs & 3) == 0 &&
+      (reinterpret_cast<uintptr_t>(Cout) & 15u) == 0 &&
+      (!p.H || ((p.ldh & 3) == 0 && (reinterpret_cast<uintptr_t>(p.H) & 15u) == 0)) &&
+      (!p.bias || (reinterpret_cast<uintptr_t>(p.bias) & 15u) == 0)) {
+    constexpr int LDC = BN + 4;
+    static_assert(BM != 128 || BN != 128 || 64 * LDC <= A_FLOATS + B_FLOATS,
+                  "half tile must fit the operand stages");
+    for (int hrow = 0; hrow < BM; hrow += 64) {
+      if (wm0 == hrow) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int rr = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+              lds[rr * LDC + wn0 + 32 * j + (lane & 31)] = acc[i][j][r];
+            }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 64 * (BN / 4) / (64 * WAVES_M * WAVES_N); ++q) {
+        const int idx = threadIdx.x + 64 * WAVES_M * WAVES_N * q;
+        const int rr = idx / (BN / 4), c4 = idx % (BN / 4);
+        const int m = m0 + hrow + rr, n = n0 + 4 * c4;
+        float4 v = *reinterpret_cast<const float4*>(lds + rr * LDC + 4 * c4);
+        float* dst = Cout + (int64_t)m * p.c_rs + n;
+        if (p.accum) {
+          const float4 o = *reinterpret_cast<const float4*>(dst);
+          v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        }
+        if (p.epi == EPI_BIAS_ACT) {
+          if (p.bias) {
+            const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+            v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+          }
+          if (p.act == 1) {
+            v.x = tanh_fast(v.x); v.y = tanh_fast(v.y);
+            v.z = tanh_fast(v.z); v.w = tanh_fast(v.w);
+          }
+        }
+        if ((p.epi == EPI_BIAS_ACT && p.H) || p.epi == EPI_MUL_DTANH) {
+          const float4 h =
+              *reinterpret_cast<const float4*>(p.H + (int64_t)m * p.ldh + n);
+          v.x *= (1.f - h.x * h.x); v.y *= (1.f - h.y * h.y);
+          v.z *= (1.f - h.z * h.z); v.w *= (1.f - h.w * h.w);
+        }
+        *reinterpret_cast<float4*>(dst) = v;
+      }
+      __syncthreads();
+    }
+    if (do_colsum) {
+      const int W = p.colsum_of_b ? BN : BM;
+      const int base = p.colsum_of_b ? n0 : m0;
+      const int lim = p.colsum_of_b ? p.N : p.M;
+      if ((int)threadIdx.x < W && base + (int)threadIdx.x < lim)
+        p.colsum[(int64_t)split * p.colsum_split_stride + base + threadIdx.x] = csum;
+    }
+    return;
+  }
+#endif
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll

@@ -387,7 +387,9 @@ def test_head_fused_into_loss_matches_unfused(dev, hidden, A, algo):
         ds = max(1e-6, float(d0.abs().max()))
         assert torch.allclose(d0, d1, atol=2e-4 * ds), (M, 'dout')
         assert torch.allclose(ll0, ll1, rtol=1e-5, atol=2e-4), (M, 'll')
-        assert torch.allclose(s0, s1, rtol=2e-4, atol=1e-6), (M, s0, s1)
+        # (a sum of ~M terms of order 1 that cancels to ~1e-2: rounding of the
+        # two head evaluations shows up at 1e-3 of the result)
+        assert torch.allclose(s0, s1, rtol=5e-3, atol=2e-6), (M, s0, s1)
 
 
 def _ppo_oracle_loss(pol, obs, act, old_ll, adv, clip, algo='ppo', ent=None):
