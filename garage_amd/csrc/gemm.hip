@@ -349,34 +349,36 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_f32_kernel(
   // ---- epilogue: D(row, col): col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   float* Cout = p.C + (int64_t)split * p.c_split_stride;
 #ifndef GA_NO_TR_EPILOGUE
-  // Interior 128x128 tiles of a row-major C go through LDS, half a tile (64 rows)
-  // at a time in the operand stages that are free now: a lane then owns 4
+  // Interior tiles of a row-major C go through LDS, 64 rows at a time in the
+  // operand stages that are free now: a lane then owns 4
   // adjacent columns of a row, so stores (and the H / C loads of the fused
   // epilogues) are 16-B accesses and a wave instruction covers two whole 512-B
   // row segments instead of two 128-B ones.
-  if (BM == 128 && BN == 128 && full && p.c_cs == 1 && (p.c_rs & 3) == 0 &&
+  constexpr int NT_ALL = 64 * WAVES_M * WAVES_N;
+  constexpr bool TR_OK = 64 * (BN + 4) <= A_FLOATS + B_FLOATS && BM % 64 == 0 &&
+                         (64 * (BN / 4)) % NT_ALL == 0;
+  if (TR_OK && full && p.c_cs == 1 && (p.c_rs & 3) == 0 &&
       (reinterpret_cast<uintptr_t>(Cout) & 15u) == 0 &&
       (!p.H || ((p.ldh & 3) == 0 && (reinterpret_cast<uintptr_t>(p.H) & 15u) == 0)) &&
       (!p.bias || (reinterpret_cast<uintptr_t>(p.bias) & 15u) == 0)) {
     constexpr int LDC = BN + 4;
-    static_assert(BM != 128 || BN != 128 || 64 * LDC <= A_FLOATS + B_FLOATS,
-                  "half tile must fit the operand stages");
     for (int hrow = 0; hrow < BM; hrow += 64) {
-      if (wm0 == hrow) {
+      if (wm0 >= hrow && wm0 < hrow + 64) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              const int rr = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-              lds[rr * LDC + wn0 + 32 * j + (lane & 31)] = acc[i][j][r];
+              const int rr =
+                  wm0 - hrow + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+              if (rr < 64) lds[rr * LDC + wn0 + 32 * j + (lane & 31)] = acc[i][j][r];
             }
       }
       __syncthreads();
 #pragma unroll
-      for (int q = 0; q < 64 * (BN / 4) / (64 * WAVES_M * WAVES_N); ++q) {
-        const int idx = threadIdx.x + 64 * WAVES_M * WAVES_N * q;
+      for (int q = 0; q < (TR_OK ? 64 * (BN / 4) / NT_ALL : 0); ++q) {
+        const int idx = threadIdx.x + NT_ALL * q;
         const int rr = idx / (BN / 4), c4 = idx % (BN / 4);
         const int m = m0 + hrow + rr, n = n0 + 4 * c4;
         float4 v = *reinterpret_cast<const float4*>(lds + rr * LDC + 4 * c4);
