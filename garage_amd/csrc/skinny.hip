@@ -370,8 +370,15 @@ int ga_skinny_forward(const float* X, int64_t ldx, const int32_t* idx, const flo
   p.ldh = ldh; p.Y = Y; p.ldy = ldy; p.M = M; p.N = N; p.K = K; p.act = act;
   p.qpr = qpr;
   const int n_rg = SK_THREADS / qpr;
-  // ~32 rows per workgroup when a row fills a wave, never fewer than one unroll
-  p.rows_per_thread = ((32 / n_rg + SK_UNROLL - 1) / SK_UNROLL) * SK_UNROLL;
+  // ~128 rows per workgroup, never fewer than one unroll per thread: every
+  // workgroup first loads its W quads into registers (20 KB from L2 at the C3
+  // first layer), so fewer, longer-lived workgroups win while the other update
+  // chain shares the chip (32 / 128 / 256 rows: 146.2 / 143.3 / 152.9 ms per C3
+  // iteration)
+  // (... but at least one workgroup per CU)
+  int rows_wg = 128;
+  while (rows_wg > 32 && (int64_t)M < 256 * (int64_t)rows_wg) rows_wg >>= 1;
+  p.rows_per_thread = ((rows_wg / n_rg + SK_UNROLL - 1) / SK_UNROLL) * SK_UNROLL;
   if (p.rows_per_thread < SK_UNROLL) p.rows_per_thread = SK_UNROLL;
   const int rows_per_block = n_rg * p.rows_per_thread;
   if ((int64_t)rows_per_block * ((K + 3) / 4) * 16 > 48 * 1024) return 1;
