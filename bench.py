@@ -148,9 +148,14 @@ def roofline_pass(algo, sampler, pol, S, itr):
     out = (C.c_double * (3 * n_kinds))()
     lib.ga_prof_collect(out, n_kinds)
     rows = []
+    # layers of at most 64 units run the wide kinds on 64x64 tiles (4 waves)
+    small = max(algo.policy.net.hidden_sizes) <= 64
     for k in range(n_kinds):
         ms, work, cnt = out[3 * k], out[3 * k + 1], out[3 * k + 2]
-        rows.append(dict(kernel=KIND_NAMES[k], total_ms=ms, work=work,
+        name = KIND_NAMES[k]
+        if small:
+            name = name.replace('<128,128,2,4,', '<64,64,2,2,')
+        rows.append(dict(kernel=name, total_ms=ms, work=work,
                          launches=int(cnt)))
     return rows
 
