@@ -82,8 +82,9 @@ struct GemmParams {
 // a load inside a data-dependent branch makes hipcc wait vmcnt(0) right behind
 // it, which serialises the whole tile fetch in front of the MFMAs.  The gathered
 // line numbers (`idx`) are fetched one tile ahead for the same reason.
-// FULL: the launch guarantees every tile is entirely inside the matrices, so the
-// clamps and the zero masks (16 v_cndmask per vector pair and k-step) drop out.
+// FULL: the workgroup's tile rows are entirely inside the matrices, so the clamps
+// and the zero masks (16 v_cndmask per vector pair and k-step) drop out on every
+// k-step but the last (which may be partial).
 template <int BR, bool KC, int NT, int BKT, bool FULL>
 struct TileLoader {
   static constexpr int NV = BR * BKT / 4 / NT;  // float4 per thread
@@ -136,8 +137,11 @@ struct TileLoader {
   }
 
   // span = number of valid floats along the contiguous direction (K or R)
+  // tail: this is the (possibly partial) last k-step of the block's k range; a
+  // FULL loader still clamps / masks there, so only the tile's row range has to
+  // be interior for the fast path, not its k range
   __device__ __forceinline__ void load(const float* __restrict__ base, int64_t ld,
-                                       int r0, int k0, int span) {
+                                       int r0, int k0, int span, bool tail) {
     const int tid = threadIdx.x;
     const int last = max(((span + 3) & ~3) - 4, 0);  // last in-bounds vector
 #pragma unroll
@@ -145,12 +149,12 @@ struct TileLoader {
       const int f = tid + NT * i;
       const int c = KC ? (k0 + 4 * (f % VPR)) : (r0 + 4 * (f % VPL));
       regs[i] = *reinterpret_cast<const float4*>(base + (int64_t)cur[i] * ld +
-                                                 (FULL ? c : min(c, last)));
+                                                 ((FULL && !tail) ? c : min(c, last)));
     }
   }
 
   __device__ __forceinline__ void store(float* __restrict__ tile, int r0, int R,
-                                        int k0, int kend) const {
+                                        int k0, int kend, bool tail) const {
     constexpr int LD = BR + PAD;
     const int tid = threadIdx.x;
 #pragma unroll
@@ -160,7 +164,7 @@ struct TileLoader {
       if (KC) {
         const int r = f / VPR;
         const int k = 4 * (f % VPR);
-        if (!FULL) {
+        if (!FULL || tail) {
           const bool row_ok = (r0 + r) < R;
           v.x = (row_ok && k0 + k + 0 < kend) ? v.x : 0.f;
           v.y = (row_ok && k0 + k + 1 < kend) ? v.y : 0.f;
@@ -173,7 +177,7 @@ struct TileLoader {
       } else {
         const int k = f / VPL;
         const int r = 4 * (f % VPL);
-        if (!FULL) {
+        if (!FULL || tail) {
           const bool k_ok = (k0 + k) < kend;
           v.x = (k_ok && r0 + r + 0 < R) ? v.x : 0.f;
           v.y = (k_ok && r0 + r + 1 < R) ? v.y : 0.f;
@@ -187,8 +191,8 @@ struct TileLoader {
 };
 
 // The k-loop of one workgroup: global -> registers -> LDS -> MFMA.  FULL selects the
-// mask-free loader (the caller has checked that this workgroup's tiles are
-// entirely inside the matrices and that its k range is a multiple of BKT).
+// mask-free loader (the caller has checked that this workgroup's tile rows are
+// entirely inside the matrices; the last k-step is masked either way).
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KC, bool B_KC, int BKT,
           bool FULL, int TM, int TN>
 __device__ __forceinline__ void gemm_mainloop(const GemmParams& p, float* lds,
@@ -209,24 +213,26 @@ __device__ __forceinline__ void gemm_mainloop(const GemmParams& p, float* lds,
   if (nk > 0) {
     la.init(p.a_idx, m0, p.M, kbeg, kend);
     lb.init(p.b_idx, n0, p.N, kbeg, kend);
-    la.load(p.A, p.lda, m0, kbeg, a_span);
-    lb.load(p.B, p.ldb, n0, kbeg, b_span);
+    const bool t0 = nk == 1;
+    la.load(p.A, p.lda, m0, kbeg, a_span, t0);
+    lb.load(p.B, p.ldb, n0, kbeg, b_span, t0);
     la.prefetch_lines(p.a_idx, kbeg + BKT, kend);
     lb.prefetch_lines(p.b_idx, kbeg + BKT, kend);
-    la.store(As, m0, p.M, kbeg, kend);
-    lb.store(Bs, n0, p.N, kbeg, kend);
+    la.store(As, m0, p.M, kbeg, kend, t0);
+    lb.store(Bs, n0, p.N, kbeg, kend, t0);
   }
   __syncthreads();
 
   const int half = lane >> 5, l31 = lane & 31;
   for (int s = 0; s < nk; ++s) {
     const bool more = (s + 1 < nk);
+    const bool tail = (s + 2 == nk);  // the tile being fetched is the last one
     const int k_next = kbeg + (s + 1) * BKT;
     if (more) {
       la.rotate();
       lb.rotate();
-      la.load(p.A, p.lda, m0, k_next, a_span);
-      lb.load(p.B, p.ldb, n0, k_next, b_span);
+      la.load(p.A, p.lda, m0, k_next, a_span, tail);
+      lb.load(p.B, p.ldb, n0, k_next, b_span, tail);
       la.prefetch_lines(p.a_idx, k_next + BKT, kend);
       lb.prefetch_lines(p.b_idx, k_next + BKT, kend);
     }
@@ -280,8 +286,8 @@ __device__ __forceinline__ void gemm_mainloop(const GemmParams& p, float* lds,
     }
     __syncthreads();
     if (more) {
-      la.store(As, m0, p.M, k_next, kend);
-      lb.store(Bs, n0, p.N, k_next, kend);
+      la.store(As, m0, p.M, k_next, kend, tail);
+      lb.store(Bs, n0, p.N, k_next, kend, tail);
       __syncthreads();
     }
   }
@@ -337,8 +343,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_f32_kernel(
 
   // interior workgroups (every one at the C3 shapes, all but the last row / column
   // block and the last split otherwise) take the mask-free loader
-  const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N) && kend > kbeg &&
-                    ((kend - kbeg) % BKT == 0);
+  const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N) && kend > kbeg;
   if (full)
     gemm_mainloop<BM, BN, WAVES_M, WAVES_N, A_KC, B_KC, BKT, true>(
         p, lds, acc, csum, do_colsum, m0, n0, kbeg, kend, wm0, wn0);

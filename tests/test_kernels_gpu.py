@@ -176,7 +176,8 @@ def test_gemm_nt(dev):
     from garage_amd._lib import call, dptr, stream_ptr
     rng = np.random.RandomState(1)
     for (M, N, K) in [(128, 128, 32), (300, 256, 256), (1000, 6, 256),
-                      (77, 200, 20), (4096, 256, 17 + 3), (5, 3, 4)]:
+                      (77, 200, 20), (4096, 256, 17 + 3), (5, 3, 4),
+                      (1024, 256, 376), (640, 384, 400), (256, 128, 36)]:
         A = rng.randn(M, K).astype(np.float32)
         B = rng.randn(N, K).astype(np.float32)
         a, b = torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev)
