@@ -53,7 +53,7 @@ KIND_NAMES = [
     'gemm_f32_kernel<128,32,4,1,true,true,32> (forward, narrow)',
     'gemm_f32_kernel<128,32,4,1,true,false,32> (data grad, narrow)',
     'gemm_f32_kernel<128,32,4,1,false,false,32> (weight grad, narrow)',
-    'gae_scan_fixed_kernel / gae_scan_rows_kernel / gae_scan_kernel',
+    'gae_scan_rows_kernel / gae_scan_kernel',
     'skinny_fwd_kernel (first-layer forward / head data grad; work = bytes)',
     'skinny_wgrad_kernel (first-layer / head weight grad; work = bytes)',
 ]
@@ -376,7 +376,7 @@ def main():
                 'avg_launch_us': scan['total_ms'] * 1e3 / scan['launches'],
                 'bytes_per_launch': scan['work'] / scan['launches'],
             }
-            for name in ('gae_scan_fixed_kernel', 'gae_scan_kernel<true>'):
+            for name in ('gae_scan_rows_kernel', 'gae_scan_kernel<true>'):
                 if args.config == 'c3' and name in traffic:
                     line['roofline_gae_scan']['traffic'] = \
                         traffic[name]['hbm_bytes']

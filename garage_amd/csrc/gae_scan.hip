@@ -235,91 +235,19 @@ __global__ __launch_bounds__(256, 4) void gae_scan_kernel(ScanParams p) {
   }
 }
 
-// Fast path for the fixed-horizon case: every row is one whole episode of exactly
-// P = max_episode_length steps (no padded tail, so the boundary is A_P = G_P =
-// V_P = 0), no per-step bonus, one chunk per row.  All decays are then the same
-// constant, so the suffix scan carries only the offsets -- the decay a lane
-// applies at scan step s is c^(4 * 2^s), precomputed on the host by the same
-// repeated squaring the general kernel does in registers -- and the per-step
-// kind selection disappears: ~5x fewer instructions than the general kernel,
-// which is issue bound (not HBM bound) at 4096 x 256.
-struct FixedScanParams {
-  const float* rew;
-  const float* val;
-  int64_t n_rows, T, ld;
-  int lpr;
-  double gamma, c, gamma_ret, bonus_const;
-  double cpow[6], gpow[6];  // c^(4 * 2^s), gamma_ret^(4 * 2^s)
-  float* adv;
-  float* ret;
-};
-
-__global__ __launch_bounds__(256) void gae_scan_fixed_kernel(FixedScanParams p) {
-  const int lane = threadIdx.x & 63;
-  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lpr = p.lpr;
-  const int sub = lane & (lpr - 1);
-  const int64_t row = wave * (64 / lpr) + lane / lpr;
-  const bool active = row < p.n_rows && 4 * sub < p.T;  // T % 4 == 0
-  const int64_t at = (row < p.n_rows ? row : 0) * p.ld + 4 * sub;
-  float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f), v4 = r4;
-  if (active) {
-    r4 = *reinterpret_cast<const float4*>(p.rew + at);
-    v4 = *reinterpret_cast<const float4*>(p.val + at);
-  }
-  // V of the step to the right of this lane's last step (0 past the row end)
-  float vr = __shfl_down(v4.x, 1, lpr);
-  if (sub == lpr - 1) vr = 0.f;
-  const double r[4] = {(double)r4.x, (double)r4.y, (double)r4.z, (double)r4.w};
-  const double v[5] = {(double)v4.x, (double)v4.y, (double)v4.z, (double)v4.w,
-                       (double)vr};
-  double xa[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-    xa[j] = active ? (r[j] + p.bonus_const) + p.gamma * v[j + 1] - v[j] : 0.0;
-  // compose the lane's four maps right to left (decay constant: offsets only)
-  double ax = xa[3], gx = active ? r[3] : 0.0;
-#pragma unroll
-  for (int j = 2; j >= 0; --j) {
-    ax = xa[j] + p.c * ax;
-    gx = (active ? r[j] : 0.0) + p.gamma_ret * gx;
-  }
-  // inclusive suffix scan over the row group
-  int s = 0;
-  for (int o = 1; o < lpr; o <<= 1, ++s) {
-    const double nax = shfl_down_d(ax, o, lpr), ngx = shfl_down_d(gx, o, lpr);
-    if (sub + o < lpr) {
-      ax = ax + p.cpow[s] * nax;
-      gx = gx + p.gpow[s] * ngx;
-    }
-  }
-  // the suffix to the right of this lane is what enters its last step
-  double ya = shfl_down_d(ax, 1, lpr), yg = shfl_down_d(gx, 1, lpr);
-  if (sub + 1 >= lpr) {
-    ya = 0.0;
-    yg = 0.0;
-  }
-  float oa[4], og[4];
-#pragma unroll
-  for (int j = 3; j >= 0; --j) {
-    ya = xa[j] + p.c * ya;
-    yg = r[j] + p.gamma_ret * yg;
-    oa[j] = (float)ya;
-    og[j] = (float)yg;
-  }
-  if (active) {
-    *reinterpret_cast<float4*>(p.adv + at) = make_float4(oa[0], oa[1], oa[2], oa[3]);
-    *reinterpret_cast<float4*>(p.ret + at) = make_float4(og[0], og[1], og[2], og[3]);
-  }
-}
-
-// The same constant-decay scan for ragged whole-episode rows (mode 1, packed with
-// offsets or padded with T < P): a row's only special step is its last one, and
-// what enters it from the zero-padded tail -- bootstrap value V(0-obs) and the
-// closed-form carry C0(P - L) -- is a constant added to that
-// step's offset, after which every step decays like any other.  Rows may start
-// at any float (packed batches): the four steps of a lane are then loaded and
-// stored one by one (still coalesced across the lanes).
+// Fast path for rows that are whole episodes of at most 256 steps (mode 1, no
+// per-step bonus): fixed-horizon batches, padded rows shorter than P, and packed
+// ragged batches.  A row's only special step is its last one, and what the
+// zero-padded tail hands it -- bootstrap value V(0-obs) and the closed-form carry
+// C0(P - L); nothing when L == P -- is a constant added to that
+// step's offset.  After that every step decays by the same constant, so the
+// suffix scan carries only the offsets: the decay a lane applies at scan step s is
+// c^(4 * 2^s), precomputed on the host by the same repeated squaring the general
+// kernel does in registers, and the per-step kind selection disappears: ~5x
+// fewer instructions than the general kernel, which is issue bound (not HBM
+// bound) at 4096 x 256.  Rows may start at any float (packed batches): the four
+// steps of a lane are then loaded and stored one by one, still coalesced across
+// the lanes.
 struct RowsScanParams {
   const float* rew;
   const float* val;
@@ -498,30 +426,7 @@ extern "C" int ga_gae_scan_f32(const float* rewards, const float* values,
   const int64_t waves = ga_ceil_div(n_rows, rows_per_wave);
   const int64_t blocks = ga_ceil_div(waves, 4);
   GA_REQUIRE(blocks < (1ll << 31), "ga_gae_scan_f32: grid too large");
-  // fixed horizon, whole episodes: the constant-decay fast path
-  if (g_fixed_fast_path && mode == 1 && !offsets && !bonus && T == max_episode_length &&
-      T % 4 == 0 && T <= 256 && ld % 4 == 0 && ga_aligned16(rewards) &&
-      ga_aligned16(values) && ga_aligned16(adv) && ga_aligned16(ret)) {
-    FixedScanParams f;
-    f.rew = rewards; f.val = values; f.n_rows = n_rows; f.T = T; f.ld = ld;
-    f.lpr = lpr; f.gamma = p.gamma; f.c = p.c; f.gamma_ret = p.gamma_ret;
-    f.bonus_const = p.bonus_const; f.adv = adv; f.ret = ret;
-    double cd = ((p.c * p.c) * p.c) * p.c, gd = ((discount * discount) * discount) * discount;
-    for (int k = 0; k < 6; ++k) {
-      f.cpow[k] = cd;
-      f.gpow[k] = gd;
-      cd *= cd;
-      gd *= gd;
-    }
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    ga_prof_events(GA_PROF_GAE_SCAN, 16.0 * (double)n_rows * (double)T, &e0, &e1);
-    hipExtLaunchKernelGGL(gae_scan_fixed_kernel, dim3((unsigned)blocks), dim3(256), 0,
-                          stream, e0, e1, 0, f);
-    GA_CHECK_LAUNCH("ga_gae_scan_f32");
-    return GA_OK;
-  }
-  // ragged whole-episode rows of at most 256 steps: the same scheme with the
-  // padded tail's contribution folded into each row's last step
+  // whole-episode rows of at most 256 steps: the constant-decay kernel
   if (g_fixed_fast_path && mode == 1 && !bonus && max_len <= 256) {
     RowsScanParams f;
     f.rew = rewards; f.val = values; f.offsets = offsets; f.n_rows = n_rows; f.T = T;

@@ -118,7 +118,7 @@ def test_gae_scan_rollout_buffer_tails(dev):
 
 @pytest.mark.parametrize('n,T', [(1, 4), (7, 64), (300, 128), (33, 200),
                                  (4096, 256)])
-def test_gae_scan_fixed_horizon_fast_path_equals_general_kernel(dev, n, T):
+def test_gae_scan_fast_path_fixed_horizon_equals_general_kernel(dev, n, T):
     """Whole episodes of exactly P steps take the constant-decay kernel; the
     general (segmented, padded-tail aware) kernel must give the same numbers."""
     from garage_amd import _lib
