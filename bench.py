@@ -234,6 +234,9 @@ def main():
     ap.add_argument('--algo', default='ppo', choices=['ppo', 'trpo'],
                     help='trpo: the section-8f.1 widening (conjugate-gradient '
                     'policy step), reported under its own metric name')
+    ap.add_argument('--no-head-dgrad-fusion', action='store_true',
+                    help='A/B switch: separate launch for the data gradient '
+                    'below the head layer')
     ap.add_argument('--no-overlap', action='store_true',
                     help='run the policy and value-function passes one after '
                     'the other on one stream (isolated per-kernel timings)')
@@ -250,6 +253,9 @@ def main():
     algo, sampler, pol, S = build_engine(cfg, comm, algo_name=args.algo)
     algo.overlap_updates = not args.no_overlap
     algo.fuse_head = bool(args.fuse_head)
+    if args.no_head_dgrad_fusion:
+        from garage_amd import _lib
+        _lib.load().ga_set_fused_head_dgrad(0)
 
     def sync():
         if comm is not None:

@@ -544,7 +544,13 @@ int ga_skinny_wgrad(const float* Wd, int64_t ldw, const int32_t* w_idx, const fl
                     int64_t ldn, const int32_t* n_idx, int rows, int wide, int NS,
                     int rows_per_split, int n_splits, float* C, int64_t c_wide_stride,
                     int64_t c_narrow_stride, int64_t split_stride, float* colsum_wide,
-                    float* colsum_narrow, hipStream_t stream);
+                    float* colsum_narrow, const float* Wn, int64_t ldwn, float* dz_out,
+                    int64_t lddz, hipStream_t stream);
+static int g_fuse_head_dgrad = 1;
+extern "C" int ga_set_fused_head_dgrad(int on) {
+  g_fuse_head_dgrad = on != 0;
+  return 0;
+}
 static int g_skinny = 1;
 extern "C" int ga_set_skinny_kernels(int on) {
   g_skinny = on != 0;
@@ -655,6 +661,7 @@ extern "C" int ga_mlp_backward_f32(const ga_mlp_desc* d, const float* params,
   const int L = d->n_layers;
   int kps = (int)(ga_ceil_div(ga_ceil_div(M, n_splits), BK) * BK);
   for (int l = L - 1; l >= 0; --l) {
+    bool dgrad_done = false;
     const float* dz = (l == L - 1) ? dout : dacts + d->act_off[l];
     const int64_t lddz = (l == L - 1) ? ldo : round4(d->dims[l + 1]);
     const int out_w = d->dims[l + 1], in_w = d->dims[l];
@@ -694,11 +701,25 @@ extern "C" int ga_mlp_backward_f32(const ga_mlp_desc* d, const float* params,
         // wide = dz (bias gradient = its column sums), narrow = layer input
         rc = ga_skinny_wgrad(dz, lddz, nullptr, in, ldin, in_idx, (int)M, out_w, in_w, kps,
                              (int)n_splits, grad_slabs + d->w_off[l], round4(in_w), 1,
-                             slab_stride, grad_slabs + d->b_off[l], nullptr, stream);
+                             slab_stride, grad_slabs + d->b_off[l], nullptr, nullptr, 0,
+                             nullptr, 0, stream);
       } else if (g_skinny && out_w <= 32 && in_w > 32) {
+        // head layer: the same pass over the hidden activations also yields the
+        // data gradient of the layer below (it needs dz and tanh' of `in` only)
+        const bool with_dz = g_fuse_head_dgrad && l > 0 && in_idx == nullptr;
         rc = ga_skinny_wgrad(in, ldin, in_idx, dz, lddz, nullptr, (int)M, in_w, out_w, kps,
                              (int)n_splits, grad_slabs + d->w_off[l], 1, round4(in_w),
-                             slab_stride, nullptr, grad_slabs + d->b_off[l], stream);
+                             slab_stride, nullptr, grad_slabs + d->b_off[l],
+                             with_dz ? params + d->w_off[l] : nullptr, round4(in_w),
+                             with_dz ? dacts + d->act_off[l - 1] : nullptr, round4(in_w),
+                             stream);
+        if (rc == 1 && with_dz)  // shape not taken with the data gradient: without
+          rc = ga_skinny_wgrad(in, ldin, in_idx, dz, lddz, nullptr, (int)M, in_w, out_w,
+                               kps, (int)n_splits, grad_slabs + d->w_off[l], 1,
+                               round4(in_w), slab_stride, nullptr,
+                               grad_slabs + d->b_off[l], nullptr, 0, nullptr, 0, stream);
+        else if (rc == 0 && with_dz)
+          dgrad_done = true;
       }
       if (rc < 0) return rc;
       if (rc == 1) {
@@ -707,7 +728,7 @@ extern "C" int ga_mlp_backward_f32(const ga_mlp_desc* d, const float* params,
       }
     }
     // ---- data gradient for the layer below
-    if (l > 0) {
+    if (l > 0 && !dgrad_done) {
       GemmParams p;
       memset(&p, 0, sizeof(p));
       p.A = dz; p.lda = lddz;

@@ -168,6 +168,12 @@ struct SkinnyWgradParams {
   int64_t split_stride;
   float* colsum_wide;    // optional: sum_r Wd[., c]  -> [split][c]
   float* colsum_narrow;  // optional: sum_r Nr[., j]  -> [split][j]
+  // DZ instantiation (head weight gradient + the data gradient of the layer below
+  // in one pass over H): dz_out[r, c] = (sum_j Nr[r, j] * Wn[j, c]) * (1 - Wd[r, c]^2)
+  const float* Wn;       // [NS][ldwn] head weights, wide-contiguous
+  int64_t ldwn;
+  float* dz_out;         // [rows][lddz]
+  int64_t lddz;
 };
 
 constexpr int SW_THREADS = 256;
@@ -180,8 +186,9 @@ constexpr int SW_LDS_FLOATS = 8192;    // 32 KB: narrow stage, then reduction st
 // operand in flight (the loads of the next step are issued before the FMAs of
 // the current one).  grid = (wide / 64, n_splits): 512 workgroups at the C3
 // minibatch, several per CU.
-// NV = round4(NS) / 4; NSUM: also the column sums of the narrow operand
-template <int NV, bool NSUM>
+// NV = round4(NS) / 4; NSUM: also the column sums of the narrow operand; DZ: also
+// the data gradient of the layer below (the wide operand is then its tanh output)
+template <int NV, bool NSUM, bool DZ = false>
 __global__ __launch_bounds__(SW_THREADS) void skinny_wgrad_kernel(SkinnyWgradParams p) {
   constexpr int U = NV <= 2 ? 8 : 4;
   __shared__ __attribute__((aligned(16))) float red[SW_LDS_FLOATS];
@@ -207,6 +214,13 @@ __global__ __launch_bounds__(SW_THREADS) void skinny_wgrad_kernel(SkinnyWgradPar
     if (NSUM) nsum[j] = 0.f;
   }
   const bool want_nsum = NSUM && colblk == 0 && q == 0;
+  float4 wq[DZ ? 4 * NV : 1];  // head weights of this thread's 4 columns
+  if (DZ) {
+#pragma unroll
+    for (int j = 0; j < 4 * NV; ++j)
+      wq[j] = (j < p.NS) ? *reinterpret_cast<const float4*>(p.Wn + (int64_t)j * p.ldwn + cc)
+                         : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
 
   for (int rc = r_beg; rc < r_end; rc += SW_CHUNK) {
     const int rc_end = min(r_end, rc + SW_CHUNK);
@@ -223,8 +237,14 @@ __global__ __launch_bounds__(SW_THREADS) void skinny_wgrad_kernel(SkinnyWgradPar
       const int r = i / NV, v = i % NV;
       const int row = min(rc + r, r_end - 1);
       const int64_t src = p.n_idx ? (int64_t)p.n_idx[row] : (int64_t)row;
-      *reinterpret_cast<float4*>(red + (r * NV + v) * 4) =
-          *reinterpret_cast<const float4*>(p.Nr + src * p.ldn + 4 * v);
+      float4 nv4 = *reinterpret_cast<const float4*>(p.Nr + src * p.ldn + 4 * v);
+      if (DZ) {  // padding columns may hold anything: they must not reach dz
+        nv4.x = (4 * v + 0 < p.NS) ? nv4.x : 0.f;
+        nv4.y = (4 * v + 1 < p.NS) ? nv4.y : 0.f;
+        nv4.z = (4 * v + 2 < p.NS) ? nv4.z : 0.f;
+        nv4.w = (4 * v + 3 < p.NS) ? nv4.w : 0.f;
+      }
+      *reinterpret_cast<float4*>(red + (r * NV + v) * 4) = nv4;
     }
     __syncthreads();
     for (int rb = rc + rg; rb < rc_end; rb += n_rg * U) {
@@ -244,6 +264,7 @@ __global__ __launch_bounds__(SW_THREADS) void skinny_wgrad_kernel(SkinnyWgradPar
         const int rl = min(r, rc_end - 1) - rc;
         const float4 wv = live ? w[u] : make_float4(0.f, 0.f, 0.f, 0.f);
         wsum.x += wv.x; wsum.y += wv.y; wsum.z += wv.z; wsum.w += wv.w;
+        float4 dz = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
           const float4 nv = *reinterpret_cast<const float4*>(red + (rl * NV + v) * 4);
@@ -256,7 +277,19 @@ __global__ __launch_bounds__(SW_THREADS) void skinny_wgrad_kernel(SkinnyWgradPar
             a.z = fmaf(wv.z, ns[j], a.z);
             a.w = fmaf(wv.w, ns[j], a.w);
             if (NSUM && want_nsum && live) nsum[4 * v + j] += ns[j];
+            if (DZ) {
+              const float4 wn = wq[4 * v + j];
+              dz.x = fmaf(ns[j], wn.x, dz.x);
+              dz.y = fmaf(ns[j], wn.y, dz.y);
+              dz.z = fmaf(ns[j], wn.z, dz.z);
+              dz.w = fmaf(ns[j], wn.w, dz.w);
+            }
           }
+        }
+        if (DZ && live && col_ok) {
+          dz.x *= (1.f - wv.x * wv.x); dz.y *= (1.f - wv.y * wv.y);
+          dz.z *= (1.f - wv.z * wv.z); dz.w *= (1.f - wv.w * wv.w);
+          *reinterpret_cast<float4*>(p.dz_out + (int64_t)r * p.lddz + c0) = dz;
         }
         __builtin_amdgcn_sched_barrier(0);  // keep the LDS reads row by row
       }
@@ -407,7 +440,8 @@ int ga_skinny_wgrad(const float* Wd, int64_t ldw, const int32_t* w_idx, const fl
                     int64_t ldn, const int32_t* n_idx, int rows, int wide, int NS,
                     int rows_per_split, int n_splits, float* C, int64_t c_wide_stride,
                     int64_t c_narrow_stride, int64_t split_stride, float* colsum_wide,
-                    float* colsum_narrow, hipStream_t stream) {
+                    float* colsum_narrow, const float* Wn, int64_t ldwn, float* dz_out,
+                    int64_t lddz, hipStream_t stream) {
   // whole rows of <= 64 floats (a power of two), else 64-float column blocks
   const int qpr = (wide % 4 != 0) ? 0
                   : (wide <= 4 * SW_QPR ? (pow2(wide / 4) ? wide / 4 : 0) : SW_QPR);
@@ -424,16 +458,25 @@ int ga_skinny_wgrad(const float* Wd, int64_t ldw, const int32_t* w_idx, const fl
   p.qpr = qpr; p.C = C; p.c_wide_stride = c_wide_stride;
   p.c_narrow_stride = c_narrow_stride; p.split_stride = split_stride;
   p.colsum_wide = colsum_wide; p.colsum_narrow = colsum_narrow;
+  p.Wn = Wn; p.ldwn = ldwn; p.dz_out = dz_out; p.lddz = lddz;
+  const bool dzf = dz_out != nullptr;
+  if (dzf && (w_idx || !Wn || ldwn % 4 != 0 || lddz % 4 != 0 || !ga_aligned16(Wn) ||
+              !ga_aligned16(dz_out) || NS > 16 || colsum_narrow == nullptr))
+    return 1;
   p.n_colblk = (int)ga_ceil_div(wide, 4 * qpr);
   p.n_splits = n_splits;
   dim3 grid((unsigned)(p.n_colblk * p.n_splits));
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  const double bytes = 4.0 * rows * ((double)wide + NS);
+  // algorithmic bytes: both operands once (+ the data gradient written once)
+  const double bytes = 4.0 * rows * ((double)wide * (dzf ? 2 : 1) + NS);
   ga_prof_events(GA_PROF_SKINNY_WGRAD, bytes, &e0, &e1);
   const bool nsum = colsum_narrow != nullptr;
 #define GA_SW_CASE(NVV)                                                              \
   case NVV:                                                                          \
-    if (nsum)                                                                        \
+    if (dzf && NVV <= 4)                                                             \
+      hipExtLaunchKernelGGL((skinny_wgrad_kernel<(NVV <= 4 ? NVV : 1), true, true>), \
+                            grid, dim3(SW_THREADS), 0, stream, e0, e1, 0, p);        \
+    else if (nsum)                                                                   \
       hipExtLaunchKernelGGL((skinny_wgrad_kernel<NVV, true>), grid, dim3(SW_THREADS), \
                             0, stream, e0, e1, 0, p);                                \
     else                                                                             \

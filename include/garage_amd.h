@@ -91,6 +91,10 @@ int ga_set_fused_forward(int on);
  * gradient, first-layer / head weight gradients) run as HBM-streaming kernels
  * instead of MFMA tiles (default on; 0 = MFMA tiles everywhere, for A/B runs). */
 int ga_set_skinny_kernels(int on);
+/* The head layer's weight-gradient streaming kernel also writes the data gradient
+ * of the layer below (same pass over the hidden activations) when the head is
+ * <= 16 wide (default on; 0 = separate data-gradient launch, for A/B runs). */
+int ga_set_fused_head_dgrad(int on);
 /* Forward-mode tangent of the MLP (torch/optimizers/conjugate_gradient_optimizer.py
  * :18-66 takes the same product by double backward): with dtheta = tangent (flat
  * parameter layout) and acts = the hidden activations of a forward at the same
