@@ -37,6 +37,13 @@ CONFIGS = {
     'c5': dict(name='Humanoid-shape synthetic, ragged', obs_dim=376,
                act_dim=17, n_envs=8192, T=256, hidden=(512, 512, 512),
                min_len=32),
+    # SURVEY.md section 8d setting (ii): the reference's default minibatch
+    # (ppo.py:65-76: 64 samples) on a reduced batch, 5 120 optimizer steps per
+    # iteration as in BASELINE.md section 2's reference measurement
+    'c3mb64': dict(name='HalfCheetah-shape synthetic, reference-default '
+                   'minibatch 64 on a reduced batch', obs_dim=17, act_dim=6,
+                   n_envs=64, T=256, hidden=(256, 256), min_len=None,
+                   minibatches=256),
 }
 HYPER = dict(discount=0.99, gae_lambda=0.97, lr_clip_range=0.2, lr=2.5e-4,
              epochs=10, minibatches_per_epoch=32)
@@ -71,6 +78,10 @@ def load_traffic():
         return json.load(f).get('kernels', {})
 
 
+def n_minibatches(cfg):
+    return cfg.get('minibatches', HYPER['minibatches_per_epoch'])
+
+
 def build_engine(cfg, comm, seed=1, algo_name='ppo'):
     from garage_amd.algos import PPO
     from garage_amd.distributed import shard_algo
@@ -94,7 +105,7 @@ def build_engine(cfg, comm, seed=1, algo_name='ppo'):
                             worker_args=dict(n_envs=n,
                                              store_agent_infos=False))
     S = n * T
-    mb = S // HYPER['minibatches_per_epoch']
+    mb = S // n_minibatches(cfg)
     opt = (torch.optim.Adam, dict(lr=HYPER['lr']))
     if algo_name == 'trpo':
         # one conjugate-gradient policy step on the full
@@ -176,7 +187,9 @@ def cpu_baseline(cfg, n_envs, seed=1):
                                   min_std=1e-6)
     vfp = nets.init_gaussian_mlp(rng, nets.VALUE_PREFIX, O, 1, cfg['hidden'])
     S = n_envs * T
-    mb = S // HYPER['minibatches_per_epoch']
+    # the sample keeps the GPU run's minibatch size when the config fixes it
+    mb = (cfg['n_envs'] * T // cfg['minibatches'] if 'minibatches' in cfg
+          else S // HYPER['minibatches_per_epoch'])
     algo = OraclePPO(polp, vfp, max_episode_length=T,
                      max_optimization_epochs=HYPER['epochs'],
                      minibatch_size=mb, policy_lr=HYPER['lr'],
@@ -215,7 +228,7 @@ def cpu_baseline(cfg, n_envs, seed=1):
                 '(E={}, {} minibatches/epoch); rollout {:.2f} s + update '
                 '{:.2f} s; host has {} logical CPUs'.format(
                     n_envs, T, steps, HYPER['epochs'],
-                    HYPER['minibatches_per_epoch'], t1 - t0, t2 - t1,
+                    S // mb, t1 - t0, t2 - t1,
                     os.cpu_count()))
 
 
@@ -237,6 +250,10 @@ def main():
     ap.add_argument('--no-head-dgrad-fusion', action='store_true',
                     help='A/B switch: separate launch for the data gradient '
                     'below the head layer')
+    ap.add_argument('--head-forward-fusion', type=int, default=None,
+                    choices=[0, 1, 2],
+                    help='A/B switch (ga_set_fused_head_forward): 0 separate '
+                    'head launch, 1 default, 2 also 256-wide hidden layers')
     ap.add_argument('--no-overlap', action='store_true',
                     help='run the policy and value-function passes one after '
                     'the other on one stream (isolated per-kernel timings)')
@@ -256,6 +273,9 @@ def main():
     if args.no_head_dgrad_fusion:
         from garage_amd import _lib
         _lib.load().ga_set_fused_head_dgrad(0)
+    if args.head_forward_fusion is not None:
+        from garage_amd import _lib
+        _lib.load().ga_set_fused_head_forward(args.head_forward_fusion)
 
     def sync():
         if comm is not None:
@@ -297,8 +317,8 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = S * world * args.steps / elapsed
     line = {
-        'metric': 'env-steps/sec (whole node) PPO 4096 envs'
-        if args.algo == 'ppo' else 'env-steps/sec (whole node) TRPO 4096 envs',
+        'metric': 'env-steps/sec (whole node) {} {} envs'.format(
+            args.algo.upper(), cfg['n_envs']),
         'value': value,
         'unit': 'env-steps/s',
         'n_gpus': world,
@@ -319,7 +339,7 @@ def main():
                             cfg['n_envs'], cfg['T'], cfg['hidden'],
                             'PPO' if args.algo == 'ppo' else
                             'TRPO (CG policy step) + value',
-                            HYPER['epochs'], HYPER['minibatches_per_epoch'],
+                            HYPER['epochs'], n_minibatches(cfg),
                             HYPER['discount'], HYPER['gae_lambda'],
                             HYPER['lr_clip_range'], HYPER['lr'],
                             'serial' if args.no_overlap else
@@ -405,7 +425,8 @@ def main():
         ]
     if args.cpu_envs > 0 and world == 1 and args.algo == 'ppo' \
             and not cfg.get('discrete'):
-        line['cpu_baseline'] = cpu_baseline(cfg, args.cpu_envs)
+        line['cpu_baseline'] = cpu_baseline(cfg, min(args.cpu_envs,
+                                                     cfg['n_envs']))
     print(json.dumps(line))
 
 

@@ -72,7 +72,82 @@ struct GemmParams {
   int colsum_of_b;       // 0: columns of A tile (index m), 1: of B tile (index n)
   int64_t colsum_split_stride;
   int gx, gy, gz;        // logical grid (m blocks, n blocks, splits); 1-D launch
+  // HEAD kernels (the tile spans all N columns): the next, narrow layer is applied to
+  // the staged output rows in the epilogue: head_out[m, j] = head_bias[j] +
+  // sum_n C(m, n) * head_W[j * head_ldw + n],  j < head_n <= 8
+  const float* head_W;
+  int64_t head_ldw;
+  const float* head_bias;
+  int head_n;
+  float* head_out;
+  int64_t head_ld;
 };
+
+// The narrow layer on 64 staged rows: lane = row, wave = a segment of CPS columns,
+// whose weights are wave-uniform and come through the scalar cache (constant
+// address space), so the inner product is v_fmac with an SGPR operand and LDS is
+// read once per element; the waves' partial sums meet in `hp` and are added in a
+// fixed order.
+template <int NT_ALL, int BN, int LDC>
+__device__ __forceinline__ void head_on_staged_rows(const GemmParams& p,
+                                                    const float* stage, float* hp,
+                                                    int n0, int m_base) {
+  typedef const __attribute__((address_space(4))) float* uniform_ptr;
+  constexpr int SEGS = NT_ALL / 64, CPS = BN / SEGS, HN = 8;
+  const int row = threadIdx.x & 63;
+  const int seg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  float4 h[CPS / 4];
+#pragma unroll
+  for (int i = 0; i < CPS / 4; ++i)
+    h[i] = *reinterpret_cast<const float4*>(stage + row * LDC + seg * CPS + 4 * i);
+  float a[HN];
+#pragma unroll
+  for (int j = 0; j < HN; ++j) {
+    a[j] = 0.f;
+    if (j < p.head_n) {
+      uniform_ptr w = (uniform_ptr)(uintptr_t)(p.head_W + (int64_t)j * p.head_ldw + n0 +
+                                               seg * CPS);
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int i = 0; i < CPS / 4; ++i) {
+        s0 = fmaf(h[i].x, w[4 * i + 0], s0);
+        s1 = fmaf(h[i].y, w[4 * i + 1], s1);
+        s0 = fmaf(h[i].z, w[4 * i + 2], s0);
+        s1 = fmaf(h[i].w, w[4 * i + 3], s1);
+      }
+      a[j] = s0 + s1;
+    }
+  }
+  // hp holds PL planes: waves PL.. add theirs onto plane (wave - PL) in a second step
+  constexpr int PL = SEGS < 4 ? SEGS : 4;
+  static_assert(SEGS <= 2 * PL, "two reduction steps");
+  float* mine = hp + ((seg % PL) * 64 + row) * HN;
+  if (seg < PL) {
+    *reinterpret_cast<float4*>(mine) = make_float4(a[0], a[1], a[2], a[3]);
+    *reinterpret_cast<float4*>(mine + 4) = make_float4(a[4], a[5], a[6], a[7]);
+  }
+  __syncthreads();
+  if (SEGS > PL) {
+    if (seg >= PL) {
+      float4 lo = *reinterpret_cast<const float4*>(mine);
+      float4 hi = *reinterpret_cast<const float4*>(mine + 4);
+      lo.x += a[0]; lo.y += a[1]; lo.z += a[2]; lo.w += a[3];
+      hi.x += a[4]; hi.y += a[5]; hi.z += a[6]; hi.w += a[7];
+      *reinterpret_cast<float4*>(mine) = lo;
+      *reinterpret_cast<float4*>(mine + 4) = hi;
+    }
+    __syncthreads();
+  }
+  for (int o = threadIdx.x; o < 64 * HN; o += NT_ALL) {
+    const int r = o / HN, j = o % HN;
+    if (j < p.head_n) {
+      float s = p.head_bias ? p.head_bias[j] : 0.f;
+#pragma unroll
+      for (int w = 0; w < PL; ++w) s += hp[(w * 64 + r) * HN + j];
+      p.head_out[(int64_t)(m_base + r) * p.head_ld + j] = s;
+    }
+  }
+}
 
 // One [BR x BK] operand tile: global -> registers -> LDS.
 //   KC = true : memory line = r (tile row), contiguous along k
@@ -294,7 +369,7 @@ __device__ __forceinline__ void gemm_mainloop(const GemmParams& p, float* lds,
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KC, bool B_KC,
-          int BKT = BK>
+          int BKT = BK, bool HEAD = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_f32_kernel(
     GemmParams p) {
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
@@ -303,7 +378,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_f32_kernel(
   constexpr int LDA_S = BM + PAD, LDB_S = BN + PAD, LDK = BKT + PAD;
   constexpr int A_FLOATS = A_KC ? BM * LDK : BKT * LDA_S;
   constexpr int B_FLOATS = B_KC ? BN * LDK : BKT * LDB_S;
-  __shared__ __attribute__((aligned(16))) float lds[A_FLOATS + B_FLOATS];
+  // (the epilogue stages 64 output rows in the same memory)
+  constexpr int STAGE_FLOATS = (BM % 64 == 0) ? 64 * (BN + 4) : 0;
+  constexpr int TILE_FLOATS =
+      A_FLOATS + B_FLOATS > STAGE_FLOATS ? A_FLOATS + B_FLOATS : STAGE_FLOATS;
+  // HEAD: + the waves' partial head sums, [<= 4 planes][64 rows][8]
+  constexpr int HEAD_PLANES = WAVES_M * WAVES_N < 4 ? WAVES_M * WAVES_N : 4;
+  constexpr int LDS_FLOATS = TILE_FLOATS + (HEAD ? HEAD_PLANES * 64 * 8 : 0);
+  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -360,8 +442,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_f32_kernel(
   // epilogues) are 16-B accesses and a wave instruction covers two whole 512-B
   // row segments instead of two 128-B ones.
   constexpr int NT_ALL = 64 * WAVES_M * WAVES_N;
-  constexpr bool TR_OK = 64 * (BN + 4) <= A_FLOATS + B_FLOATS && BM % 64 == 0 &&
-                         (64 * (BN / 4)) % NT_ALL == 0;
+  constexpr bool TR_OK = BM % 64 == 0 && (64 * (BN / 4)) % NT_ALL == 0;
   if (TR_OK && full && p.c_cs == 1 && (p.c_rs & 3) == 0 &&
       (reinterpret_cast<uintptr_t>(Cout) & 15u) == 0 &&
       (!p.H || ((p.ldh & 3) == 0 && (reinterpret_cast<uintptr_t>(p.H) & 15u) == 0)) &&
@@ -409,8 +490,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_f32_kernel(
           v.z *= (1.f - h.z * h.z); v.w *= (1.f - h.w * h.w);
         }
         *reinterpret_cast<float4*>(dst) = v;
+        if constexpr (HEAD) *reinterpret_cast<float4*>(lds + rr * LDC + 4 * c4) = v;
       }
       __syncthreads();
+      if constexpr (HEAD) {
+        head_on_staged_rows<NT_ALL, BN, LDC>(p, lds, lds + TILE_FLOATS, n0, m0 + hrow);
+        __syncthreads();
+      }
     }
     if (do_colsum) {
       const int W = p.colsum_of_b ? BN : BM;
@@ -501,6 +587,38 @@ int launch_gemm(const GemmParams& p_in, int splits, hipStream_t stream) {
 
 inline int round4(int v) { return (v + 3) & ~3; }
 
+// The last hidden layer and the head layer in one launch (tiles that span the
+// layer's whole width: 64, 128 or 256 units).  Returns 1 when the shape is not
+// taken -- every workgroup must be on the staged-epilogue path, which the kernel
+// decides from the same conditions.
+int launch_gemm_with_head(const GemmParams& p_in, hipStream_t stream) {
+  GemmParams p = p_in;
+  const int bm = 64;
+  if (!(p.N == 64 || p.N == 128 || p.N == 256) || p.M % bm != 0 || p.M < bm ||
+      p.head_n < 1 || p.head_n > 8 || p.head_ld < p.head_n || p.head_ldw % 4 != 0 ||
+      !ga_aligned16(p.head_W) || p.c_cs != 1 || (p.c_rs & 3) != 0 ||
+      !ga_aligned16(p.C) || (p.bias && !ga_aligned16(p.bias)) || p.H || p.accum ||
+      p.colsum || p.epi != EPI_BIAS_ACT || p.K < 1)
+    return 1;
+  p.gx = p.M / bm; p.gy = 1; p.gz = 1;
+  dim3 grid((unsigned)p.gx);
+  // algorithmic flops of both layers
+  const double flops = 2.0 * (double)p.M * (double)p.N * ((double)p.K + p.head_n);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  ga_prof_events(GA_PROF_GEMM_NT_128, flops, &e0, &e1);
+  if (p.N == 64)
+    hipExtLaunchKernelGGL((gemm_f32_kernel<64, 64, 2, 2, true, true, BK, true>), grid,
+                          dim3(256), 0, stream, e0, e1, 0, p);
+  else if (p.N == 128)
+    hipExtLaunchKernelGGL((gemm_f32_kernel<64, 128, 1, 4, true, true, BK, true>), grid,
+                          dim3(256), 0, stream, e0, e1, 0, p);
+  else
+    hipExtLaunchKernelGGL((gemm_f32_kernel<64, 256, 1, 8, true, true, BK, true>), grid,
+                          dim3(512), 0, stream, e0, e1, 0, p);
+  GA_CHECK_LAUNCH("gemm_f32 (+head)");
+  return GA_OK;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -546,6 +664,18 @@ int ga_skinny_wgrad(const float* Wd, int64_t ldw, const int32_t* w_idx, const fl
                     int64_t c_narrow_stride, int64_t split_stride, float* colsum_wide,
                     float* colsum_narrow, const float* Wn, int64_t ldwn, float* dz_out,
                     int64_t lddz, hipStream_t stream);
+// 0 off, 1 hidden layers up to 128 wide, 2 also 256-wide ones.  At 256 units the
+// fused launch (64 x 256 tiles, 75 KB of LDS) saves 7.7 us per minibatch with the
+// chip to itself (C3, one stream: 167.0 -> 160.6 ms per iteration) but loses 1 %
+// when the policy and value chains share the chip on two streams, where the narrow
+// head GEMM it replaces was hidden under the other chain's kernels anyway
+// (3 x A/B: 147.1 / 148.5 / 149.4 vs 146.6 / 146.7 / 147.5 ms) -- so the default
+// stops at 128 and both schedules keep the same arithmetic.
+static int g_fuse_head_forward = 1;
+extern "C" int ga_set_fused_head_forward(int mode) {
+  g_fuse_head_forward = mode < 0 ? 0 : (mode > 2 ? 2 : mode);
+  return 0;
+}
 static int g_fuse_head_dgrad = 1;
 extern "C" int ga_set_fused_head_dgrad(int on) {
   g_fuse_head_dgrad = on != 0;
@@ -615,6 +745,19 @@ extern "C" int ga_mlp_forward_f32(const ga_mlp_desc* d, const float* params,
                              nullptr, 0, p.C, p.c_rs, p.M, p.N, p.K, stream);
       if (rc < 0) return rc;
       if (rc == 0) continue;
+    }
+    if (out && l == L - 2 &&
+        (g_fuse_head_forward == 2 || (g_fuse_head_forward == 1 && p.N <= 128))) {
+      p.head_W = params + d->w_off[L - 1];
+      p.head_ldw = round4(d->dims[L - 1]);
+      p.head_bias = params + d->b_off[L - 1];
+      p.head_n = d->dims[L];
+      p.head_out = out;
+      p.head_ld = ldo;
+      rc = launch_gemm_with_head(p, stream);
+      if (rc < 0) return rc;
+      if (rc == 0) break;  // both layers done
+      p.head_n = 0;
     }
     rc = launch_gemm<true, true>(p, 1, stream);
     if (rc) return rc;

@@ -111,7 +111,7 @@ int run_minibatch(const ga_update_args* a, int64_t k, ga_stream_t stream) {
                            a->dout, a->ldo, a->dacts, a->slabs, a->n_flat, splits,
                            stream);
   if (rc) return rc;
-  if (!(a->comm && a->world > 1)) {
+  if (!a->comm) {
     // single process: slab sum and Adam in one launch
     return ga_reduce_adam_f32(a->slabs, splits, a->n_flat, a->params, a->grads,
                               a->exp_avg, a->exp_avg_sq, a->n_flat, a->step0 + k + 1,

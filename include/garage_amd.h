@@ -95,6 +95,14 @@ int ga_set_skinny_kernels(int on);
  * of the layer below (same pass over the hidden activations) when the head is
  * <= 16 wide (default on; 0 = separate data-gradient launch, for A/B runs). */
 int ga_set_fused_head_dgrad(int on);
+/* ga_mlp_forward_f32 applies the head layer (<= 8 outputs) in the epilogue of the
+ * last hidden layer's GEMM when that layer is 64 or 128 units wide (mode 2: also
+ * 256) and M is a multiple of 64: a workgroup's tile then spans whole rows, so the
+ * staged tanh outputs are multiplied with the head weights before they leave the
+ * CU and the narrow head GEMM (one more pass over the hidden activations)
+ * disappears.  mode 0 = separate head launch, 1 = default, 2 = 256-wide layers too
+ * (faster with one update chain on the chip, slower with two; gemm.hip). */
+int ga_set_fused_head_forward(int mode);
 /* Forward-mode tangent of the MLP (torch/optimizers/conjugate_gradient_optimizer.py
  * :18-66 takes the same product by double backward): with dtheta = tangent (flat
  * parameter layout) and acts = the hidden activations of a forward at the same

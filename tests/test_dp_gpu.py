@@ -42,11 +42,12 @@ def _make_shard(rank):
                 rewards=rng.randn(S), step_types=np.asarray(st), lengths=lens)
 
 
-def _rank_main(rank, world, port, q, init_pol, init_vf, algo_name='ppo'):
+def _rank_main(rank, world, port, q, init_pol, init_vf, algo_name='ppo',
+               backend='gloo'):
     try:
         os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank),
                           WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
-                          MASTER_PORT=str(port), GARAGE_AMD_BACKEND='gloo')
+                          MASTER_PORT=str(port), GARAGE_AMD_BACKEND=backend)
         import sys
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         sys.path.insert(0, root)
@@ -57,6 +58,12 @@ def _rank_main(rank, world, port, q, init_pol, init_vf, algo_name='ppo'):
         from garage_amd.policies import (GaussianMLPPolicy,
                                          GaussianMLPValueFunction)
         comm = init_from_env()
+        if comm is None:  # a world of one rank: still a real process group
+            import torch.distributed as dist
+            from garage_amd.distributed import Comm
+            torch.cuda.set_device(0)
+            dist.init_process_group(backend=backend, rank=0, world_size=1)
+            comm = Comm()
         spec = EnvSpec(Box(-np.inf, np.inf, (O, )), Box(-np.inf, np.inf, (A, )),
                        max_episode_length=P)
         pol = GaussianMLPPolicy(spec, hidden_sizes=(16, 16))
@@ -93,6 +100,9 @@ def _rank_main(rank, world, port, q, init_pol, init_vf, algo_name='ppo'):
         out = {k: v.numpy() for k, v in pol.state_dict().items()}
         out.update({'vf:' + k: v.numpy() for k, v in vf.state_dict().items()})
         out['tab'] = dict(algo.last_tabular)
+        out['native_comm'] = algo._policy_optimizer.native_comm is not None \
+            and algo._vf_optimizer.native_comm is not None
+        out['native_loop'] = bool(algo._native_update_ok())
         if algo_name == 'trpo':
             out['accepted'] = algo.last_cg['accepted']
         import torch.distributed as dist
@@ -306,3 +316,76 @@ def test_two_rank_trpo_equals_single_process_oracle():
     # both ranks hold the same parameters bit for bit
     for k in wp:
         assert np.array_equal(results[0][k], results[1][k]), k
+
+
+@pytest.mark.timeout(300)
+def test_rccl_communicators_of_one_rank_on_two_streams():
+    """``ga_comm_*`` against the real RCCL library with a world of one rank (all a
+    one-GPU box allows): unique id -> init -> in-place sum on a side stream and
+    on the current stream with two communicators, as the overlapped policy /
+    value passes use them -> destroy.  A one-rank sum returns its input."""
+    import ctypes as C
+
+    from garage_amd import _lib
+    lib = _lib.load()
+    dev = torch.device('cuda')
+    comms = []
+    for _ in range(2):
+        raw = (C.c_ubyte * 128)()
+        assert lib.ga_comm_unique_id(raw) == 0, lib.ga_last_error().decode()
+        h = lib.ga_comm_init_rank(raw, 0, 1)
+        assert h, lib.ga_last_error().decode()
+        comms.append(h)
+    side = torch.cuda.Stream()
+    a = torch.randn(71943, device=dev)
+    b = torch.randn(70658, device=dev)
+    a0, b0 = a.clone(), b.clone()
+    torch.cuda.synchronize()
+    for _ in range(3):
+        assert lib.ga_comm_allreduce_sum_f32(
+            comms[0], _lib.dptr(a), a.numel(), _lib.stream_ptr()) == 0
+        with torch.cuda.stream(side):
+            assert lib.ga_comm_allreduce_sum_f32(
+                comms[1], _lib.dptr(b), b.numel(), _lib.stream_ptr()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(a, a0) and torch.equal(b, b0)
+    for h in comms:
+        assert lib.ga_comm_destroy(h) == 0
+
+
+@pytest.mark.timeout(300)
+def test_one_rank_nccl_group_takes_the_rccl_branch_of_the_epoch_loop():
+    """``shard_algo`` over a real ``nccl`` (= RCCL) process group of one rank: the
+    library-owned communicators are created from the broadcast unique id, the
+    C++ epoch loop takes its data-parallel branch (scaled slab sum -> RCCL
+    all-reduce -> Adam) and the iteration equals the single-process oracle."""
+    from oracle import batch as ob
+    from oracle import networks as nets
+    from oracle.ppo import OraclePPO
+    rng = np.random.RandomState(0)
+    init_pol = nets.init_gaussian_mlp(rng, nets.POLICY_PREFIX, O, A, (16, 16),
+                                      min_std=1e-6)
+    init_vf = nets.init_gaussian_mlp(rng, nets.VALUE_PREFIX, O, 1, (16, 16))
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    proc = ctx.Process(target=_rank_main,
+                       args=(0, 1, port, q, init_pol, init_vf, 'ppo', 'nccl'))
+    proc.start()
+    rank, status, got = q.get(timeout=240)
+    proc.join(30)
+    assert status == 'ok', status
+    assert got['native_comm'] and got['native_loop']
+    batch = ob.OracleEpisodeBatch(max_episode_length=P, **_make_shard(0))
+    oracle = OraclePPO(init_pol, init_vf, max_episode_length=P,
+                       max_optimization_epochs=3, minibatch_size=None,
+                       policy_lr=1e-3, vf_lr=1e-3)
+    want = oracle.train_once(batch)
+    wp, wv = oracle.state()
+    for k, v in wp.items():
+        assert np.allclose(got[k], v, atol=2e-6), k
+    for k, v in wv.items():
+        assert np.allclose(got['vf:' + k], v, atol=2e-6), k
+    for k in ('policy/LossBefore', 'policy/LossAfter', 'policy/KL',
+              'vf/LossBefore', 'vf/LossAfter'):
+        assert np.isclose(got['tab'][k], want[k], atol=2e-5, rtol=2e-5), k
