@@ -394,12 +394,13 @@ class DeviceEpisodeBatch(EpisodeBatch):
     def __init__(self, env_spec, *, lengths, obs_dev, last_obs_dev,
                  actions_dev, rewards_dev, step_types_dev, ep_off_dev,
                  head_dev=None, head_name='mean', log_std=None,
-                 discrete=False, extras=None):
+                 discrete=False, extras=None, env_infos=None):
         # deliberately no base-class __init__: nothing to validate on host
         self.env_spec = env_spec
         self.lengths = np.asarray(lengths, dtype='l')
         self.episode_infos_by_episode = {}
-        self.env_infos = {}
+        # host arrays of shape (S, ...): what CPU environments reported per step
+        self.env_infos = dict(env_infos or {})
         self.obs_dev = obs_dev
         self.last_obs_dev = last_obs_dev
         self.actions_dev = actions_dev
@@ -463,5 +464,6 @@ class DeviceEpisodeBatch(EpisodeBatch):
                             observations=self.observations,
                             last_observations=self.last_observations,
                             actions=self.actions, rewards=self.rewards,
-                            env_infos={}, agent_infos=self.agent_infos,
+                            env_infos=dict(self.env_infos),
+                            agent_infos=self.agent_infos,
                             step_types=self.step_types, lengths=self.lengths)

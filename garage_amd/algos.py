@@ -772,6 +772,13 @@ class VPG:
             tab.record('MaxReturn', np.max(undiscounted))
             tab.record('MinReturn', np.min(undiscounted))
             tab.record('TerminationRate', np.mean(term))
+            if 'success' in batch.env_infos:  # CPU envs that report it
+                lengths = np.asarray(batch.lengths, dtype=np.int64)
+                flags = np.asarray(batch.env_infos['success']).reshape(
+                    int(lengths.sum()), -1).any(axis=1)
+                starts = np.concatenate([[0], np.cumsum(lengths)[:-1]])
+                tab.record('SuccessRate', np.mean(
+                    np.logical_or.reduceat(flags, starts).astype(np.float64)))
         self.last_performance = {
             'NumEpisodes': N,
             'AverageDiscountedReturn': float(np.mean(discounted)),

@@ -202,6 +202,11 @@ class NormalizedVecEnv(VecEnv):
     step_type = property(lambda self: self._env.step_type)
     env_id0 = property(lambda self: getattr(self._env, 'env_id0', 0))
 
+    @property
+    def last_env_infos(self):
+        """Pass-through of a wrapped CPU env batch's per-step ``env_info``."""
+        return getattr(self._env, 'last_env_infos', None)
+
     def advance(self):
         self._env.advance()
         if self._normalize_obs:
@@ -278,6 +283,10 @@ class HostVecEnv(VecEnv):
         self._h_rew = torch.zeros(n, dtype=torch.float32).pin_memory()
         self._h_st = torch.zeros(n, dtype=torch.uint8).pin_memory()
         self.discrete = is_discrete(self.spec.action_space)
+        # the last step's ``EnvStep.env_info`` per env (None when every env
+        # reported an empty dict); the worker files them per rollout column and
+        # packs them into ``EpisodeBatch.env_infos`` (vec_worker.py:192-193)
+        self.last_env_infos = None
 
     def _put_obs(self, i, obs):
         flat = np.asarray(obs, dtype=np.float32).reshape(-1)
@@ -290,14 +299,17 @@ class HostVecEnv(VecEnv):
 
     def step_all(self, actions):
         acts = actions.cpu().numpy()
-        O = self.obs_dim
+        infos, any_info = [], False
         for i, env in enumerate(self.envs):
             a = int(acts[i, 0]) if self.discrete else acts[i, :self.act_width]
             es = env.step(a)
             self._put_obs(i, es.observation)
             self._h_rew[i] = float(es.reward)
             self._h_st[i] = int(es.step_type)
-        del O
+            info = getattr(es, 'env_info', None) or {}
+            any_info = any_info or bool(info)
+            infos.append(info)
+        self.last_env_infos = infos if any_info else None
         self.next_obs.copy_(self._h_obs)
         self.reward.copy_(self._h_rew)
         self.step_type.copy_(self._h_st)

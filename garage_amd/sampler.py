@@ -165,6 +165,8 @@ class GpuVecWorker:
             'step_samples': torch.zeros(tcap, dtype=torch.int32, device=dev),
             'action': torch.zeros(n, lda, dtype=f32, device=dev),
             'done': torch.zeros(n, dtype=torch.uint8, device=dev),
+            # per column: the n ``env_info`` dicts of a CPU env batch (or None)
+            'infos': [None] * tcap,
         }
         if ldo != env.obs_dim:
             b['obs'].zero_()      # padding columns feed the GEMMs: keep them 0
@@ -204,6 +206,7 @@ class GpuVecWorker:
         else:
             call('ga_policy_head_sample', C.byref(a), s)
         env.step_all(b['action'])
+        b['infos'][col] = getattr(env, 'last_env_infos', None)
         r = self._record_args(b, col)
         call('ga_record_step', C.byref(r), s)
         env.reset_where(b['done'])
@@ -369,7 +372,25 @@ class GpuVecWorker:
             ep_off_dev=off_dev, head_dev=head,
             head_name='mean' if gaussian else 'prob',
             log_std=pol.clamped_log_std() if gaussian else None,
-            discrete=is_discrete(self.env.spec.action_space))
+            discrete=is_discrete(self.env.spec.action_space),
+            env_infos=self._packed_env_infos(b, src, tcap))
+
+    @staticmethod
+    def _packed_env_infos(b, src, tcap):
+        """``env_infos`` of the packed batch: per key an ``(S, ...)`` array in the
+        same sample order as the device arrays (``vec_worker.py:146-147,192-193``
+        builds the same arrays per episode).  Only CPU env batches report any."""
+        log = b.get('infos')
+        if not log or all(entry is None for entry in log):
+            return {}
+        cells = src.cpu().numpy().astype(np.int64)  # env * tcap + column
+        envs, cols = cells // tcap, cells % tcap
+        first = log[int(cols[0])][int(envs[0])] if cells.size else {}
+        out = {}
+        for key in first:
+            out[key] = np.asarray([log[int(c)][int(e)][key]
+                                   for e, c in zip(envs, cols)])
+        return out
 
     # -- reference-shaped API (one rollout() = until >=1 episode completes) ---
     def start_episode(self):
@@ -405,6 +426,7 @@ class GpuVecWorker:
         for k in ('obs', 'act', 'head', 'lastobs', 'rew', 'st'):
             if old[k] is not None:
                 new[k][:, :keep] = old[k][:, col - keep:col]
+        new['infos'][:keep] = old['infos'][col - keep:col]
         self._api_buf, self._api_col = new, keep
 
     def step_episode(self):
@@ -539,7 +561,8 @@ class GpuFragmentWorker(GpuVecWorker):
             step_types_dev=st, ep_off_dev=off_dev, head_dev=head,
             head_name='mean' if gaussian else 'prob',
             log_std=pol.clamped_log_std() if gaussian else None,
-            discrete=is_discrete(self.env.spec.action_space))
+            discrete=is_discrete(self.env.spec.action_space),
+            env_infos=self._packed_env_infos(b, src, tcap))
 
 
 class GpuVecSampler:

@@ -179,3 +179,64 @@ def performance_stats(batch, discount):
     if success:
         stats['SuccessRate'] = np.mean(success)
     return stats, undiscounted
+
+
+def select_episodes(batch, which):
+    """The episodes ``which`` (indices) of ``batch`` as a new batch, in that order
+    (``EpisodeBatch.split`` + ``concatenate``, ``_dtypes.py:592-674``)."""
+    ranges = list(batch.episode_ranges())
+    rows = np.concatenate([np.arange(*ranges[e]) for e in which])
+    which = np.asarray(which)
+    return OracleEpisodeBatch(
+        observations=batch.observations[rows],
+        last_observations=batch.last_observations[which],
+        actions=batch.actions[rows], rewards=batch.rewards[rows],
+        step_types=batch.step_types[rows], lengths=batch.lengths[which],
+        agent_infos={k: v[rows] for k, v in batch.agent_infos.items()},
+        env_infos={k: v[rows] for k, v in batch.env_infos.items()},
+        max_episode_length=batch.max_episode_length)
+
+
+def multitask_performance_stats(itr, batch, discount, name_map=None):
+    """What ``log_multitask_performance`` records (``_functions.py:177-230``), as
+    ``{prefixed key: value}`` plus the undiscounted returns it returns.
+
+    Episodes are grouped by the FIRST step's ``task_name`` env-info, else by
+    ``name_map[task_id]`` (default ``'Task #<id>'``), else ``'__unnamed_task__'``;
+    with a ``name_map`` every listed task (and only those) is logged, absent
+    ones as NaN rows with ``NumEpisodes = 0``; the whole batch is logged under
+    ``Average/``."""
+    groups = {}
+    for e, (start, _) in enumerate(batch.episode_ranges()):
+        name = '__unnamed_task__'
+        if 'task_name' in batch.env_infos:
+            name = batch.env_infos['task_name'][start]
+        elif 'task_id' in batch.env_infos:
+            # (_functions.py:204: the map is REPLACED by {} when it was None, so
+            # with task ids and no map the per-task rows below are skipped --
+            # ``task_names = name_map.values()`` is then empty; pinned by
+            # tests/golden/multitask.npz ``ids_nomap``)
+            name_map = {} if name_map is None else name_map
+            task_id = batch.env_infos['task_id'][start]
+            name = name_map.get(task_id, 'Task #{}'.format(task_id))
+        groups.setdefault(name, []).append(e)
+    names = list(groups) if name_map is None else list(name_map.values())
+    out = {}
+    for name in names:
+        out[name + '/Iteration'] = itr
+        if name in groups:
+            stats, _ = performance_stats(select_episodes(batch, groups[name]),
+                                         discount)
+            for k, v in stats.items():
+                out[name + '/' + k] = v
+        else:
+            out[name + '/NumEpisodes'] = 0
+            for k in ('AverageDiscountedReturn', 'AverageReturn', 'StdReturn',
+                      'MaxReturn', 'MinReturn', 'TerminationRate',
+                      'SuccessRate'):
+                out[name + '/' + k] = np.nan
+    stats, undiscounted = performance_stats(batch, discount)
+    out['Average/Iteration'] = itr
+    for k, v in stats.items():
+        out['Average/' + k] = v
+    return out, undiscounted

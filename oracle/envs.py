@@ -202,3 +202,27 @@ class CountingEnv:
 
     def close(self):
         pass
+
+
+class TaskEnv(CountingEnv):
+    """``CountingEnv`` that reports multi-task ``env_info`` entries the way the
+    reference's multi-task wrappers do (``envs/multi_env_wrapper.py:216-219``
+    adds ``task_id`` / ``task_name``; MetaWorld-style envs add ``success``):
+    ``success`` turns on at step ``success_at`` of an episode (never if None)."""
+
+    def __init__(self, env_id, lengths, max_episode_length, task_id,
+                 task_name=None, success_at=None):
+        super().__init__(env_id, lengths, max_episode_length)
+        self.task_id = task_id
+        self.task_name = task_name
+        self.success_at = success_at
+
+    def step(self, action):
+        es = super().step(action)
+        info = {'task_id': self.task_id,
+                'success': bool(self.success_at is not None
+                                and self._t >= self.success_at)}
+        if self.task_name is not None:
+            info['task_name'] = self.task_name
+        return EnvStepLite(es.action, es.reward, es.observation, info,
+                           es.step_type)

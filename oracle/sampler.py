@@ -126,6 +126,7 @@ class OracleVecWorker:
     def _clear(self, i):
         self._obs[i], self._act[i], self._rew[i], self._st[i] = [], [], [], []
         self._infos[i] = {}
+        self._env_infos[i] = {}
         self._lengths[i] = 0
 
     def start_episode(self):
@@ -145,6 +146,7 @@ class OracleVecWorker:
         self._rew = [[] for _ in range(n)]
         self._st = [[] for _ in range(n)]
         self._infos = [{} for _ in range(n)]
+        self._env_infos = [{} for _ in range(n)]
         self._lengths = [0] * n
         self._needs_agent_reset = False
         self._needs_env_reset = False
@@ -160,6 +162,7 @@ class OracleVecWorker:
                 step_types=np.asarray(self._st[i], dtype=object),
                 lengths=np.asarray([self._lengths[i]], dtype='l'),
                 agent_infos=_stack_infos(self._infos[i]),
+                env_infos=_stack_infos(self._env_infos[i]),
                 max_episode_length=self._max_episode_length))
         self._clear(i)
         self._prev_obs[i] = self._envs[i].reset()[0]
@@ -180,6 +183,8 @@ class OracleVecWorker:
                 self._act[i].append(es.action)
                 for k, v in agent_info.items():
                     self._infos[i].setdefault(k, []).append(v[i])
+                for k, v in es.env_info.items():  # vec_worker.py:192-193
+                    self._env_infos[i].setdefault(k, []).append(v)
                 self._lengths[i] += 1
                 self._st[i].append(es.step_type)
                 self._prev_obs[i] = es.observation

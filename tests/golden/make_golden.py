@@ -644,6 +644,43 @@ def gen_log_performance():
     save('log_performance', **out)
 
 
+def gen_multitask():
+    """env_infos through the real VecWorker + log_multitask_performance."""
+    out = {}
+    P, n = 6, 4
+    cyc = [[3, 6, 2], [4, 4, 4], [6, 1, 5], [2, 2, 6]]
+    names = ['reach', 'push', 'reach', None]
+    for tag, use_names, name_map in (
+            ('named', True, None),
+            ('ids', False, {0: 'zero', 1: 'one', 5: 'five'}),
+            ('ids_nomap', False, None)):
+        envs = [
+            RefEnv(oenvs.TaskEnv(i, cyc[i], P, task_id=i % 2,
+                                 task_name=(names[i] or 'pick')
+                                 if use_names else None,
+                                 success_at=[2, None, 5, 1][i]), 3, 2, P)
+            for i in range(n)
+        ]
+        pol = ScriptedVecPolicy(2)
+        wf = WorkerFactory(seed=1, n_workers=1, worker_class=VecWorker,
+                           worker_args=dict(n_envs=n), max_episode_length=P)
+        sampler = LocalSampler.from_worker_factory(wf, pol, [envs])
+        eps = sampler.obtain_samples(0, 40, None)
+        out.update(batch_arrays(tag + '_', eps))
+        for k, v in eps.env_infos.items():
+            out[tag + '_env_' + k] = np.asarray(v)
+        rec = ref.TabularRecorder()
+        gfun.tabular = rec
+        und = gfun.log_multitask_performance(7, eps, 0.9, name_map=name_map)
+        out[tag + '_undiscounted'] = np.asarray(und)
+        out[tag + '_keys'] = np.asarray(list(rec.values.keys()))
+        out[tag + '_vals'] = np.asarray(
+            [float(v) for v in rec.values.values()])
+    out['cfg'] = np.asarray([P, n])
+    out['cycles'] = np.asarray(cyc)
+    save('multitask', **out)
+
+
 if __name__ == '__main__':
     print('reference:', garage.__file__)
     if len(sys.argv) > 1:  # regenerate selected fixtures only, e.g. `trpo`
@@ -661,3 +698,4 @@ if __name__ == '__main__':
     gen_train_once()
     gen_normalized_env()
     gen_log_performance()
+    gen_multitask()

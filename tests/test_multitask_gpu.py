@@ -1,0 +1,114 @@
+"""what CPU environments report per step
+(``EnvStep.env_info``: task ids / names, success flags) survives the device
+sampler as ``EpisodeBatch.env_infos``, and ``log_performance`` /
+``log_multitask_performance`` record the reference's rows from it.  Expected
+values: tests/golden/multitask.npz, captured from the real
+``LocalSampler(VecWorker)`` and ``garage.log_multitask_performance``.
+"""
+import numpy as np
+import pytest
+import torch
+
+from test_oracle_golden import (MULTITASK_CASES, check_multitask,
+                                multitask_envs)
+
+pytestmark = pytest.mark.gpu
+
+
+def _sampler(g, use_names, worker_class=None, **worker_args):
+    from garage_amd._dtypes import Box, EnvSpec
+    from garage_amd.policies import GaussianMLPPolicy
+    from garage_amd.sampler import GpuVecSampler, GpuVecWorker
+    envs, P, n = multitask_envs(g, use_names)
+    spec = EnvSpec(Box(-np.inf, np.inf, (3, )), Box(-np.inf, np.inf, (2, )),
+                   max_episode_length=P)
+    for env in envs:
+        env.spec = spec
+    torch.manual_seed(0)
+    pol = GaussianMLPPolicy(spec, hidden_sizes=(8, ))
+    return GpuVecSampler(pol, [envs], max_episode_length=P, n_workers=1,
+                         worker_class=worker_class or GpuVecWorker,
+                         worker_args=dict(n_envs=n, **worker_args)), n
+
+
+@pytest.mark.parametrize('tag', sorted(MULTITASK_CASES))
+def test_env_infos_and_multitask_rows_match_the_reference(golden, tag):
+    from garage_amd import logger
+    from garage_amd.functions import (log_multitask_performance,
+                                      log_performance)
+    g = golden('multitask')
+    use_names, name_map = MULTITASK_CASES[tag]
+    sampler, _ = _sampler(g, use_names)
+    eps = sampler.obtain_samples(0, 40, None)
+    # the environments ignore the actions: every env-side field is the golden's
+    assert np.array_equal(eps.lengths, g[tag + '_lengths'])
+    assert np.array_equal(eps.rewards, g[tag + '_rewards'])
+    assert np.array_equal([int(s) for s in eps.step_types],
+                          g[tag + '_step_types'])
+    want = {k[len(tag) + 5:]: g[k] for k in g.files
+            if k.startswith(tag + '_env_')}
+    assert set(eps.env_infos) == set(want)
+    for k, v in want.items():
+        assert eps.env_infos[k].shape == v.shape, k
+        assert np.array_equal(eps.env_infos[k], v), k
+    host = eps.to_host()  # validated: every env_info has S leading rows
+    assert set(host.env_infos) == set(want)
+
+    logger.tabular.clear()
+    und = log_multitask_performance(7, eps, 0.9, name_map=name_map)
+    check_multitask(g, tag, logger.tabular.as_dict, und)
+    # the same rows from a plain host EpisodeBatch (any other garage sampler)
+    logger.tabular.clear()
+    und = log_multitask_performance(7, host, 0.9, name_map=name_map)
+    check_multitask(g, tag, logger.tabular.as_dict, und)
+    # log_performance on the whole batch = the 'Average/' block
+    logger.tabular.clear()
+    log_performance(7, eps, 0.9, prefix='Average')
+    rec = logger.tabular.as_dict
+    keys = [str(k) for k in g[tag + '_keys']]
+    vals = dict(zip(keys, g[tag + '_vals']))
+    assert list(rec) == [k for k in keys if k.startswith('Average/')]
+    for k, v in rec.items():
+        assert np.isclose(float(v), vals[k]), k
+
+
+def test_ppo_logs_success_rate_from_env_infos(golden):
+    """``PPO._train_once`` -> ``Evaluation/SuccessRate`` when the environments
+    report ``success`` (``_functions.py:258-259,272-273``)."""
+    from garage_amd import logger
+    from garage_amd.algos import PPO
+    from garage_amd.policies import GaussianMLPValueFunction
+    g = golden('multitask')
+    sampler, _ = _sampler(g, True)
+    eps = sampler.obtain_samples(0, 40, None)
+    pol = sampler._workers[0].agent
+    vf = GaussianMLPValueFunction(eps.env_spec, hidden_sizes=(8, ))
+    algo = PPO(env_spec=eps.env_spec, policy=pol, value_function=vf,
+               sampler=sampler)
+    logger.tabular.clear()
+    algo._train_once(7, eps)
+    keys = [str(k) for k in g['named_keys']]
+    vals = dict(zip(keys, g['named_vals']))
+    rec = logger.tabular.as_dict
+    assert np.isclose(float(rec['Evaluation/SuccessRate']),
+                      vals['Average/SuccessRate'])
+    assert np.isclose(float(rec['Evaluation/AverageReturn']),
+                      vals['Average/AverageReturn'])
+
+
+def test_fragment_worker_carries_env_infos(golden):
+    """``GpuFragmentWorker`` fragments keep the per-step env_infos too."""
+    from garage_amd.sampler import GpuFragmentWorker
+    g = golden('multitask')
+    sampler, n = _sampler(g, True, worker_class=GpuFragmentWorker,
+                          timesteps_per_call=2)
+    eps = sampler.obtain_samples(0, 16, None)
+    S = int(eps.lengths.sum())
+    assert set(eps.env_infos) == {'task_id', 'task_name', 'success'}
+    for v in eps.env_infos.values():
+        assert v.shape[0] == S
+    # obs = [env_id, episode, t] and env i reports task_id = i % 2
+    env_ids = eps.observations[:, 0].astype(np.int64)
+    assert np.array_equal(eps.env_infos['task_id'], env_ids % 2)
+    names = np.asarray(['reach', 'push', 'reach', 'pick'])
+    assert np.array_equal(eps.env_infos['task_name'], names[env_ids])

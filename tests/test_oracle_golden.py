@@ -407,6 +407,57 @@ def test_golden_log_performance(golden):
             assert np.isclose(v, float(g[tag + ':Evaluation/' + k])), k
 
 
+MULTITASK_CASES = {
+    'named': (True, None),
+    'ids': (False, {0: 'zero', 1: 'one', 5: 'five'}),
+    'ids_nomap': (False, None),
+}
+
+
+def multitask_envs(g, use_names):
+    """The environments tests/golden/make_golden.py::gen_multitask stepped."""
+    P, n = [int(v) for v in g['cfg']]
+    cyc = g['cycles']
+    names = ['reach', 'push', 'reach', 'pick']
+    return [
+        oenvs.TaskEnv(i, cyc[i], P, task_id=i % 2,
+                      task_name=names[i] if use_names else None,
+                      success_at=[2, None, 5, 1][i]) for i in range(n)
+    ], P, n
+
+
+def check_multitask(g, tag, recorded, undiscounted):
+    keys = [str(k) for k in g[tag + '_keys']]
+    assert list(recorded) == keys  # same rows, same order
+    for k, want in zip(keys, g[tag + '_vals']):
+        got = float(recorded[k])
+        assert (np.isnan(got) and np.isnan(want)) or np.isclose(got, want), k
+    assert np.allclose(undiscounted, g[tag + '_undiscounted'])
+
+
+@pytest.mark.parametrize('tag', sorted(MULTITASK_CASES))
+def test_golden_multitask_env_infos_and_performance(golden, tag):
+    """env_infos through the VecWorker restatement and the rows
+    ``log_multitask_performance`` records, against the real reference
+    (including its dropped per-task rows for task ids without a name map)."""
+    g = golden('multitask')
+    use_names, name_map = MULTITASK_CASES[tag]
+    envs, P, n = multitask_envs(g, use_names)
+    s = osamp.OracleLocalSampler(_Scripted(2), [envs], max_episode_length=P,
+                                 n_workers=1,
+                                 worker_class=osamp.OracleVecWorker,
+                                 worker_args=dict(n_envs=n, alias_bug=True))
+    eps = s.obtain_samples(0, 40, None)
+    _check_batch(g, tag + '_', eps)
+    want_keys = {k[len(tag) + 5:] for k in g.files
+                 if k.startswith(tag + '_env_')}
+    assert set(eps.env_infos) == want_keys
+    for k in want_keys:
+        assert np.array_equal(eps.env_infos[k], g[tag + '_env_' + k]), k
+    rec, und = ob.multitask_performance_stats(7, eps, 0.9, name_map=name_map)
+    check_multitask(g, tag, rec, und)
+
+
 TRPO_CASES = {
     'trpo': {},
     'trpo_tight': {},
