@@ -546,6 +546,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_f32_kernel(
   }
 }
 
+static int g_small_m = 1;
+
 template <bool A_KC, bool B_KC>
 int launch_gemm(const GemmParams& p_in, int splits, hipStream_t stream) {
   GemmParams p = p_in;
@@ -553,7 +555,27 @@ int launch_gemm(const GemmParams& p_in, int splits, hipStream_t stream) {
   // algorithmic flops: 2 M N K (the padding of ragged tiles is not counted)
   const double flops = 2.0 * (double)p.M * (double)p.N * (double)p.K;
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (p.N <= 32) {
+  if (g_small_m && splits == 1 && p.K > 64 &&
+      (p.N > 32 ? ga_ceil_div(p.M, 128) * ga_ceil_div(p.N, 128) <= 128 : p.M <= 4096)) {
+    // fewer 128x128 tiles than half the CUs: the k-loop of one workgroup is then a
+    // chain of dependent memory round trips (the weights were rewritten by the
+    // optimizer step just before, so they come from beyond this XCD's L2) with
+    // nothing else on the CU to hide them.  64x64 tiles spread rows and columns
+    // over 4x the workgroups and a 128-deep k-step cuts the chain to K / 128 round
+    // trips with 16 16-B loads in flight per thread.  Same k order per output
+    // element as every other tile shape, so the results are bit-identical.
+    // MLP(256,256) forward + backward at 64 rows: 43.6 + 54.3 -> 26.5 + 33.3 us,
+    // at 4096 rows 43.5 + 81.2 -> 31.3 + 66.8 us; MLP(512,512,512) at 64 rows
+    // 149.5 + 141.9 -> 61.7 + 69.5 us (tools/small_m_ab.py).  Narrow outputs (the
+    // head layer) take the same kernel up to 4096 rows: a half-empty tile costs
+    // nothing when the launch is one round-trip chain anyway.
+    p.gx = (int)ga_ceil_div(p.M, 64); p.gy = (int)ga_ceil_div(p.N, 64); p.gz = 1;
+    p.k_per_split = (int)ga_ceil_div(p.K, 128) * 128;
+    dim3 grid((unsigned)(p.gx * p.gy));
+    ga_prof_events(GA_PROF_GEMM_NT_128 + mode, flops, &e0, &e1);
+    hipExtLaunchKernelGGL((gemm_f32_kernel<64, 64, 2, 2, A_KC, B_KC, 128>), grid,
+                          dim3(256), 0, stream, e0, e1, 0, p);
+  } else if (p.N <= 32) {
     // narrow outputs are HBM bound on the wide operand: 128-row tiles give
     // M/128 workgroups (256 at the C3 minibatch) to pull it through
     p.gx = (int)ga_ceil_div(p.M, 128); p.gy = (int)ga_ceil_div(p.N, 32); p.gz = splits;
@@ -674,6 +696,10 @@ int ga_skinny_wgrad(const float* Wd, int64_t ldw, const int32_t* w_idx, const fl
 static int g_fuse_head_forward = 1;
 extern "C" int ga_set_fused_head_forward(int mode) {
   g_fuse_head_forward = mode < 0 ? 0 : (mode > 2 ? 2 : mode);
+  return 0;
+}
+extern "C" int ga_set_small_m_gemm(int on) {
+  g_small_m = on != 0;
   return 0;
 }
 static int g_fuse_head_dgrad = 1;

@@ -52,7 +52,45 @@ struct PpoLossParams {
   float* dmean;           // optional [M, ldm]: dLoss/dmean (already / M)
   float* ll_out;          // optional [M]: new log-likelihoods
   double* partials;       // [gridDim.x][2]: sum objective, sum dLoss/dlog_std * M
+  // single-block launches (minibatches of <= 256 rows) finish in the same kernel
+  // (no second launch): the scalars the finalize kernel would write
+  float* loss_out;        // null: a finalize launch follows
+  float* grad_slab0;
+  int64_t slab_stride, n_splits;
 };
+
+// Loss value and the log-std gradient slot from the batch sums (thread 0 of the
+// finalize kernel, or of the loss kernel when it is the only block).
+__device__ void ppo_gaussian_finish(double obj, double ds, const float* log_std,
+                                    int has_min, float min_log_std, int has_max,
+                                    float max_log_std, int64_t M, int A,
+                                    float ent_coeff, int ent_regularized,
+                                    int ent_softplus, int ent_stop_grad,
+                                    float* loss_out, float* grad_slab0,
+                                    int64_t slab_stride, int64_t n_splits) {
+  float s = *log_std;
+  bool s_grad = true;
+  if (has_min && s < min_log_std) { s = min_log_std; s_grad = false; }
+  if (has_max && s > max_log_std) { s = max_log_std; s_grad = false; }
+  double mean_obj = obj / (double)M;
+  double dlogstd = ds / (double)M;  // d(-mean obj)/ds through the likelihood
+  if (ent_regularized) {
+    // Independent Normal entropy: A * (0.5 + 0.5 log 2pi + s), state independent
+    float ent = (float)A * (0.5f + (float)HALF_LOG_2PI + s);
+    float dent = (float)A;
+    if (ent_softplus) {
+      dent *= sigmoidf(ent);
+      ent = softplusf(ent);
+    }
+    mean_obj += (double)(ent_coeff * ent);
+    if (!ent_stop_grad) dlogstd += -(double)(ent_coeff * dent);
+  }
+  *loss_out = (float)(-mean_obj);
+  if (grad_slab0) {
+    grad_slab0[0] = s_grad ? (float)dlogstd : 0.f;
+    for (int64_t k = 1; k < n_splits; ++k) grad_slab0[k * slab_stride] = 0.f;
+  }
+}
 
 __global__ __launch_bounds__(256) void ppo_gaussian_loss_kernel(PpoLossParams p) {
   __shared__ double red[4];
@@ -112,8 +150,15 @@ __global__ __launch_bounds__(256) void ppo_gaussian_loss_kernel(PpoLossParams p)
   const double o = ga_block_sum_256(obj_sum, red);
   const double d = ga_block_sum_256(ds_sum, red);
   if (threadIdx.x == 0) {
-    p.partials[2 * blockIdx.x + 0] = o;
-    p.partials[2 * blockIdx.x + 1] = d;
+    if (p.loss_out) {  // the only block: o and d are the batch sums
+      ppo_gaussian_finish(o, d, p.log_std, p.has_min, p.min_log_std, p.has_max,
+                          p.max_log_std, p.M, p.A, p.ent_coeff, p.ent_regularized,
+                          p.ent_softplus, p.ent_stop_grad, p.loss_out, p.grad_slab0,
+                          p.slab_stride, p.n_splits);
+    } else {
+      p.partials[2 * blockIdx.x + 0] = o;
+      p.partials[2 * blockIdx.x + 1] = d;
+    }
   }
   (void)s_grad;
   (void)s_raw;
@@ -145,28 +190,10 @@ __global__ void ppo_gaussian_finalize_kernel(PpoFinalizeParams p) {
   obj = ga_wave_sum(obj);
   ds = ga_wave_sum(ds);
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  float s = *p.log_std;
-  bool s_grad = true;
-  if (p.has_min && s < p.min_log_std) { s = p.min_log_std; s_grad = false; }
-  if (p.has_max && s > p.max_log_std) { s = p.max_log_std; s_grad = false; }
-  double mean_obj = obj / (double)p.M;
-  double dlogstd = ds / (double)p.M;  // d(-mean obj)/ds through the likelihood
-  if (p.ent_regularized) {
-    // Independent Normal entropy: A * (0.5 + 0.5 log 2pi + s), state independent
-    float ent = (float)p.A * (0.5f + (float)HALF_LOG_2PI + s);
-    float dent = (float)p.A;
-    if (p.ent_softplus) {
-      dent *= sigmoidf(ent);
-      ent = softplusf(ent);
-    }
-    mean_obj += (double)(p.ent_coeff * ent);
-    if (!p.ent_stop_grad) dlogstd += -(double)(p.ent_coeff * dent);
-  }
-  *p.loss_out = (float)(-mean_obj);
-  if (p.grad_slab0) {
-    p.grad_slab0[0] = s_grad ? (float)dlogstd : 0.f;
-    for (int64_t k = 1; k < p.n_splits; ++k) p.grad_slab0[k * p.slab_stride] = 0.f;
-  }
+  ppo_gaussian_finish(obj, ds, p.log_std, p.has_min, p.min_log_std, p.has_max,
+                      p.max_log_std, p.M, p.A, p.ent_coeff, p.ent_regularized,
+                      p.ent_softplus, p.ent_stop_grad, p.loss_out, p.grad_slab0,
+                      p.slab_stride, p.n_splits);
 }
 
 // ---- categorical policy head ---------------------------------------------------
@@ -357,6 +384,9 @@ struct NllParams {
   int64_t M;
   float* dv;             // optional [M, ldv] column 0
   double* partials;      // [gridDim.x][2]
+  float* loss_out;       // single-block launches finish here; null: finalize follows
+  float* grad_slab0;
+  int64_t slab_stride, n_splits;
 };
 
 __global__ __launch_bounds__(256) void gaussian_nll_kernel(NllParams p) {
@@ -377,8 +407,17 @@ __global__ __launch_bounds__(256) void gaussian_nll_kernel(NllParams p) {
   const double a = ga_block_sum_256(nll, red);
   const double b = ga_block_sum_256(ds, red);
   if (threadIdx.x == 0) {
-    p.partials[2 * blockIdx.x + 0] = a;
-    p.partials[2 * blockIdx.x + 1] = b;
+    if (p.loss_out) {  // the only block: a and b are the batch sums
+      *p.loss_out = (float)(a / (double)p.M);
+      if (p.grad_slab0) {
+        p.grad_slab0[0] = (float)(b / (double)p.M);
+        for (int64_t k = 1; k < p.n_splits; ++k)
+          p.grad_slab0[k * p.slab_stride] = 0.f;
+      }
+    } else {
+      p.partials[2 * blockIdx.x + 0] = a;
+      p.partials[2 * blockIdx.x + 1] = b;
+    }
   }
 }
 
@@ -676,8 +715,12 @@ extern "C" int ga_ppo_gaussian_loss_f32(
   p.ent_stop_grad = (ent_flags >> 2) & 1;
   p.dmean = dmean; p.ll_out = ll_out; p.partials = workspace;
   const int nb = red_blocks(M);
+  const bool one_launch = nb == 1;
+  p.loss_out = one_launch ? loss_out : nullptr;
+  p.grad_slab0 = grad_slab0; p.slab_stride = slab_stride; p.n_splits = n_splits;
   hipLaunchKernelGGL(ppo_gaussian_loss_kernel, dim3(nb), dim3(256), 0, stream, p);
   GA_CHECK_LAUNCH("ppo_gaussian_loss");
+  if (one_launch) return GA_OK;
   PpoFinalizeParams f;
   f.partials = workspace; f.nblocks = nb; f.log_std = log_std;
   f.min_log_std = min_log_std; f.max_log_std = max_log_std; f.has_min = has_min;
@@ -750,8 +793,12 @@ extern "C" int ga_gaussian_nll_loss_f32(const float* v, int64_t ldv,
   p.v = v; p.ldv = ldv; p.returns = returns; p.idx = idx; p.log_std = log_std;
   p.M = M; p.dv = dv; p.partials = workspace;
   const int nb = red_blocks(M);
+  const bool one_launch = nb == 1;
+  p.loss_out = one_launch ? loss_out : nullptr;
+  p.grad_slab0 = grad_slab0; p.slab_stride = slab_stride; p.n_splits = n_splits;
   hipLaunchKernelGGL(gaussian_nll_kernel, dim3(nb), dim3(256), 0, stream, p);
   GA_CHECK_LAUNCH("gaussian_nll");
+  if (one_launch) return GA_OK;
   hipLaunchKernelGGL(gaussian_nll_finalize_kernel, dim3(1), dim3(64), 0, stream,
                      (const double*)workspace, nb, M, loss_out, grad_slab0,
                      slab_stride, n_splits);
@@ -1249,6 +1296,7 @@ extern "C" int ga_head_ppo_gaussian_loss_f32(
   p.ent_regularized = ent_flags & 1; p.ent_softplus = (ent_flags >> 1) & 1;
   p.ent_stop_grad = (ent_flags >> 2) & 1;
   p.dmean = dmean; p.ll_out = ll_out; p.partials = workspace;
+  p.loss_out = nullptr; p.grad_slab0 = nullptr; p.slab_stride = 0; p.n_splits = 0;
   const int nb = head_blocks(M);
   const unsigned lds =
       (unsigned)((A * hidden_width + ((A + 3) & ~3) + 16 * 4 * A) * sizeof(float));
@@ -1290,6 +1338,7 @@ extern "C" int ga_head_gaussian_nll_loss_f32(
   NllParams p;
   p.v = nullptr; p.ldv = ldd; p.returns = returns; p.idx = idx; p.log_std = log_std;
   p.M = M; p.dv = dv; p.partials = workspace;
+  p.loss_out = nullptr; p.grad_slab0 = nullptr; p.slab_stride = 0; p.n_splits = 0;
   const int nb = head_blocks(M);
   const unsigned lds = (unsigned)((hidden_width + 4 + 16 * 4) * sizeof(float));
   switch (hidden_width / 64) {

@@ -103,6 +103,11 @@ int ga_set_fused_head_dgrad(int on);
  * disappears.  mode 0 = separate head launch, 1 = default, 2 = 256-wide layers too
  * (faster with one update chain on the chip, slower with two; gemm.hip). */
 int ga_set_fused_head_forward(int mode);
+/* GEMMs with at most 128 tiles of 128 x 128 (minibatches of a few thousand rows
+ * and below, e.g. the reference's default minibatch of 64) run on 64 x 64 tiles
+ * with 128-deep k-steps: more workgroups, K / 128 dependent memory round trips
+ * instead of K / 32; bit-identical results (default on; 0 for A/B runs). */
+int ga_set_small_m_gemm(int on);
 /* Forward-mode tangent of the MLP (torch/optimizers/conjugate_gradient_optimizer.py
  * :18-66 takes the same product by double backward): with dtheta = tangent (flat
  * parameter layout) and acts = the hidden activations of a forward at the same

@@ -297,6 +297,44 @@ def test_streaming_layer_kernels_match_mfma_tiles(dev, shape):
                               rtol=1e-5), M
 
 
+@pytest.mark.parametrize('shape', [(17, 6, (256, 256)), (40, 3, (512, 96, 130)),
+                                   (70, 17, (512, 512))])
+def test_small_m_gemm_dispatch_is_bit_identical(dev, shape):
+    """GEMMs of few row tiles run on 64x64 tiles with 128-deep k-steps
+    (``ga_set_small_m_gemm``): every output element accumulates its k in the same
+    order as on the 128x128 tiles, so forward, activations and gradients have the
+    same bits, for ragged and gathered row counts."""
+    from garage_amd import _lib
+    from garage_amd.engine import FlatMLP, pad_rows
+    lib = _lib.load()
+    O, A, hs = shape
+    rng = np.random.RandomState(7)
+    mlp = FlatMLP(O, A, hs, dev)
+    mlp.params.copy_(torch.from_numpy(
+        (rng.randn(mlp.n_flat) * 0.1).astype(np.float32)))
+    n_rows = 3000
+    X = pad_rows(rng.randn(n_rows, O).astype(np.float32))
+    for M, gather in ((64, False), (1, False), (333, True), (2999, True)):
+        idx = None
+        if gather:
+            idx = torch.from_numpy(
+                rng.randint(0, n_rows, size=M).astype(np.int32)).to(dev)
+        G = rng.randn(M, A).astype(np.float32)
+        res = {}
+        for on in (0, 1):
+            lib.ga_set_small_m_gemm(on)
+            out = mlp.forward(X, M, row_idx=idx)[:, :A].clone()
+            dout = mlp.dout_view(M)
+            dout.zero_()
+            dout[:, :A] = torch.from_numpy(G).to(dev)
+            mlp.backward(X, M, dout, row_idx=idx)
+            mlp.reduce_grads()
+            res[on] = (out, mlp._acts.clone(), mlp.grads.clone())
+        lib.ga_set_small_m_gemm(1)
+        for a0, a1 in zip(res[0], res[1]):
+            assert torch.equal(a0, a1), M
+
+
 @pytest.mark.parametrize('shape', [(17, 6, (256, 256)), (4, 2, (64, 64)),
                                    (9, 1, (64, 128)), (17, 8, (128, 256)),
                                    (40, 3, (256,)), (6, 1, (32, 64))])
