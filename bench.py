@@ -54,12 +54,12 @@ PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
 
 # garage_amd/csrc/prof.h kinds (kernel names as rocprofv3 prints them)
 KIND_NAMES = [
-    'gemm_f32_kernel<128,128,2,4,true,true,32> (forward)',
-    'gemm_f32_kernel<128,128,2,4,true,false,32> (data grad)',
-    'gemm_f32_kernel<128,128,2,4,false,false,32> (weight grad)',
-    'gemm_f32_kernel<128,32,4,1,true,true,32> (forward, narrow)',
-    'gemm_f32_kernel<128,32,4,1,true,false,32> (data grad, narrow)',
-    'gemm_f32_kernel<128,32,4,1,false,false,32> (weight grad, narrow)',
+    'gemm_f32_kernel<128,128,2,4,true,true,32,false> (forward)',
+    'gemm_f32_kernel<128,128,2,4,true,false,32,false> (data grad)',
+    'gemm_f32_kernel<128,128,2,4,false,false,32,false> (weight grad)',
+    'gemm_f32_kernel<128,32,4,1,true,true,32,false> (forward, narrow)',
+    'gemm_f32_kernel<128,32,4,1,true,false,32,false> (data grad, narrow)',
+    'gemm_f32_kernel<128,32,4,1,false,false,32,false> (weight grad, narrow)',
     'gae_scan_rows_kernel / gae_scan_kernel',
     'skinny_fwd_kernel (first-layer forward / head data grad; work = bytes)',
     'skinny_wgrad_kernel (first-layer / head weight grad; work = bytes)',

@@ -370,6 +370,9 @@ __device__ __forceinline__ void gemm_mainloop(const GemmParams& p, float* lds,
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KC, bool B_KC,
           int BKT = BK, bool HEAD = false>
+#ifdef GA_GEMM_WAVES_PER_EU  // A/B builds (tools/build_variants.sh)
+__attribute__((amdgpu_waves_per_eu(GA_GEMM_WAVES_PER_EU, 8)))
+#endif
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_f32_kernel(
     GemmParams p) {
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;

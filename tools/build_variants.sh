@@ -13,6 +13,6 @@ build() {  # name, flags...
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs $OUT/gemm_$name.o -ldl -o $OUT/lib_$name.so
   echo built $name
 }
-build w8 -DGA_WN=4 &
-build w4 -DGA_WN=2 &
+build occ6 -DGA_GEMM_WAVES_PER_EU=6 &
+build occ5 -DGA_GEMM_WAVES_PER_EU=5 &
 wait
