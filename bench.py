@@ -250,6 +250,9 @@ def main():
     ap.add_argument('--no-head-dgrad-fusion', action='store_true',
                     help='A/B switch: separate launch for the data gradient '
                     'below the head layer')
+    ap.add_argument('--one-launch-losses', action='store_true',
+                    help='A/B switch: multi-block losses finish through a '
+                    'last-ticket block instead of a finalize launch')
     ap.add_argument('--head-forward-fusion', type=int, default=None,
                     choices=[0, 1, 2],
                     help='A/B switch (ga_set_fused_head_forward): 0 separate '
@@ -273,6 +276,9 @@ def main():
     if args.no_head_dgrad_fusion:
         from garage_amd import _lib
         _lib.load().ga_set_fused_head_dgrad(0)
+    if args.one_launch_losses:
+        from garage_amd import _lib
+        _lib.load().ga_set_one_launch_losses(1)
     if args.head_forward_fusion is not None:
         from garage_amd import _lib
         _lib.load().ga_set_fused_head_forward(args.head_forward_fusion)

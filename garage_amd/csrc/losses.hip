@@ -29,6 +29,37 @@ __device__ __forceinline__ float softplusf(float x) {
 }
 __device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
 
+// Multi-block reductions finish in the same launch: every block publishes its
+// partial sums, then takes a ticket; the block that draws the last one sees all of
+// them (release fence before the ticket, acquire fence after it, device-scope
+// loads) and adds them in block order -- the same order, hence the same bits, as a
+// separate one-wave finalize launch -- and leaves the ticket at 0 for the next
+// launch on this workspace.  The ticket lives behind the partials
+// (ga_reduction_workspace_doubles() counts it; the workspace starts zeroed).
+__device__ __forceinline__ bool ga_take_last_ticket(unsigned* ticket) {
+  __shared__ int is_last;
+  if (threadIdx.x == 0) {
+    __threadfence();  // this block's partials before its ticket
+    const unsigned t = atomicAdd(ticket, 1u);
+    is_last = (t == gridDim.x - 1);
+    if (is_last) *ticket = 0;
+  }
+  __syncthreads();
+  const bool last = is_last != 0;
+  if (last) __threadfence();  // every block's partials after its ticket
+  return last;
+}
+__device__ __forceinline__ double ga_peek(const double* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Sum of partials[2 b + which] over the blocks, one wave, fixed order.
+__device__ __forceinline__ double ga_sum_partials(const double* partials, int nblocks,
+                                                  int which) {
+  double v = 0.0;
+  for (int b = threadIdx.x; b < nblocks; b += 64) v += ga_peek(partials + 2 * b + which);
+  return ga_wave_sum(v);
+}
+
 struct PpoLossParams {
   const float* mean;      // [M, ldm] policy means of the minibatch rows
   int64_t ldm;
@@ -52,11 +83,11 @@ struct PpoLossParams {
   float* dmean;           // optional [M, ldm]: dLoss/dmean (already / M)
   float* ll_out;          // optional [M]: new log-likelihoods
   double* partials;       // [gridDim.x][2]: sum objective, sum dLoss/dlog_std * M
-  // single-block launches (minibatches of <= 256 rows) finish in the same kernel
-  // (no second launch): the scalars the finalize kernel would write
+  // the scalars of the batch (written by the last block to finish)
   float* loss_out;        // null: a finalize launch follows
   float* grad_slab0;
   int64_t slab_stride, n_splits;
+  unsigned* ticket;
 };
 
 // Loss value and the log-std gradient slot from the batch sums (thread 0 of the
@@ -149,17 +180,22 @@ __global__ __launch_bounds__(256) void ppo_gaussian_loss_kernel(PpoLossParams p)
   }
   const double o = ga_block_sum_256(obj_sum, red);
   const double d = ga_block_sum_256(ds_sum, red);
-  if (threadIdx.x == 0) {
-    if (p.loss_out) {  // the only block: o and d are the batch sums
-      ppo_gaussian_finish(o, d, p.log_std, p.has_min, p.min_log_std, p.has_max,
-                          p.max_log_std, p.M, p.A, p.ent_coeff, p.ent_regularized,
-                          p.ent_softplus, p.ent_stop_grad, p.loss_out, p.grad_slab0,
-                          p.slab_stride, p.n_splits);
-    } else {
+  double bo = o, bd = d;  // batch sums (the only block: its own)
+  if (gridDim.x > 1 || !p.loss_out) {
+    if (threadIdx.x == 0) {
       p.partials[2 * blockIdx.x + 0] = o;
       p.partials[2 * blockIdx.x + 1] = d;
     }
+    if (!p.loss_out || !ga_take_last_ticket(p.ticket)) return;
+    if (threadIdx.x >= 64) return;
+    bo = ga_sum_partials(p.partials, gridDim.x, 0);
+    bd = ga_sum_partials(p.partials, gridDim.x, 1);
   }
+  if (threadIdx.x == 0 && p.loss_out)
+    ppo_gaussian_finish(bo, bd, p.log_std, p.has_min, p.min_log_std, p.has_max,
+                        p.max_log_std, p.M, p.A, p.ent_coeff, p.ent_regularized,
+                        p.ent_softplus, p.ent_stop_grad, p.loss_out, p.grad_slab0,
+                        p.slab_stride, p.n_splits);
   (void)s_grad;
   (void)s_raw;
 }
@@ -220,6 +256,12 @@ struct CatLossParams {
   float* ll_out;         // optional [M]
   float* ent_out;        // optional [M]: per-row entropy (after softplus if set)
   double* partials;      // [gridDim.x][2]: sum objective, sum entropy
+  // the scalars of the batch (written by the last block to finish)
+  float* loss_out;       // null: a finalize launch follows
+  double* ent_sum_out;
+  float* grad_slab0;
+  int64_t slab_stride, n_splits;
+  unsigned* ticket;
 };
 
 // Final log-probabilities lp[j] of the row, its entropy, and (for the
@@ -326,9 +368,22 @@ __global__ __launch_bounds__(256) void ppo_categorical_loss_kernel(CatLossParams
   }
   const double o = ga_block_sum_256(obj_sum, red);
   const double e = ga_block_sum_256(ent_sum, red);
+  double bo = o, be = e;  // batch sums (the only block: its own)
+  if (gridDim.x > 1 || !p.loss_out) {
+    if (threadIdx.x == 0) {
+      p.partials[2 * blockIdx.x + 0] = o;
+      p.partials[2 * blockIdx.x + 1] = e;
+    }
+    if (!p.loss_out || !ga_take_last_ticket(p.ticket)) return;
+    if (threadIdx.x >= 64) return;
+    bo = ga_sum_partials(p.partials, gridDim.x, 0);
+    be = ga_sum_partials(p.partials, gridDim.x, 1);
+  }
   if (threadIdx.x == 0) {
-    p.partials[2 * blockIdx.x + 0] = o;
-    p.partials[2 * blockIdx.x + 1] = e;
+    *p.loss_out = (float)(-(bo / (double)p.M));
+    if (p.ent_sum_out) *p.ent_sum_out = be;
+    if (p.grad_slab0)  // the (unused) log-std slot of the flat layout stays 0
+      for (int64_t k = 0; k < p.n_splits; ++k) p.grad_slab0[k * p.slab_stride] = 0.f;
   }
 }
 
@@ -384,9 +439,10 @@ struct NllParams {
   int64_t M;
   float* dv;             // optional [M, ldv] column 0
   double* partials;      // [gridDim.x][2]
-  float* loss_out;       // single-block launches finish here; null: finalize follows
+  float* loss_out;       // written by the last block; null: a finalize launch follows
   float* grad_slab0;
   int64_t slab_stride, n_splits;
+  unsigned* ticket;
 };
 
 __global__ __launch_bounds__(256) void gaussian_nll_kernel(NllParams p) {
@@ -406,17 +462,22 @@ __global__ __launch_bounds__(256) void gaussian_nll_kernel(NllParams p) {
   }
   const double a = ga_block_sum_256(nll, red);
   const double b = ga_block_sum_256(ds, red);
-  if (threadIdx.x == 0) {
-    if (p.loss_out) {  // the only block: a and b are the batch sums
-      *p.loss_out = (float)(a / (double)p.M);
-      if (p.grad_slab0) {
-        p.grad_slab0[0] = (float)(b / (double)p.M);
-        for (int64_t k = 1; k < p.n_splits; ++k)
-          p.grad_slab0[k * p.slab_stride] = 0.f;
-      }
-    } else {
+  double ba = a, bb = b;  // batch sums (the only block: its own)
+  if (gridDim.x > 1 || !p.loss_out) {
+    if (threadIdx.x == 0) {
       p.partials[2 * blockIdx.x + 0] = a;
       p.partials[2 * blockIdx.x + 1] = b;
+    }
+    if (!p.loss_out || !ga_take_last_ticket(p.ticket)) return;
+    if (threadIdx.x >= 64) return;
+    ba = ga_sum_partials(p.partials, gridDim.x, 0);
+    bb = ga_sum_partials(p.partials, gridDim.x, 1);
+  }
+  if (threadIdx.x == 0 && p.loss_out) {
+    *p.loss_out = (float)(ba / (double)p.M);
+    if (p.grad_slab0) {
+      p.grad_slab0[0] = (float)(bb / (double)p.M);
+      for (int64_t k = 1; k < p.n_splits; ++k) p.grad_slab0[k * p.slab_stride] = 0.f;
     }
   }
 }
@@ -692,7 +753,19 @@ inline int red_blocks(int64_t n) {
 
 }  // namespace
 
-extern "C" int64_t ga_reduction_workspace_doubles(void) { return 2 * RED_BLOCKS; }
+// [RED_BLOCKS][2] partial sums + the ticket of the single-launch reductions
+extern "C" int64_t ga_reduction_workspace_doubles(void) { return 2 * RED_BLOCKS + 1; }
+
+// A single block always finishes its own launch.  With several blocks the last
+// ticket saves the finalize launch but pays two device-scope fences (L2 write-back
+// / invalidate across the XCDs) in every block: measured +1 % per C3 iteration
+// (146.5 vs 145.1 ms overlapped, 167.4 vs 166.1 ms on one stream) and +2 % at C2,
+// so it is off by default.
+static int g_one_launch_losses = 0;
+extern "C" int ga_set_one_launch_losses(int on) {
+  g_one_launch_losses = on != 0;
+  return 0;
+}
 
 extern "C" int ga_ppo_gaussian_loss_f32(
     const float* mean, int64_t ldm, const float* actions, int64_t lda,
@@ -715,9 +788,10 @@ extern "C" int ga_ppo_gaussian_loss_f32(
   p.ent_stop_grad = (ent_flags >> 2) & 1;
   p.dmean = dmean; p.ll_out = ll_out; p.partials = workspace;
   const int nb = red_blocks(M);
-  const bool one_launch = nb == 1;
+  const bool one_launch = nb == 1 || g_one_launch_losses != 0;
   p.loss_out = one_launch ? loss_out : nullptr;
   p.grad_slab0 = grad_slab0; p.slab_stride = slab_stride; p.n_splits = n_splits;
+  p.ticket = reinterpret_cast<unsigned*>(workspace + 2 * RED_BLOCKS);
   hipLaunchKernelGGL(ppo_gaussian_loss_kernel, dim3(nb), dim3(256), 0, stream, p);
   GA_CHECK_LAUNCH("ppo_gaussian_loss");
   if (one_launch) return GA_OK;
@@ -754,8 +828,14 @@ extern "C" int ga_ppo_categorical_loss_f32(
   p.dscores = dscores; p.ll_out = ll_out; p.ent_out = ent_out;
   p.partials = workspace;
   const int nb = red_blocks(M);
+  const bool one_launch = nb == 1 || g_one_launch_losses != 0;
+  p.loss_out = one_launch ? loss_out : nullptr;
+  p.ent_sum_out = ent_sum_out; p.grad_slab0 = grad_slab0;
+  p.slab_stride = slab_stride; p.n_splits = n_splits;
+  p.ticket = reinterpret_cast<unsigned*>(workspace + 2 * RED_BLOCKS);
   hipLaunchKernelGGL(ppo_categorical_loss_kernel, dim3(nb), dim3(256), 0, stream, p);
   GA_CHECK_LAUNCH("ppo_categorical_loss");
+  if (one_launch) return GA_OK;
   hipLaunchKernelGGL(ppo_categorical_finalize_kernel, dim3(1), dim3(64), 0, stream,
                      (const double*)workspace, nb, M, loss_out, ent_sum_out,
                      grad_slab0, slab_stride, n_splits);
@@ -793,9 +873,10 @@ extern "C" int ga_gaussian_nll_loss_f32(const float* v, int64_t ldv,
   p.v = v; p.ldv = ldv; p.returns = returns; p.idx = idx; p.log_std = log_std;
   p.M = M; p.dv = dv; p.partials = workspace;
   const int nb = red_blocks(M);
-  const bool one_launch = nb == 1;
+  const bool one_launch = nb == 1 || g_one_launch_losses != 0;
   p.loss_out = one_launch ? loss_out : nullptr;
   p.grad_slab0 = grad_slab0; p.slab_stride = slab_stride; p.n_splits = n_splits;
+  p.ticket = reinterpret_cast<unsigned*>(workspace + 2 * RED_BLOCKS);
   hipLaunchKernelGGL(gaussian_nll_kernel, dim3(nb), dim3(256), 0, stream, p);
   GA_CHECK_LAUNCH("gaussian_nll");
   if (one_launch) return GA_OK;
@@ -1297,6 +1378,7 @@ extern "C" int ga_head_ppo_gaussian_loss_f32(
   p.ent_stop_grad = (ent_flags >> 2) & 1;
   p.dmean = dmean; p.ll_out = ll_out; p.partials = workspace;
   p.loss_out = nullptr; p.grad_slab0 = nullptr; p.slab_stride = 0; p.n_splits = 0;
+  p.ticket = nullptr;
   const int nb = head_blocks(M);
   const unsigned lds =
       (unsigned)((A * hidden_width + ((A + 3) & ~3) + 16 * 4 * A) * sizeof(float));
@@ -1339,6 +1421,7 @@ extern "C" int ga_head_gaussian_nll_loss_f32(
   p.v = nullptr; p.ldv = ldd; p.returns = returns; p.idx = idx; p.log_std = log_std;
   p.M = M; p.dv = dv; p.partials = workspace;
   p.loss_out = nullptr; p.grad_slab0 = nullptr; p.slab_stride = 0; p.n_splits = 0;
+  p.ticket = nullptr;
   const int nb = head_blocks(M);
   const unsigned lds = (unsigned)((hidden_width + 4 + 16 * 4) * sizeof(float));
   switch (hidden_width / 64) {

@@ -32,7 +32,9 @@ def reduction_workspace(device, tag=0):
     key = (device.type, device.index, tag)
     if key not in _WS:
         n = int(_lib.load().ga_reduction_workspace_doubles())
-        _WS[key] = torch.empty(n, dtype=torch.float64, device=device)
+        # zeroed once: the last slot is the ticket of the single-launch
+        # reductions, which every launch leaves at 0
+        _WS[key] = torch.zeros(n, dtype=torch.float64, device=device)
     return _WS[key]
 
 

@@ -131,8 +131,16 @@ int ga_gemm_nt_f32(const float* A, int64_t lda, const float* B, int64_t ldb,
                    ga_stream_t stream);
 
 /* ---- losses -----------------------------------------------------------------
- * workspace: ga_reduction_workspace_doubles() doubles of device scratch. */
+ * workspace: ga_reduction_workspace_doubles() doubles of device scratch, ZEROED
+ * once by the caller (its last slot is a ticket every launch leaves at 0), used by
+ * one stream at a time. */
 int64_t ga_reduction_workspace_doubles(void);
+/* Loss launches of one block (<= 256 rows) write the loss and the log-std gradient
+ * slot themselves.  1 = launches of several blocks do too: the block that draws
+ * the last ticket adds the blocks' partial sums in block order (the bits of the
+ * one-wave finalize launch it replaces); default 0 -- the device-scope fences cost
+ * more than the launch they save (losses.hip). */
+int ga_set_one_launch_losses(int on);
 
 /* PPO clipped surrogate (algo 0; torch/algos/ppo.py:96-132) or VPG objective
  * (algo 1; vpg.py:434-454) for a Gaussian policy with a scalar log-std

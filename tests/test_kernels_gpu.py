@@ -648,3 +648,62 @@ def test_gaussian_kl(dev):
     call('ga_gaussian_kl_f32', dptr(a), dptr(b), a.stride(0), M, A, s0, s1,
          dptr(out), dptr(reduction_workspace(dev)), stream_ptr())
     assert np.isclose(out.item(), want, rtol=1e-5)
+
+
+@pytest.mark.parametrize('M', [200, 257, 70001, 1048576])
+def test_losses_finish_in_one_launch_with_the_same_bits(dev, M):
+    """The loss entry points with the last-ticket finish (one launch) against the
+    separate finalize launch: loss and log-std gradient slot bit for bit, for one
+    block, a few blocks and the full block count, launch after launch (the
+    ticket returns to 0), for the Gaussian PPO, categorical PPO and NLL losses."""
+    from garage_amd import _lib
+    from garage_amd._lib import call, dptr, stream_ptr
+    from garage_amd.engine import reduction_workspace
+    lib = _lib.load()
+    g = torch.Generator(device='cpu').manual_seed(M)
+    A, ld = 3, 4
+    mean = torch.randn(M, ld, generator=g).to(dev)
+    act = torch.randn(M, ld, generator=g).to(dev)
+    act_cls = torch.zeros(M, ld)
+    act_cls[:, 0] = torch.randint(0, A, (M, ), generator=g).float()
+    act_cls = act_cls.to(dev)
+    old_ll = (-2.0 + 0.3 * torch.randn(M, generator=g)).to(dev)
+    adv = torch.randn(M, generator=g).to(dev)
+    ret = torch.randn(M, generator=g).to(dev)
+    log_std = torch.full((4, ), -0.2, device=dev)
+    ws = reduction_workspace(dev)
+    n_splits, stride = 3, 16
+    res = {}
+    for on in (0, 1, 1, 0, 1):
+        lib.ga_set_one_launch_losses(on)
+        out = []
+        for kind in ('gauss', 'cat', 'nll'):
+            loss = torch.full((1, ), float('nan'), device=dev)
+            slabs = torch.full((n_splits * stride, ), float('nan'), device=dev)
+            d = torch.zeros(M, ld, device=dev)
+            if kind == 'gauss':
+                call('ga_ppo_gaussian_loss_f32', dptr(mean), ld, dptr(act), ld,
+                     dptr(old_ll), dptr(adv), None, dptr(log_std), 1, -3.0, 0,
+                     0.0, M, A, 0, 0.2, 0.01, 1, dptr(d), None, dptr(loss),
+                     dptr(slabs), stride, n_splits, dptr(ws), stream_ptr())
+            elif kind == 'cat':
+                call('ga_ppo_categorical_loss_f32', dptr(mean), ld,
+                     dptr(act_cls), ld, dptr(old_ll), dptr(adv), None, M, A, 1,
+                     0, 0.2, 0.01, 1, dptr(d), None, None, dptr(loss), None,
+                     dptr(slabs), stride, n_splits, dptr(ws), stream_ptr())
+            else:
+                call('ga_gaussian_nll_loss_f32', dptr(mean), ld, dptr(ret),
+                     None, dptr(log_std), M, dptr(d), dptr(loss), dptr(slabs),
+                     stride, n_splits, dptr(ws), stream_ptr())
+            out.append((loss.clone(), slabs[::stride].clone(), d.clone()))
+        torch.cuda.synchronize()
+        assert ws[-1].item() == 0.0  # the ticket (last slot) is back at 0
+        res.setdefault(on, []).append(out)
+    lib.ga_set_one_launch_losses(0)
+    base = res[0][0]
+    for runs in res.values():
+        for out in runs:
+            for (l0, s0, d0), (l1, s1, d1) in zip(base, out):
+                assert torch.isfinite(l1).all() and torch.isfinite(s1).all()
+                assert torch.equal(l0, l1) and torch.equal(s0, s1)
+                assert torch.equal(d0, d1)
