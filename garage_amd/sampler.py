@@ -302,6 +302,9 @@ class GpuVecWorker:
         """
         self._start()
         n = self._n_envs
+        # the reference loop runs at least one rollout(), i.e. until an episode
+        # completes, whatever the target (local_sampler.py:157-166)
+        num_samples = max(int(num_samples), 1)
         b = self._alloc_buffers(num_samples)
         col = 0
         # the target cannot be reached before step ceil(num_samples / n): those
