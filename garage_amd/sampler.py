@@ -9,6 +9,7 @@ finished envs, the discard of in-flight episodes at each ``obtain_samples``)
 follows the reference exactly and is verified bit for bit against it.
 """
 import copy
+import warnings
 import ctypes as C
 
 import numpy as np
@@ -53,6 +54,96 @@ class WorkerFactory:
                                   seed=self._seed,
                                   max_episode_length=self._max_episode_length,
                                   **self._worker_args)
+
+
+class EnvUpdate:
+    """``sampler/env_update.py:5-33``: a callable ``old_env -> env``; the caller
+    uses what it returns and forgets ``old_env``.  The base class keeps it."""
+
+    def __call__(self, old_env=None):
+        return old_env
+
+
+class NewEnvUpdate(EnvUpdate):
+    """``env_update.py:36-63``: closes the old environment and constructs a new
+    one with ``env_constructor()`` at every update."""
+
+    def __init__(self, env_constructor):
+        self._env_constructor = env_constructor
+
+    def __call__(self, old_env=None):
+        if old_env:
+            old_env.close()
+        return self._env_constructor()
+
+
+class SetTaskUpdate(EnvUpdate):
+    """``env_update.py:66-121``: ``set_task(task)`` on an environment of type
+    ``env_type``, constructing (and wrapping) one when the old environment is
+    missing or of another type."""
+
+    def __init__(self, env_type, task, wrapper_constructor):
+        if not isinstance(env_type, type):
+            raise ValueError('env_type should be a type, not '
+                             f'{type(env_type)!r}')
+        self._env_type = env_type
+        self._task = task
+        self._wrapper_cons = wrapper_constructor
+
+    def _make_env(self):
+        env = self._env_type()
+        env.set_task(self._task)
+        if self._wrapper_cons is not None:
+            env = self._wrapper_cons(env, self._task)
+        return env
+
+    def __call__(self, old_env=None):
+        if old_env is None:
+            return self._make_env()
+        if not isinstance(getattr(old_env, 'unwrapped', old_env),
+                          self._env_type):
+            warnings.warn('SetTaskEnvUpdate is closing an environment. This '
+                          'may indicate a very slow TaskSampler setup.')
+            old_env.close()
+            return self._make_env()
+        old_env.set_task(self._task)
+        return old_env
+
+
+class ExistingEnvUpdate(EnvUpdate):
+    """``env_update.py:124-159``: hands over an environment that already
+    exists; the old one is not closed."""
+
+    def __init__(self, env):
+        self._env = env
+
+    def __call__(self, old_env=None):
+        return self._env
+
+    def __getstate__(self):
+        warnings.warn('ExistingEnvUpdate is generally not the most efficient '
+                      'method of transmitting environments to other '
+                      'processes.')
+        return self.__dict__
+
+
+def _is_environment(obj):
+    return hasattr(obj, 'step') and hasattr(obj, 'reset')
+
+
+def _apply_env_update(old_env, env_update):
+    """``sampler/_functions.py:6-40``: ``(env, updated)``; ``None`` keeps the
+    environment, an :class:`EnvUpdate` is called on it, an environment replaces
+    it (the old one is closed), anything else is a ``TypeError``."""
+    if env_update is None:
+        return old_env, False
+    if isinstance(env_update, EnvUpdate):
+        return env_update(old_env), True
+    if _is_environment(env_update):
+        if old_env is not None:
+            old_env.close()
+        return env_update, True
+    raise TypeError('Unknown environment update type.')
 
 
 def _copy_env(env):
@@ -107,34 +198,53 @@ class GpuVecWorker:
         self._needs_agent_reset = True
 
     def update_env(self, env_update):
+        """``vec_worker.py:75-105``.  A :class:`~garage_amd.envs.VecEnv` replaces
+        the batch as a whole (so does a plain callable ``VecEnv -> VecEnv``, for
+        device-resident batches); a list holds one update per environment --
+        ``None``, an environment or an :class:`EnvUpdate` each; a single
+        environment or :class:`EnvUpdate` is deep-copied ``n_envs`` times."""
         if env_update is None:
             return
-        if isinstance(env_update, VecEnv):
-            if env_update.n_envs != self._n_envs:
+        n = self._n_envs
+        if isinstance(env_update, VecEnv) or (
+                callable(env_update) and not isinstance(env_update, EnvUpdate)
+                and not _is_environment(env_update)):
+            new_env = (env_update if isinstance(env_update, VecEnv) else
+                       env_update(self.env))
+            if new_env.n_envs != n:
                 raise ValueError('If separate environments are passed for '
                                  'each worker, there must be exactly n_envs '
                                  '({}) environments, but received {} '
-                                 'environments.'.format(
-                                     self._n_envs, env_update.n_envs))
-            new_env = env_update
-        elif isinstance(env_update, list):
-            if len(env_update) != self._n_envs:
+                                 'environments.'.format(n, new_env.n_envs))
+            if self.env is not None and self.env is not new_env:
+                self.env.close()
+            self.env = new_env
+            self._needs_env_reset = True
+            return
+        if isinstance(env_update, list):
+            if len(env_update) != n:
                 raise ValueError('If separate environments are passed for '
                                  'each worker, there must be exactly n_envs '
                                  '({}) environments, but received {} '
-                                 'environments.'.format(
-                                     self._n_envs, len(env_update)))
-            new_env = HostVecEnv(env_update)
-        elif hasattr(env_update, 'step') and hasattr(env_update, 'reset'):
-            new_env = HostVecEnv(
-                [copy.deepcopy(env_update) for _ in range(self._n_envs)])
-        elif callable(env_update):  # EnvUpdate (sampler/env_update.py:5-159)
-            new_env = env_update(self.env)
+                                 'environments.'.format(n, len(env_update)))
         else:
+            env_update = [copy.deepcopy(env_update) for _ in range(n)]
+        old = (list(self.env.envs) if isinstance(self.env, HostVecEnv)
+               else [None] * n)
+        members, updated = [], False
+        for old_env, env_up in zip(old, env_update):
+            env, up = _apply_env_update(old_env, env_up)
+            members.append(env)
+            updated = updated or up
+        if not updated:
+            return
+        if any(m is None for m in members):
             raise TypeError('Unknown environment update type.')
-        if self.env is not None and self.env is not new_env:
-            self.env.close()
-        self.env = new_env
+        if self.env is not None and not isinstance(self.env, HostVecEnv):
+            self.env.close()  # a device batch gives way to per-env objects
+        # (the members of a previous HostVecEnv were kept, replaced or closed
+        # one by one above: the batch object itself owns only staging buffers)
+        self.env = HostVecEnv(members)
         self._needs_env_reset = True
 
     # -- rollout buffers ------------------------------------------------------

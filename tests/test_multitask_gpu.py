@@ -9,8 +9,8 @@ import numpy as np
 import pytest
 import torch
 
-from test_oracle_golden import (MULTITASK_CASES, check_multitask,
-                                multitask_envs)
+from test_oracle_golden import (MT_LITERAL, MULTITASK_CASES, check_multitask,
+                                check_multitask_literals, multitask_envs)
 
 pytestmark = pytest.mark.gpu
 
@@ -112,3 +112,29 @@ def test_fragment_worker_carries_env_infos(golden):
     assert np.array_equal(eps.env_infos['task_id'], env_ids % 2)
     names = np.asarray(['reach', 'push', 'reach', 'pick'])
     assert np.array_equal(eps.env_infos['task_name'], names[env_ids])
+
+
+@pytest.mark.parametrize('by', ['task_name', 'task_id'])
+def test_log_multitask_performance_reference_literals(by):
+    """The reference's own two tests of ``log_multitask_performance``
+    (tests/garage/test_functions.py:101-200) against the device version, fed a
+    host ``EpisodeBatch`` like theirs."""
+    from garage_amd import logger
+    from garage_amd._dtypes import Box, EnvSpec, EpisodeBatch, StepType
+    from garage_amd.functions import log_multitask_performance
+    lit = MT_LITERAL
+    S = int(lit['lengths'].sum())
+    spec = EnvSpec(Box(np.zeros(3), np.ones(3)), Box(-np.ones(2), np.zeros(2)))
+    batch = EpisodeBatch(
+        env_spec=spec, episode_infos={},
+        observations=np.ones((S, 3), np.float32),
+        last_observations=np.ones((4, 3), np.float32),
+        actions=np.zeros((S, 2), np.float32), rewards=lit['rewards'],
+        step_types=np.array([StepType.MID] * S, dtype=StepType),
+        env_infos={'success': lit['success'], by: lit[by]}, agent_infos={},
+        lengths=lit['lengths'])
+    logger.tabular.clear()
+    log_multitask_performance(
+        7, batch, 0.8, lit['name_map'] if by == 'task_id' else None)
+    rec = {k: float(v) for k, v in logger.tabular.as_dict.items()}
+    check_multitask_literals(rec, by)

@@ -44,6 +44,55 @@ def test_log_performance_literals():
     assert math.isclose(stats['StdReturn'], 2.354067152038576)
 
 
+MT_LITERAL = dict(
+    lengths=np.array([10, 5, 1, 1]),
+    rewards=np.array([
+        0.34026529, 0.58263177, 0.84307509, 0.97651095, 0.81723901,
+        0.22631398, 0.03421301, 0.97515046, 0.64311832, 0.65068933,
+        0.17657714, 0.04783857, 0.73904013, 0.41364329, 0.52235551,
+        0.24203526, 0.43328910
+    ]),
+    success=np.array([0, 0, 0, 0, 0, 0, 1, 1, 0, 0, 0, 0, 0, 0, 1, 0, 1],
+                     dtype=bool),
+    task_name=np.array(['env1'] * 10 + ['env2'] * 5 + ['env1'] + ['env3']),
+    task_id=np.array([1] * 10 + [3] * 5 + [1] + [4]),
+    name_map={1: 'env1', 3: 'env2', 4: 'env3', 5: 'env4'},
+)
+
+
+def check_multitask_literals(rec, by):
+    """The assertions of tests/garage/test_functions.py:101-200."""
+    names = ['env1', 'env2', 'env3'] + (['env4'] if by == 'task_id' else [])
+    for name in names:
+        assert rec[name + '/Iteration'] == 7
+    assert rec['env1/NumEpisodes'] == 2
+    assert rec['env2/NumEpisodes'] == 1
+    assert rec['env3/NumEpisodes'] == 1
+    assert math.isclose(rec['env1/SuccessRate'], 0.5)
+    assert math.isclose(rec['env2/SuccessRate'], 1.0)
+    assert math.isclose(rec['env3/SuccessRate'], 1.0)
+    if by == 'task_id':
+        assert rec['env4/NumEpisodes'] == 0
+        assert math.isnan(rec['env4/SuccessRate'])
+        assert math.isnan(rec['env4/AverageReturn'])
+
+
+@pytest.mark.parametrize('by', ['task_name', 'task_id'])
+def test_log_multitask_performance_literals(by):
+    """tests/garage/test_functions.py:101-200 (both reference tests)."""
+    lit = MT_LITERAL
+    S = int(lit['lengths'].sum())
+    b = ob.OracleEpisodeBatch(
+        observations=np.ones((S, 3), np.float32),
+        last_observations=np.ones((4, 3), np.float32),
+        actions=np.zeros((S, 2), np.float32), rewards=lit['rewards'],
+        step_types=np.ones(S, dtype=np.int64), lengths=lit['lengths'],
+        env_infos={'success': lit['success'], by: lit[by]})
+    rec, _ = ob.multitask_performance_stats(
+        7, b, 0.8, name_map=lit['name_map'] if by == 'task_id' else None)
+    check_multitask_literals(rec, by)
+
+
 @pytest.mark.parametrize('discount', [1, 0.95])
 @pytest.mark.parametrize('num_eps', [1, 5])
 @pytest.mark.parametrize('gae_lambda', [0, 0.5, 1])
