@@ -377,6 +377,32 @@ class EpisodeBatch:
                                self.env_spec.max_episode_length)
 
 
+def step_types_as_uint8(step_types):
+    """``step_types`` (garage's object array of :class:`StepType`, or integers)
+    as a uint8 array.  The four enum members are singletons, so an object array
+    of them is an array of four distinct pointers: those are compared in bulk
+    (CPython: ``id`` is the address) instead of calling ``int()`` a million
+    times; anything else takes numpy's element-wise conversion."""
+    arr = np.asarray(step_types)
+    if arr.dtype != object:
+        return arr.astype(np.uint8)
+    flat = np.ascontiguousarray(arr).reshape(-1)
+    if flat.size == 0:
+        return np.zeros(0, dtype=np.uint8)
+    try:
+        import ctypes
+        ptrs = np.ctypeslib.as_array(
+            (ctypes.c_size_t * flat.size).from_address(flat.ctypes.data))
+        out = np.full(flat.size, 255, dtype=np.uint8)
+        for member in StepType:
+            out[ptrs == id(member)] = int(member)
+        if not (out == 255).any():
+            return out
+    except (TypeError, ValueError, AttributeError):  # pragma: no cover
+        pass
+    return flat.astype(np.uint8)
+
+
 class DeviceEpisodeBatch(EpisodeBatch):
     """An :class:`EpisodeBatch` whose arrays live in HBM.
 

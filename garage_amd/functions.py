@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from garage_amd import logger
-from garage_amd._dtypes import StepType
+from garage_amd._dtypes import StepType, step_types_as_uint8
 from garage_amd._dtypes import pad_batch_array  # noqa: F401  (host helper)
 from garage_amd._lib import call, dptr, stream_ptr
 from garage_amd.engine import gae_scan, require_gpu
@@ -81,9 +81,7 @@ def episode_statistics(batch, discount, returns=None):
     else:
         rew = torch.from_numpy(
             np.ascontiguousarray(batch.rewards, dtype=np.float32)).to(dev)
-        st = torch.from_numpy(
-            np.asarray([int(s) for s in batch.step_types],
-                       dtype=np.uint8)).to(dev)
+        st = torch.from_numpy(step_types_as_uint8(batch.step_types)).to(dev)
         off = torch.from_numpy(
             np.concatenate([[0], np.cumsum(lengths)])).to(dev)
     sums = torch.empty(N, dtype=torch.float64, device=dev)

@@ -206,3 +206,21 @@ def test_numpy_minibatch_stream_equals_batchdataset_semantics():
     assert len(got) == len(want)
     for a, b in zip(got, want):
         assert np.array_equal(a, b)
+
+
+def test_step_types_as_uint8_fast_and_fallback_paths():
+    """Object arrays of the enum singletons (what garage's EpisodeBatch holds),
+    integer arrays, mixed objects (plain ints among the members) and empties."""
+    from garage_amd._dtypes import StepType, step_types_as_uint8
+    rng = np.random.RandomState(0)
+    codes = rng.randint(0, 4, size=1000).astype(np.uint8)
+    members = [StepType(int(c)) for c in codes]
+    out = step_types_as_uint8(np.array(members, dtype=object))
+    assert out.dtype == np.uint8 and np.array_equal(out, codes)
+    assert np.array_equal(step_types_as_uint8(codes.astype(np.int64)), codes)
+    mixed = np.array(members, dtype=object)
+    mixed[::7] = [int(c) for c in codes[::7]]  # plain ints: not the singletons
+    assert np.array_equal(step_types_as_uint8(mixed), codes)
+    assert step_types_as_uint8(np.array([], dtype=object)).shape == (0, )
+    strided = np.array(members, dtype=object)[::3]  # non-contiguous view
+    assert np.array_equal(step_types_as_uint8(strided), codes[::3])
