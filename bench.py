@@ -250,6 +250,9 @@ def main():
     ap.add_argument('--no-head-dgrad-fusion', action='store_true',
                     help='A/B switch: separate launch for the data gradient '
                     'below the head layer')
+    ap.add_argument('--no-small-step', action='store_true',
+                    help='A/B switch: minibatches of <= 64 rows take the '
+                    'per-layer launches instead of the one-launch step')
     ap.add_argument('--one-launch-losses', action='store_true',
                     help='A/B switch: multi-block losses finish through a '
                     'last-ticket block instead of a finalize launch')
@@ -276,6 +279,9 @@ def main():
     if args.no_head_dgrad_fusion:
         from garage_amd import _lib
         _lib.load().ga_set_fused_head_dgrad(0)
+    if args.no_small_step:
+        from garage_amd import _lib
+        _lib.load().ga_set_small_step(0)
     if args.one_launch_losses:
         from garage_amd import _lib
         _lib.load().ga_set_one_launch_losses(1)

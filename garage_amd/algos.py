@@ -379,6 +379,12 @@ class VPG:
             scalars[4:] /= self._comm.world_size
             self._allreduce(scalars, 'sum')
         pl_b, pl_a, vl_b, vl_a, kl_b, kl_a = scalars.cpu().tolist()
+        # the one-launch small-minibatch step raises the last workspace slot if
+        # one of its grid barriers ever gave up (its results are then garbage)
+        for tag in (0, 1):
+            if float(reduction_workspace(dev, tag)[-1]) != 0.0:
+                raise RuntimeError('ga_small_step: a grid barrier timed out; '
+                                   'disable it with ga_set_small_step(0)')
         tab = logger.tabular
         with tab.prefix(self.policy.name):
             tab.record('/LossBefore', pl_b)

@@ -753,8 +753,11 @@ inline int red_blocks(int64_t n) {
 
 }  // namespace
 
-// [RED_BLOCKS][2] partial sums + the ticket of the single-launch reductions
-extern "C" int64_t ga_reduction_workspace_doubles(void) { return 2 * RED_BLOCKS + 1; }
+// [RED_BLOCKS][2] partial sums + one slot for the ticket of the single-launch
+// reductions / the grid-barrier words of small_step.hip (both leave it zero) + one
+// slot whose first word small_step.hip raises when a barrier gave up
+extern "C" int64_t ga_reduction_workspace_doubles(void) { return 2 * RED_BLOCKS + 2; }
+extern "C" int64_t ga_reduction_partials_doubles(void) { return 2 * RED_BLOCKS; }
 
 // A single block always finishes its own launch.  With several blocks the last
 // ticket saves the finalize launch but pays two device-scope fences (L2 write-back

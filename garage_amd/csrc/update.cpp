@@ -34,6 +34,32 @@ extern "C" int ga_set_fused_head_loss(int on) {
   return 0;
 }
 
+// small_step.hip: one launch per optimizer step for minibatches of <= 64 rows
+struct ga_small_step_args {
+  float* params; float* exp_avg; float* exp_avg_sq;
+  int64_t w_off[3], b_off[3];
+  int in_w, H, out_w, M;
+  const float* X; int64_t ldx; const int32_t* idx;
+  int kind;
+  const float* actions; int64_t lda; const float* old_ll; const float* adv;
+  const float* returns;
+  int algo; float clip;
+  int has_min, has_max; float min_log_std, max_log_std;
+  int64_t step; double lr, beta1, beta2, eps;
+  int learn_std;
+  float* xh2; float* xdz;
+  unsigned* bar; float* loss_out; int* fault;
+};
+extern "C" int ga_small_step_supported(int n_layers, const int* dims, int64_t M);
+extern "C" int ga_small_step(const ga_small_step_args* a, ga_stream_t stream);
+extern "C" int64_t ga_reduction_partials_doubles(void);
+
+static int g_small_step = 1;
+extern "C" int ga_set_small_step(int on) {
+  g_small_step = on != 0;
+  return 0;
+}
+
 namespace {
 
 int check_args(const ga_update_args* a) {
@@ -66,6 +92,35 @@ int run_minibatch(const ga_update_args* a, int64_t k, ga_stream_t stream) {
     return -1;
   }
   float* loss_slot = a->losses ? a->losses + k : a->loss_scratch;
+  // a minibatch of <= 64 rows through a 2 x H net: the whole step in one launch
+  // (the activation workspaces, unused on that path, carry its two exchanges:
+  // they hold min(S, mb) x 2H floats each, enough from 32 rows up)
+  if (g_small_step && !g_fuse_head && !a->comm && (a->kind == 0 || a->kind == 1) &&
+      a->ent_flags == 0 && (a->algo == 0 || a->algo == 1) && a->acts && a->dacts &&
+      (a->perm ? a->mb : a->S) >= 32 &&
+      ga_small_step_supported(L, a->desc->dims, M)) {
+    ga_small_step_args s;
+    memset(&s, 0, sizeof(s));
+    s.params = a->params; s.exp_avg = a->exp_avg; s.exp_avg_sq = a->exp_avg_sq;
+    for (int l = 0; l < 3; ++l) {
+      s.w_off[l] = a->desc->w_off[l];
+      s.b_off[l] = a->desc->b_off[l];
+    }
+    s.in_w = a->desc->dims[0]; s.H = a->desc->dims[1]; s.out_w = out_w; s.M = (int)M;
+    s.X = a->X; s.ldx = a->ldx; s.idx = idx; s.kind = a->kind;
+    s.actions = a->actions; s.lda = a->lda; s.old_ll = a->old_ll; s.adv = a->adv;
+    s.returns = a->returns; s.algo = a->algo; s.clip = a->clip;
+    s.has_min = a->has_min; s.has_max = a->has_max; s.min_log_std = a->min_log_std;
+    s.max_log_std = a->max_log_std;
+    s.step = a->step0 + k + 1; s.lr = a->lr; s.beta1 = a->beta1; s.beta2 = a->beta2;
+    s.eps = a->eps; s.learn_std = a->learn_std;
+    s.xh2 = a->acts; s.xdz = a->dacts;
+    double* tail = a->workspace + ga_reduction_partials_doubles();
+    s.bar = reinterpret_cast<unsigned*>(tail);
+    s.fault = reinterpret_cast<int*>(tail + 1);
+    s.loss_out = loss_slot;
+    return ga_small_step(&s, stream);
+  }
   // the head layer (hidden -> means / value) is computed inside the loss kernel
   // when its shape allows: no narrow GEMM launch, no round trip of its output
   const int hid_w = L >= 2 ? a->desc->dims[L - 1] : 0;

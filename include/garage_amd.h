@@ -108,6 +108,22 @@ int ga_set_fused_head_forward(int mode);
  * with 128-deep k-steps: more workgroups, K / 128 dependent memory round trips
  * instead of K / 32; bit-identical results (default on; 0 for A/B runs). */
 int ga_set_small_m_gemm(int on);
+/* ga_update_epoch*: a minibatch of <= 64 rows through a network of two equal
+ * tanh hidden layers (64 / 128 / 192 / 256 units, <= 32 inputs, <= 8 outputs;
+ * Gaussian PPO / VPG objective without entropy terms, or the value NLL; one
+ * process) takes its whole optimizer step -- gather, forward, loss, backward,
+ * Adam -- in ONE launch of H / 16 workgroups with two grid barriers
+ * (small_step.hip) instead of ten dependent launches.  Same formulas, other
+ * summation orders: results agree to rounding.  The last slot of the reduction
+ * workspace is raised when a barrier gave up (never seen; the step is then
+ * garbage).  Default on; 0 = per-layer path. */
+int ga_set_small_step(int on);
+int64_t ga_small_step_launches(void); /* launches so far (tests, diagnostics) */
+/* Developer hook (tools/small_step_phases.py): the first call arms the recording
+ * and returns 1; later calls synchronise and copy 16 timestamps (100 MHz wall
+ * clock of workgroup 0 at the phase boundaries of the most recent launch) to the
+ * HOST array and return 0. */
+int ga_small_step_debug(long long* host_out16);
 /* Forward-mode tangent of the MLP (torch/optimizers/conjugate_gradient_optimizer.py
  * :18-66 takes the same product by double backward): with dtheta = tangent (flat
  * parameter layout) and acts = the hidden activations of a forward at the same
@@ -132,8 +148,8 @@ int ga_gemm_nt_f32(const float* A, int64_t lda, const float* B, int64_t ldb,
 
 /* ---- losses -----------------------------------------------------------------
  * workspace: ga_reduction_workspace_doubles() doubles of device scratch, ZEROED
- * once by the caller (its last slot is a ticket every launch leaves at 0), used by
- * one stream at a time. */
+ * once by the caller (its last two slots are a ticket / barrier pair every launch
+ * leaves at 0 and a fault flag), used by one stream at a time. */
 int64_t ga_reduction_workspace_doubles(void);
 /* Loss launches of one block (<= 256 rows) write the loss and the log-std gradient
  * slot themselves.  1 = launches of several blocks do too: the block that draws
