@@ -21,7 +21,7 @@
 //
 // Weights a wave reads are wave-uniform (a wave = 64 rows x one column group), so
 // they come through the scalar cache; activations are read from LDS once.
-// Shapes: two tanh hidden layers of equal width H (multiple of 64, <= 256), input
+// Shapes: two tanh hidden layers of equal width H (multiple of 32, <= 256), input
 // width <= 32, <= 8 outputs, <= 64 rows; Gaussian PPO / VPG objective without
 // entropy terms, or the value function's Gaussian NLL.  Everything else takes the
 // per-layer path.  Same formulas as losses.hip / gemm.hip; sums are taken in a
@@ -674,7 +674,7 @@ struct ga_small_step_args {
 extern "C" int ga_small_step_supported(int n_layers, const int* dims, int64_t M) {
   if (n_layers != 3) return 0;
   const int in_w = dims[0], H = dims[1], out_w = dims[3];
-  return dims[2] == H && H % 64 == 0 && H >= 64 && H <= SS_HMAX && in_w >= 1 &&
+  return dims[2] == H && H % 32 == 0 && H >= 32 && H <= SS_HMAX && in_w >= 1 &&
          in_w <= 32 && out_w >= 1 && out_w <= 8 && M >= 1 && M <= SS_ROWS;
 }
 

@@ -19,6 +19,8 @@ CASES = {
     'ragged_rows': (9, 1, (128, 128), 48, {}),
     'vpg_objective': (5, 3, (64, 64), 33, {'vpg': True}),
     'uncentered': (17, 6, (192, 192), 64, {'center_adv': False}),
+    'cartpole_sized': (4, 1, (32, 32), 64, {}),
+    'odd_tiles': (12, 8, (96, 96), 50, {}),
 }
 
 
