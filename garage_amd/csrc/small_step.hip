@@ -22,8 +22,8 @@
 // Weights a wave reads are wave-uniform (a wave = 64 rows x one column group), so
 // they come through the scalar cache; activations are read from LDS once.
 // Shapes: two tanh hidden layers of equal width H (multiple of 32, <= 256), input
-// width <= 32, <= 8 outputs, <= 64 rows; Gaussian PPO / VPG objective without
-// entropy terms, or the value function's Gaussian NLL.  Everything else takes the
+// width <= 32, <= 8 outputs, <= 64 rows; Gaussian PPO / VPG objective (with its
+// entropy options), or the value function's Gaussian NLL.  Everything else takes the
 // per-layer path.  Same formulas as losses.hip / gemm.hip; sums are taken in a
 // different order, so results agree to rounding, not bit for bit.
 #include "common.h"
@@ -53,6 +53,7 @@ struct SmallStepParams {
   const float* returns;
   int algo; float clip;
   int has_min, has_max; float min_log_std, max_log_std;
+  float ent_coeff; int ent_regularized, ent_softplus, ent_stop_grad;
   // Adam (one step for every parameter)
   float lerp_w, beta2, one_minus_beta2, neg_step_size, bc2_sqrt, eps;
   int learn_std;
@@ -487,9 +488,22 @@ __global__ __launch_bounds__(SS_THREADS) void small_step_kernel(SmallStepParams 
     obj = ga_wave_sum(obj);
     ds = ga_wave_sum(ds);
     if (tid == 0) {
-      const double mean = obj / (double)M;
+      double mean = obj / (double)M;
+      double dls = ds / (double)M;
+      if (p.kind == 0 && p.ent_regularized) {
+        // entropy of the Independent Normal, A (0.5 + 0.5 log 2 pi + s): the same for
+        // every state (losses.hip: ppo_gaussian_finish)
+        float ent = (float)A * (0.5f + (float)SS_HALF_LOG_2PI + s);
+        float dent = (float)A;
+        if (p.ent_softplus) {
+          dent *= 1.f / (1.f + expf(-ent));
+          ent = ent > 20.f ? ent : log1pf(expf(ent));
+        }
+        mean += (double)(p.ent_coeff * ent);
+        if (!p.ent_stop_grad) dls += -(double)(p.ent_coeff * dent);
+      }
       if (blockIdx.x == 0) *p.loss_out = (float)(p.kind == 0 ? -mean : mean);
-      dlogstd_s = s_grad ? (float)(ds / (double)M) : 0.f;
+      dlogstd_s = s_grad ? (float)dls : 0.f;
     }
   }
   __syncthreads();
@@ -665,6 +679,7 @@ struct ga_small_step_args {
   const float* returns;
   int algo; float clip;
   int has_min, has_max; float min_log_std, max_log_std;
+  float ent_coeff; int ent_flags;
   int64_t step; double lr, beta1, beta2, eps;
   int learn_std;
   float* xh2; float* xdz;  // [64][H] floats each
@@ -714,6 +729,8 @@ extern "C" int ga_small_step(const ga_small_step_args* a, hipStream_t stream) {
   p.returns = a->returns; p.algo = a->algo; p.clip = a->clip;
   p.has_min = a->has_min; p.has_max = a->has_max; p.min_log_std = a->min_log_std;
   p.max_log_std = a->max_log_std;
+  p.ent_coeff = a->ent_coeff; p.ent_regularized = a->ent_flags & 1;
+  p.ent_softplus = (a->ent_flags >> 1) & 1; p.ent_stop_grad = (a->ent_flags >> 2) & 1;
   p.lerp_w = (float)(1.0 - a->beta1);
   p.beta2 = (float)a->beta2;
   p.one_minus_beta2 = (float)(1.0 - a->beta2);

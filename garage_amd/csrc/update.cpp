@@ -45,6 +45,7 @@ struct ga_small_step_args {
   const float* returns;
   int algo; float clip;
   int has_min, has_max; float min_log_std, max_log_std;
+  float ent_coeff; int ent_flags;
   int64_t step; double lr, beta1, beta2, eps;
   int learn_std;
   float* xh2; float* xdz;
@@ -96,7 +97,7 @@ int run_minibatch(const ga_update_args* a, int64_t k, ga_stream_t stream) {
   // (the activation workspaces, unused on that path, carry its two exchanges:
   // they hold min(S, mb) x 2H floats each, enough from 32 rows up)
   if (g_small_step && !g_fuse_head && !a->comm && (a->kind == 0 || a->kind == 1) &&
-      a->ent_flags == 0 && (a->algo == 0 || a->algo == 1) && a->acts && a->dacts &&
+      (a->algo == 0 || a->algo == 1) && a->acts && a->dacts &&
       (a->perm ? a->mb : a->S) >= 32 &&
       ga_small_step_supported(L, a->desc->dims, M)) {
     ga_small_step_args s;
@@ -112,6 +113,7 @@ int run_minibatch(const ga_update_args* a, int64_t k, ga_stream_t stream) {
     s.returns = a->returns; s.algo = a->algo; s.clip = a->clip;
     s.has_min = a->has_min; s.has_max = a->has_max; s.min_log_std = a->min_log_std;
     s.max_log_std = a->max_log_std;
+    s.ent_coeff = a->ent_coeff; s.ent_flags = a->ent_flags;
     s.step = a->step0 + k + 1; s.lr = a->lr; s.beta1 = a->beta1; s.beta2 = a->beta2;
     s.eps = a->eps; s.learn_std = a->learn_std;
     s.xh2 = a->acts; s.xdz = a->dacts;

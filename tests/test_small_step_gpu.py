@@ -20,6 +20,13 @@ CASES = {
     'vpg_objective': (5, 3, (64, 64), 33, {'vpg': True}),
     'uncentered': (17, 6, (192, 192), 64, {'center_adv': False}),
     'cartpole_sized': (4, 1, (32, 32), 64, {}),
+    'entropy_regularized': (6, 3, (64, 64), 64,
+                            {'entropy_method': 'regularized',
+                             'policy_ent_coeff': 0.02}),
+    'max_entropy_softplus': (6, 3, (64, 64), 40,
+                             {'entropy_method': 'max', 'policy_ent_coeff': 0.01,
+                              'center_adv': False, 'stop_entropy_gradient': True,
+                              'use_softplus_entropy': True}),
     'odd_tiles': (12, 8, (96, 96), 50, {}),
 }
 
