@@ -190,6 +190,7 @@ __global__ __launch_bounds__(SS_THREADS) void small_step_kernel(SmallStepParams 
   __shared__ __attribute__((aligned(16))) float part[4 * SS_ROWS * 8];
   __shared__ __attribute__((aligned(16))) float w0s[SS_HMAX * 32];        // W1 (all rows)
   __shared__ float bias_s[SS_HMAX + SS_COLS + 8];  // b1 (all), b2 (own), b_head
+  __shared__ float whs[8 * SS_COLS];               // W_head[:, own] (0 beyond A)
   __shared__ float dlogstd_s;
 
   SS_MARK(0);
@@ -246,6 +247,9 @@ __global__ __launch_bounds__(SS_THREADS) void small_step_kernel(SmallStepParams 
     const float bq0 = b0[min(tid, H - 1)];
     const float bq1 = tid < SS_COLS ? b1[c0 + tid] : (tid < SS_COLS + 8 && tid - SS_COLS < A
                                                           ? bh[tid - SS_COLS] : 0.f);
+    const float whq = (tid < 8 * SS_COLS && tid / SS_COLS < A)
+                          ? Wh[(int64_t)(tid / SS_COLS) * H + c0 + tid % SS_COLS]
+                          : 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       // (unconditional loads from clamped addresses: a conditionally written
@@ -277,6 +281,7 @@ __global__ __launch_bounds__(SS_THREADS) void small_step_kernel(SmallStepParams 
     }
     if (tid < H) bias_s[tid] = bq0;
     if (tid < SS_COLS + 8) bias_s[SS_HMAX + tid] = bq1;
+    if (tid < 8 * SS_COLS) whs[tid] = whq;
   }
   __syncthreads();
   // W2's own rows [16][H] go to LDS (over the first-layer weights) once A.1 is done
@@ -387,9 +392,11 @@ __global__ __launch_bounds__(SS_THREADS) void small_step_kernel(SmallStepParams 
     for (int j = 0; j < 8; ++j) {
       float sacc = 0.f;
       if (j < A) {
-        uptr w = (uptr)(uintptr_t)(Wh + (int64_t)j * H + c0 + 4 * cg);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) sacc = fmaf(hv[u], w[u], sacc);
+        const float4 w = *reinterpret_cast<const float4*>(whs + j * SS_COLS + 4 * cg);
+        sacc = fmaf(hv[0], w.x, sacc);
+        sacc = fmaf(hv[1], w.y, sacc);
+        sacc = fmaf(hv[2], w.z, sacc);
+        sacc = fmaf(hv[3], w.w, sacc);
       }
       part[(cg * SS_ROWS + r) * 8 + j] = sacc;
     }
@@ -514,11 +521,10 @@ __global__ __launch_bounds__(SS_THREADS) void small_step_kernel(SmallStepParams 
     float dzp[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int c = c0 + 4 * cg + j;
       float s = 0.f;
 #pragma unroll
-      for (int o = 0; o < 8; ++o)
-        if (o < A) s = fmaf(doutl[r * 8 + o], ((uptr)(uintptr_t)Wh)[(int64_t)o * H + c], s);
+      for (int o = 0; o < 8; ++o)  // rows >= A of whs are zero
+        s = fmaf(doutl[r * 8 + o], whs[o * SS_COLS + 4 * cg + j], s);
       const float h = h2own[r * SS_LDO + 4 * cg + j];
       dzp[j] = s * (1.f - h * h);
     }
@@ -597,6 +603,22 @@ __global__ __launch_bounds__(SS_THREADS) void small_step_kernel(SmallStepParams 
   }
   __syncthreads();
   SS_MARK(14);
+  // the optimizer state of this workgroup's layer-2 rows: loads issued now, used
+  // after the dZ1 product (C.2)
+  float ap[2][8], am[2][8], av[2][8];
+  {
+    const int lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int cj = (32 * (cg + 4 * t) < H) ? cg + 4 * t : cg;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int row = (i & 3) + 8 * (i >> 2) + 4 * kh;
+        const int64_t e = p.w_off[1] + (int64_t)(c0 + row) * H + 32 * cj + l31;
+        ap[t][i] = p.params[e]; am[t][i] = p.m[e]; av[t][i] = p.v[e];
+      }
+    }
+  }
   // B(n, j) = W2[n][c0 + j] = w1c[j][n]
   ss_mma_64xKx16(full, SS_LDH, w1c, SS_LDH, H, part);
   __syncthreads();
@@ -627,12 +649,13 @@ __global__ __launch_bounds__(SS_THREADS) void small_step_kernel(SmallStepParams 
     for (int t = 0; t < 2; ++t) {
       const int cj = cg + 4 * t;
       if (32 * cj < H) {
-        // rows (i & 3) + 8 (i >> 2) + 4 kh: i = 0..3 -> 4 kh + i, i = 4..7 -> 8 + 4 kh + i - 4
-        const float ga[4] = {g_w1[t][0], g_w1[t][1], g_w1[t][2], g_w1[t][3]};
-        const float gb[4] = {g_w1[t][4], g_w1[t][5], g_w1[t][6], g_w1[t][7]};
-        ss_adam_n<4>(p, ga, p.w_off[1] + (int64_t)(c0 + 4 * kh) * H + 32 * cj + l31, H);
-        ss_adam_n<4>(p, gb, p.w_off[1] + (int64_t)(c0 + 8 + 4 * kh) * H + 32 * cj + l31,
-                     H);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int row = (i & 3) + 8 * (i >> 2) + 4 * kh;
+          const int64_t e = p.w_off[1] + (int64_t)(c0 + row) * H + 32 * cj + l31;
+          ss_adam_math(p, g_w1[t][i], ap[t][i], am[t][i], av[t][i]);
+          p.params[e] = ap[t][i]; p.m[e] = am[t][i]; p.v[e] = av[t][i];
+        }
       }
     }
   }
