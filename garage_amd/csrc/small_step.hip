@@ -22,8 +22,8 @@
 // Weights a wave reads are wave-uniform (a wave = 64 rows x one column group), so
 // they come through the scalar cache; activations are read from LDS once.
 // Shapes: two tanh hidden layers of equal width H (multiple of 32, <= 256), input
-// width <= 32, <= 8 outputs, <= 64 rows; Gaussian PPO / VPG objective (with its
-// entropy options), or the value function's Gaussian NLL.  Everything else takes the
+// width <= 32, <= 8 outputs, <= 64 rows; Gaussian or categorical PPO / VPG objective
+// (with the entropy options), or the value function's Gaussian NLL.  Everything else takes the
 // per-layer path.  Same formulas as losses.hip / gemm.hip; sums are taken in a
 // different order, so results agree to rounding, not bit for bit.
 #include "common.h"
@@ -48,7 +48,8 @@ struct SmallStepParams {
   int in_w, H, out_w, M;
   // minibatch
   const float* X; int64_t ldx; const int32_t* idx;
-  int kind;  // 0 Gaussian policy, 1 value function
+  int kind;  // 0 Gaussian policy, 1 value function, 2 categorical policy
+  int double_softmax;
   const float* actions; int64_t lda; const float* old_ll; const float* adv;
   const float* returns;
   int algo; float clip;
@@ -480,6 +481,83 @@ __global__ __launch_bounds__(SS_THREADS) void small_step_kernel(SmallStepParams 
           if (j < A) dm[j] = scale * (a[j] - outl[r * 8 + j]);
         ds = (double)(-g * (q - (float)A));
       }
+    } else if (p.kind == 2) {
+      // categorical head (losses.hip: ppo_categorical_loss_kernel): the scores are
+      // logits, or -- double_softmax -- their softmax is
+      s_grad = false;  // no log-std parameter: its slot keeps a zero gradient
+      if (live) {
+        float sc[8], pr[8], lp[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sc[j] = outl[r * 8 + j];
+        float mx = sc[0];
+#pragma unroll
+        for (int j = 1; j < 8; ++j)
+          if (j < A) mx = fmaxf(mx, sc[j]);
+        float den = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (j < A) den += expf(sc[j] - mx);
+        float lse;
+        if (!p.double_softmax) {
+          lse = mx + logf(den);
+        } else {
+          float s2 = 0.f;
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (j < A) s2 += expf(expf(sc[j] - mx) / den);
+          lse = logf(s2);
+        }
+        const int a = (int)p.actions[src * p.lda];
+        float ll = 0.f, Hent = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          pr[j] = 0.f; lp[j] = 0.f;
+          if (j < A) {
+            pr[j] = expf(sc[j] - mx) / den;
+            lp[j] = (p.double_softmax ? pr[j] : sc[j]) - lse;
+            Hent -= expf(lp[j]) * lp[j];
+            if (j == a) ll = lp[j];
+          }
+        }
+        float Hs = Hent, dHs = 1.f;
+        if (p.ent_softplus) {
+          dHs = 1.f / (1.f + expf(-Hent));
+          Hs = Hent > 20.f ? Hent : log1pf(expf(Hent));
+        }
+        const float adv = p.adv[src];
+        float o, g;
+        if (p.algo == 1) {
+          o = ll * adv;
+          g = adv;
+        } else {
+          const float ratio = expf(ll - p.old_ll[src]);
+          const float lo = 1.f - p.clip, hi = 1.f + p.clip;
+          const float rc = fminf(fmaxf(ratio, lo), hi);
+          const float s1 = ratio * adv, s2 = rc * adv;
+          o = fminf(s1, s2);
+          const float g1 = adv * ratio;
+          const float g2 = (ratio >= lo && ratio <= hi) ? adv * ratio : 0.f;
+          g = (s1 < s2) ? g1 : ((s1 > s2) ? g2 : 0.5f * (g1 + g2));
+        }
+        if (p.ent_regularized) o += p.ent_coeff * Hs;
+        obj = (double)o;
+        const float cH = (p.ent_regularized && !p.ent_stop_grad) ? p.ent_coeff * dHs : 0.f;
+        float dp[8];
+        float dot = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          dp[j] = 0.f;
+          if (j < A) {
+            const float q = expf(lp[j]);
+            dp[j] = g * ((j == a ? 1.f : 0.f) - q) - cH * q * (lp[j] + Hent);
+            dot += dp[j] * pr[j];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (j < A)
+            dm[j] = p.double_softmax ? -(pr[j] * (dp[j] - dot)) * invM : -dp[j] * invM;
+      }
     } else {
       const float inv_var = expf(-2.f * s);
       if (live) {
@@ -509,7 +587,7 @@ __global__ __launch_bounds__(SS_THREADS) void small_step_kernel(SmallStepParams 
         mean += (double)(p.ent_coeff * ent);
         if (!p.ent_stop_grad) dls += -(double)(p.ent_coeff * dent);
       }
-      if (blockIdx.x == 0) *p.loss_out = (float)(p.kind == 0 ? -mean : mean);
+      if (blockIdx.x == 0) *p.loss_out = (float)(p.kind == 1 ? mean : -mean);
       dlogstd_s = s_grad ? (float)dls : 0.f;
     }
   }
@@ -697,7 +775,7 @@ struct ga_small_step_args {
   int64_t w_off[3], b_off[3];
   int in_w, H, out_w, M;
   const float* X; int64_t ldx; const int32_t* idx;
-  int kind;
+  int kind; int double_softmax;
   const float* actions; int64_t lda; const float* old_ll; const float* adv;
   const float* returns;
   int algo; float clip;
@@ -740,7 +818,7 @@ extern "C" int ga_small_step(const ga_small_step_args* a, hipStream_t stream) {
   GA_REQUIRE(ga_aligned16(a->params) && ga_aligned16(a->xh2) && ga_aligned16(a->xdz) &&
                  a->w_off[1] % 4 == 0 && a->w_off[2] % 4 == 0,
              "ga_small_step: alignment");
-  GA_REQUIRE(a->kind == 0 ? (a->actions && a->adv && (a->algo == 1 || a->old_ll))
+  GA_REQUIRE(a->kind != 1 ? (a->actions && a->adv && (a->algo == 1 || a->old_ll))
                           : (a->returns != nullptr),
              "ga_small_step: missing minibatch arrays");
   SmallStepParams p;
@@ -748,6 +826,7 @@ extern "C" int ga_small_step(const ga_small_step_args* a, hipStream_t stream) {
   for (int i = 0; i < 3; ++i) { p.w_off[i] = a->w_off[i]; p.b_off[i] = a->b_off[i]; }
   p.in_w = a->in_w; p.H = a->H; p.out_w = a->out_w; p.M = a->M;
   p.X = a->X; p.ldx = a->ldx; p.idx = a->idx; p.kind = a->kind;
+  p.double_softmax = a->double_softmax;
   p.actions = a->actions; p.lda = a->lda; p.old_ll = a->old_ll; p.adv = a->adv;
   p.returns = a->returns; p.algo = a->algo; p.clip = a->clip;
   p.has_min = a->has_min; p.has_max = a->has_max; p.min_log_std = a->min_log_std;

@@ -40,7 +40,7 @@ struct ga_small_step_args {
   int64_t w_off[3], b_off[3];
   int in_w, H, out_w, M;
   const float* X; int64_t ldx; const int32_t* idx;
-  int kind;
+  int kind; int double_softmax;
   const float* actions; int64_t lda; const float* old_ll; const float* adv;
   const float* returns;
   int algo; float clip;
@@ -96,7 +96,7 @@ int run_minibatch(const ga_update_args* a, int64_t k, ga_stream_t stream) {
   // a minibatch of <= 64 rows through a 2 x H net: the whole step in one launch
   // (the activation workspaces, unused on that path, carry its two exchanges:
   // they hold min(S, mb) x 2H floats each, enough from 32 rows up)
-  if (g_small_step && !g_fuse_head && !a->comm && (a->kind == 0 || a->kind == 1) &&
+  if (g_small_step && !g_fuse_head && !a->comm && a->kind >= 0 && a->kind <= 2 &&
       (a->algo == 0 || a->algo == 1) && a->acts && a->dacts &&
       (a->perm ? a->mb : a->S) >= 32 &&
       ga_small_step_supported(L, a->desc->dims, M)) {
@@ -109,6 +109,7 @@ int run_minibatch(const ga_update_args* a, int64_t k, ga_stream_t stream) {
     }
     s.in_w = a->desc->dims[0]; s.H = a->desc->dims[1]; s.out_w = out_w; s.M = (int)M;
     s.X = a->X; s.ldx = a->ldx; s.idx = idx; s.kind = a->kind;
+    s.double_softmax = a->double_softmax;
     s.actions = a->actions; s.lda = a->lda; s.old_ll = a->old_ll; s.adv = a->adv;
     s.returns = a->returns; s.algo = a->algo; s.clip = a->clip;
     s.has_min = a->has_min; s.has_max = a->has_max; s.min_log_std = a->min_log_std;

@@ -110,8 +110,8 @@ int ga_set_fused_head_forward(int mode);
 int ga_set_small_m_gemm(int on);
 /* ga_update_epoch*: a minibatch of <= 64 rows through a network of two equal
  * tanh hidden layers (32, 64, ... 256 units, <= 32 inputs, <= 8 outputs;
- * Gaussian PPO / VPG objective with its entropy options, or the value NLL; one
- * process) takes its whole optimizer step -- gather, forward, loss, backward,
+ * Gaussian or categorical PPO / VPG objective with the entropy options, or the
+ * value NLL; one process) takes its whole optimizer step -- gather, forward, loss, backward,
  * Adam -- in ONE launch of H / 16 workgroups with two grid barriers
  * (small_step.hip) instead of ten dependent launches.  Same formulas, other
  * summation orders: results agree to rounding.  The last slot of the reduction

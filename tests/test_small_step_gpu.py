@@ -174,3 +174,84 @@ def test_small_step_gradients_match_per_layer_path(case):
         assert scale > 1e-2  # the pass did move the parameters
         d = float((out[1][i] - out[0][i]).abs().max())
         assert d < 1e-4 * scale + 4e-5, (i, d, scale)
+
+
+@pytest.mark.parametrize('kw', [dict(), dict(entropy_method='regularized',
+                                             policy_ent_coeff=0.02),
+                                dict(entropy_method='max', policy_ent_coeff=0.05,
+                                     center_adv=False,
+                                     stop_entropy_gradient=True)])
+def test_categorical_small_steps_vs_oracle_and_per_layer_path(kw):
+    """BASELINE.json configs[0]'s shape of problem (discrete actions, MLP(32,32),
+    the default minibatch of 64): a categorical PPO iteration whose optimizer
+    steps all take the one-launch path, against the oracle and -- gradients, with
+    the linear-regime Adam -- against the per-layer path."""
+    from garage_amd import _lib
+    from garage_amd.algos import PPO
+    from garage_amd.envs import SyntheticVecEnv
+    from garage_amd.optimizers import OptimizerWrapper
+    from garage_amd.policies import (CategoricalMLPPolicy,
+                                     GaussianMLPValueFunction)
+    from garage_amd.sampler import GpuVecSampler, GpuVecWorker
+    from oracle import batch as ob
+    from oracle.ppo import OraclePPO
+    lib = _lib.load()
+    n, O, A, P = 24, 4, 2, 20
+    E, mb = 2, 64
+
+    def build(opt):
+        torch.manual_seed(9)
+        env = SyntheticVecEnv(n, O, A, P, min_len=4, seed=11, discrete=True)
+        pol = CategoricalMLPPolicy(env.spec, hidden_sizes=(32, 32))
+        vf = GaussianMLPValueFunction(env.spec, hidden_sizes=(32, 32))
+        sampler = GpuVecSampler(pol, env, max_episode_length=P, n_workers=1,
+                                worker_class=GpuVecWorker,
+                                worker_args=dict(n_envs=n))
+        algo = PPO(env_spec=env.spec, policy=pol, value_function=vf,
+                   sampler=sampler,
+                   policy_optimizer=OptimizerWrapper(opt, pol, E, mb),
+                   vf_optimizer=OptimizerWrapper(opt, vf, E, mb), **kw)
+        return algo, sampler, pol, vf
+
+    # against the oracle, default Adam
+    lib.ga_set_small_step(1)
+    algo, sampler, pol, vf = build((torch.optim.Adam, dict(lr=1e-3)))
+    oracle = OraclePPO(pol.state_dict(), vf.state_dict(), max_episode_length=P,
+                       policy_kind='categorical', max_optimization_epochs=E,
+                       minibatch_size=mb, policy_lr=1e-3, vf_lr=1e-3, **kw)
+    eps = sampler.obtain_samples(0, n * P, None)
+    host = ob.OracleEpisodeBatch(
+        observations=eps.observations, last_observations=eps.last_observations,
+        actions=eps.actions, rewards=eps.rewards, step_types=eps.step_types,
+        lengths=eps.lengths, max_episode_length=P)
+    np.random.seed(70)
+    want = oracle.train_once(host)
+    n0 = int(lib.ga_small_step_launches())
+    np.random.seed(70)
+    algo._train_once(0, eps)
+    S = int(eps.lengths.sum())
+    assert int(lib.ga_small_step_launches()) - n0 == 2 * E * -(-S // mb)
+    for k in LOG_KEYS:
+        assert np.isclose(algo.last_tabular[k], want[k], atol=2e-5, rtol=2e-5), \
+            (k, algo.last_tabular[k], want[k])
+    wp, wv = oracle.state()
+    for state, ref in ((pol.state_dict(), wp), (vf.state_dict(), wv)):
+        for k, v in state.items():
+            d = np.abs(v.numpy() - np.asarray(ref[k]))
+            assert d.max() < 5e-4 and d.mean() < 1e-6, (k, d.max(), d.mean())
+    # gradients against the per-layer path
+    out = {}
+    for on in (1, 0):
+        lib.ga_set_small_step(on)
+        algo, sampler, pol, vf = build(
+            (torch.optim.Adam, dict(lr=1e-3, betas=(0.0, 0.0), eps=1.0)))
+        eps = sampler.obtain_samples(0, n * P, None)
+        p0, v0 = pol.net.params.clone(), vf.net.params.clone()
+        np.random.seed(70)
+        algo._train_once(0, eps)
+        out[on] = ((pol.net.params - p0) / 1e-3, (vf.net.params - v0) / 1e-3)
+    lib.ga_set_small_step(1)
+    for i in (0, 1):
+        scale = float(out[0][i].abs().max())
+        d = float((out[1][i] - out[0][i]).abs().max())
+        assert scale > 1e-2 and d < 1e-4 * scale + 4e-5, (i, d, scale)
