@@ -40,6 +40,13 @@ CONFIGS = {
     # SURVEY.md section 8d setting (ii): the reference's default minibatch
     # (ppo.py:65-76: 64 samples) on a reduced batch, 5 120 optimizer steps per
     # iteration as in BASELINE.md section 2's reference measurement
+    # BASELINE.json configs[0]'s shape (CartPole: obs 4, 2 discrete actions,
+    # MLP(32,32), batch 2048, the reference-default minibatch of 64) on the
+    # synthetic env -- the reference itself runs this one on the CPU
+    'c1': dict(name='CartPole-shape synthetic, discrete-2 categorical head, '
+               'batch 2048, reference-default minibatch 64', obs_dim=4,
+               act_dim=2, n_envs=16, T=128, hidden=(32, 32), min_len=None,
+               discrete=True, minibatches=32),
     'c3mb64': dict(name='HalfCheetah-shape synthetic, reference-default '
                    'minibatch 64 on a reduced batch', obs_dim=17, act_dim=6,
                    n_envs=64, T=256, hidden=(256, 256), min_len=None,
