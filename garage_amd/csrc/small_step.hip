@@ -815,6 +815,8 @@ extern "C" int ga_small_step(const ga_small_step_args* a, hipStream_t stream) {
              "ga_small_step: null pointer");
   const int dims[4] = {a->in_w, a->H, a->H, a->out_w};
   GA_REQUIRE(ga_small_step_supported(3, dims, a->M), "ga_small_step: unsupported shape");
+  GA_REQUIRE(ga_aligned16(a->X) && a->ldx % 4 == 0 && a->ldx >= ((a->in_w + 3) & ~3),
+             "ga_small_step: X rows must be 16-B aligned quads");
   GA_REQUIRE(ga_aligned16(a->params) && ga_aligned16(a->xh2) && ga_aligned16(a->xdz) &&
                  a->w_off[1] % 4 == 0 && a->w_off[2] % 4 == 0,
              "ga_small_step: alignment");
