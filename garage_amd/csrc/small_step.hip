@@ -818,7 +818,7 @@ extern "C" int ga_small_step(const ga_small_step_args* a, hipStream_t stream) {
   GA_REQUIRE(ga_aligned16(a->X) && a->ldx % 4 == 0 && a->ldx >= ((a->in_w + 3) & ~3),
              "ga_small_step: X rows must be 16-B aligned quads");
   GA_REQUIRE(ga_aligned16(a->params) && ga_aligned16(a->xh2) && ga_aligned16(a->xdz) &&
-                 a->w_off[1] % 4 == 0 && a->w_off[2] % 4 == 0,
+                 a->w_off[0] % 4 == 0 && a->w_off[1] % 4 == 0 && a->w_off[2] % 4 == 0,
              "ga_small_step: alignment");
   GA_REQUIRE(a->kind != 1 ? (a->actions && a->adv && (a->algo == 1 || a->old_ll))
                           : (a->returns != nullptr),
