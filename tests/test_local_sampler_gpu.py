@@ -81,3 +81,31 @@ def test_no_seed_and_init_without_worker_factory():
         GpuVecSampler(agents=pol, envs=_env())
     eps = sampler.obtain_samples(0, 20, None)
     assert sum(eps.lengths) >= 20
+
+
+def test_ownership_policy_by_reference_envs_by_copy_batches_not_reused():
+    """``local_sampler.py:16-18,77-79``: the sampler works on the caller's policy
+    object (updates of its parameters are seen without an ``agent_update``), on
+    deep copies of the environments, and never touches a batch it has returned."""
+    from garage_amd.sampler import GpuVecSampler, GpuVecWorker
+    pol = _fixed_policy([0.25, -0.5])
+    env = _env()
+    sampler = GpuVecSampler(agents=pol, envs=env, max_episode_length=P,
+                            n_workers=1, worker_class=GpuVecWorker,
+                            worker_args=dict(n_envs=3))
+    worker = sampler._workers[0]
+    assert worker.agent is pol
+    assert all(e is not env for e in worker.env.envs)
+    assert len({id(e) for e in worker.env.envs}) == 3
+    eps1 = sampler.obtain_samples(0, 20, None)
+    kept = {k: np.array(getattr(eps1, k), copy=True)
+            for k in ('observations', 'actions', 'rewards', 'lengths')}
+    assert np.allclose(eps1.actions, [0.25, -0.5], atol=1e-4)
+    assert env._episode == -1  # the caller's environment was never stepped
+    # the caller changes its policy in place: the next batch follows
+    pol.net.bias(0).copy_(torch.tensor([0.75, 0.1]))
+    eps2 = sampler.obtain_samples(1, 20, None)
+    assert np.allclose(eps2.actions, [0.75, 0.1], atol=1e-4)
+    for k, v in kept.items():
+        assert np.array_equal(getattr(eps1, k), v), k
+    sampler.shutdown_worker()
