@@ -100,6 +100,21 @@ class Discrete:
         x = np.asarray(x)
         return x.shape == () and 0 <= int(x) < self.n
 
+    def flatten(self, x):
+        """One-hot vector of length ``n`` (``akro.Discrete.flatten``)."""
+        out = np.zeros(self.n, dtype=np.float32)
+        out[int(x)] = 1.0
+        return out
+
+    def flatten_n(self, xs):
+        xs = np.asarray(xs, dtype=np.int64).reshape(-1)
+        out = np.zeros((xs.shape[0], self.n), dtype=np.float32)
+        out[np.arange(xs.shape[0]), xs] = 1.0
+        return out
+
+    def unflatten(self, x):
+        return int(np.nonzero(np.asarray(x))[0][0])
+
     def __repr__(self):
         return 'Discrete({})'.format(self.n)
 
@@ -458,11 +473,12 @@ class DeviceEpisodeBatch(EpisodeBatch):
 
     def _materialise(self, name):
         O = self.env_spec.observation_space.flat_dim
-        if name == 'observations':
-            a = self.obs_dev[:, :O].cpu().numpy()
-            return a.reshape((a.shape[0], ) + self._obs_shape())
-        if name == 'last_observations':
-            a = self.last_obs_dev[:, :O].cpu().numpy()
+        if name in ('observations', 'last_observations'):
+            dev = self.obs_dev if name == 'observations' else self.last_obs_dev
+            a = dev[:, :O].cpu().numpy()
+            if is_discrete(self.env_spec.observation_space):
+                # the networks saw one-hot rows; garage's batch holds the states
+                return a.argmax(axis=1).astype(np.int64)
             return a.reshape((a.shape[0], ) + self._obs_shape())
         if name == 'actions':
             if self._discrete:

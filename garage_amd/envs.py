@@ -289,7 +289,15 @@ class HostVecEnv(VecEnv):
         self.last_env_infos = None
 
     def _put_obs(self, i, obs):
-        flat = np.asarray(obs, dtype=np.float32).reshape(-1)
+        # discrete observation spaces are seen one-hot by the networks, as
+        # ``observation_space.flatten`` makes them for garage's policies
+        # (torch/policies/stochastic_policy.py:70-74)
+        space = self.spec.observation_space
+        if is_discrete(space):
+            flat = np.zeros(space.flat_dim, dtype=np.float32)
+            flat[int(obs)] = 1.0
+        else:
+            flat = np.asarray(obs, dtype=np.float32).reshape(-1)
         self._h_obs[i, :flat.shape[0]] = torch.from_numpy(flat)
 
     def reset_all(self):

@@ -165,6 +165,17 @@ class _GaussianMLP:
             observations = np.stack([np.asarray(o) for o in observations])
         if torch.is_tensor(observations):
             observations = observations.detach().cpu().numpy()
+        space = getattr(getattr(self, '_env_spec', None), 'observation_space',
+                        None)
+        obs = np.asarray(observations)
+        if space is not None and is_discrete(space) and (
+                obs.ndim == 1 or obs.shape[-1] != space.flat_dim):
+            # state indices -> one-hot rows (observation_space.flatten_n,
+            # torch/policies/stochastic_policy.py:70-74)
+            ids = obs.astype(np.int64).reshape(-1)
+            flat = np.zeros((ids.shape[0], space.flat_dim), dtype=np.float32)
+            flat[np.arange(ids.shape[0]), ids] = 1.0
+            return pad_rows(flat)
         flat = np.asarray(observations, dtype=np.float32)
         flat = flat.reshape(flat.shape[0], -1)
         return pad_rows(flat)

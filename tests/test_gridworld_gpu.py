@@ -1,0 +1,131 @@
+"""The reference's own sampler scenario (tests/garage/sampler/test_vec_worker.py:
+14-60,62-118): ``GridWorldEnv`` maps with discrete observations and a scripted
+policy, one vectorised worker against one ``DefaultWorker`` per environment --
+the sets of (actions, observations) of the episodes must be equal.  The grid world
+below restates ``envs/grid_world_env.py:111-215`` (deterministic moves, holes and
+goal end the episode); the scripted policy is a one-layer categorical "network"
+whose weight matrix is the action table, seen through one-hot observations."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+MAX_EPISODE_LENGTH = 9
+SCRIPT = [2, 2, 1, 0, 3, 1, 1, 1, 2, 2, 1, 1, 1, 2, 2, 1]
+DESCS = [
+    ['SFFF', 'FHFH', 'FFFH', 'HFFG'],
+    ['SFFF', 'FFFH', 'FHFH', 'HFFG'],
+    ['SFFF', 'FFFH', 'FHFH', 'FFFG'],
+    ['SFFF', 'FFFF', 'FFFF', 'FFFF'],
+    ['SHFF', 'HHFF', 'FFFF', 'FFFF'],
+]
+OTHER = [
+    ['FFFS', 'FHFH', 'FFFH', 'HFFG'],
+    ['FFSF', 'FFFH', 'FHFH', 'HFFG'],
+    ['FFFF', 'FFSH', 'FHFH', 'FFFG'],
+    ['FFFF', 'FFFF', 'FSFF', 'FFFF'],
+    ['HHFF', 'HHHF', 'HSHF', 'HHHF'],
+]
+
+
+class GridWorld:
+    """``GridWorldEnv`` (``envs/grid_world_env.py``) for 4x4 maps."""
+
+    def __init__(self, desc, max_episode_length=None):
+        from garage_amd._dtypes import Discrete, EnvSpec
+        self._desc = np.array([list(row) for row in desc])
+        self._n_row, self._n_col = self._desc.shape
+        (sx, ), (sy, ) = np.nonzero(self._desc == 'S')
+        self._start = int(sx) * self._n_col + int(sy)
+        self._state, self._step_cnt = None, None
+        self._max_len = max_episode_length
+        self.spec = EnvSpec(Discrete(self._n_row * self._n_col), Discrete(4),
+                            max_episode_length=max_episode_length)
+
+    def reset(self):
+        self._state, self._step_cnt = self._start, 0
+        return self._state, {}
+
+    def step(self, action):
+        from garage_amd._dtypes import StepType
+        from oracle.envs import EnvStepLite
+        x, y = divmod(self._state, self._n_col)
+        inc = [[0, -1], [1, 0], [0, 1], [-1, 0]][int(action)]
+        nx = min(max(x + inc[0], 0), self._n_row - 1)
+        ny = min(max(y + inc[1], 0), self._n_col - 1)
+        here, there = self._desc[x, y], self._desc[nx, ny]
+        nxt = self._state if (there == 'W' or here in 'HG') else nx * self._n_col + ny
+        kind = self._desc[divmod(nxt, self._n_col)]
+        done, reward = kind in 'HG', float(kind == 'G')
+        self._state = nxt
+        self._step_cnt += 1
+        st = StepType.get_step_type(self._step_cnt, self._max_len, done)
+        return EnvStepLite(action, reward, nxt, {}, st)
+
+    def close(self):
+        pass
+
+
+class Scripted:
+    """``ScriptedPolicy`` (np/policies/scripted_policy.py): action = table[obs]."""
+
+    def reset(self, do_resets=None):
+        pass
+
+    def get_actions(self, obs):
+        return np.asarray([SCRIPT[int(o)] for o in obs]), {}
+
+    def get_action(self, obs):
+        return SCRIPT[int(obs)], {}
+
+
+def _table_policy(spec):
+    """The same table as a one-layer categorical policy over one-hot states."""
+    from garage_amd.policies import CategoricalMLPPolicy
+    pol = CategoricalMLPPolicy(spec, hidden_sizes=(), double_softmax=False)
+    w = torch.full((4, 16), -40.0)
+    for s, a in enumerate(SCRIPT):
+        w[a, s] = 40.0
+    pol.net.weight(0).copy_(w)
+    pol.net.bias(0).zero_()
+    return pol
+
+
+def _episode_set(eps):
+    out, start = set(), 0
+    for L in eps.lengths:
+        stop = start + int(L)
+        out.add((tuple(int(a) for a in np.asarray(eps.actions)[start:stop]),
+                 tuple(int(o) for o in np.asarray(eps.observations)[start:stop])))
+        start = stop
+    return out
+
+
+def test_vectorised_rollouts_equal_per_env_workers_on_grid_worlds():
+    from garage_amd.sampler import GpuVecSampler, GpuVecWorker
+    from oracle import sampler as osamp
+    P, n = MAX_EPISODE_LENGTH, len(DESCS)
+    envs = [GridWorld(d, P) for d in DESCS]
+    vec = GpuVecSampler(_table_policy(envs[0].spec), [envs],
+                        max_episode_length=P, n_workers=1,
+                        worker_class=GpuVecWorker, worker_args=dict(n_envs=n))
+    true = osamp.OracleLocalSampler(Scripted(), [GridWorld(d, P) for d in DESCS],
+                                    max_episode_length=P, n_workers=n,
+                                    worker_class=osamp.OracleDefaultWorker)
+    n_samples = 100
+    for _ in range(2):  # the second round exercises the reset at the call start
+        true_eps = true.obtain_samples(0, n_samples, None)
+        vec_eps = vec.obtain_samples(0, n_samples, None)
+        assert vec_eps.lengths.sum() >= n_samples
+        assert vec_eps.observations.dtype == np.int64  # states, not one-hot rows
+        assert _episode_set(vec_eps) == _episode_set(true_eps)
+        vec_eps.to_host()  # passes EpisodeBatch validation for a Discrete space
+    # test_reset_optimization: other maps replace all five environments
+    true_eps = true.obtain_samples(0, 4 * P, None,
+                                   [GridWorld(d, P) for d in OTHER])
+    vec_eps = vec.obtain_samples(0, 4 * P, None,
+                                 [[GridWorld(d, P) for d in OTHER]])
+    assert vec_eps.lengths.sum() >= 4 * P
+    assert _episode_set(vec_eps) == _episode_set(true_eps)
+    vec.shutdown_worker()

@@ -224,3 +224,14 @@ def test_step_types_as_uint8_fast_and_fallback_paths():
     assert step_types_as_uint8(np.array([], dtype=object)).shape == (0, )
     strided = np.array(members, dtype=object)[::3]  # non-contiguous view
     assert np.array_equal(step_types_as_uint8(strided), codes[::3])
+
+
+def test_discrete_space_flatten_is_one_hot():
+    """``akro.Discrete.flatten`` / ``flatten_n`` / ``unflatten`` semantics."""
+    from garage_amd._dtypes import Discrete
+    sp = Discrete(5)
+    assert sp.flat_dim == 5 and sp.contains(np.int64(4)) and not sp.contains(5)
+    assert np.array_equal(sp.flatten(3), [0, 0, 0, 1, 0])
+    assert np.array_equal(sp.flatten_n([0, 4]),
+                          [[1, 0, 0, 0, 0], [0, 0, 0, 0, 1]])
+    assert sp.unflatten(sp.flatten(2)) == 2
