@@ -129,3 +129,76 @@ def test_vectorised_rollouts_equal_per_env_workers_on_grid_worlds():
     assert vec_eps.lengths.sum() >= 4 * P
     assert _episode_set(vec_eps) == _episode_set(true_eps)
     vec.shutdown_worker()
+
+
+# the maps test_fragment_worker.py:41-50 swaps in
+FRAG_OTHER = [
+    ['SFFF', 'FFFF', 'FFFF', 'FFFF'],
+    ['FFSF', 'FFFH', 'FHFH', 'HFFG'],
+    ['FHSF', 'FFFH', 'FHFH', 'HFFG'],
+    ['FHSF', 'FGFH', 'FHFH', 'HFFH'],
+    ['SHFF', 'HHFF', 'FFFF', 'FFFF'],
+]
+
+
+def _slices(eps, size):
+    """Every episode cut into consecutive pieces of ``size`` steps
+    (test_fragment_worker.py:51-82), as (actions, observations) -- what the
+    reference's ``eps_eq`` compares.  (Last observations are left out as there:
+    ``DefaultWorker`` records the observation BEFORE an episode's final step as its
+    last one, ``default_worker.py:120-131``, the vectorised workers the one after.)"""
+    out, start = [], 0
+    obs, act = np.asarray(eps.observations), np.asarray(eps.actions)
+    for L in eps.lengths:
+        L = int(L)
+        for a in range(0, L, size):
+            b = min(a + size, L)
+            out.append((tuple(int(v) for v in act[start + a:start + b]),
+                        tuple(int(v) for v in obs[start + a:start + b])))
+        start += L
+    return out
+
+
+@pytest.mark.parametrize('tpc', [1, 2])
+def test_fragment_worker_on_grid_worlds(tpc):
+    """tests/garage/sampler/test_fragment_worker.py:86-139: every rollout()
+    yields ``timesteps_per_call`` steps per environment, no episode ends during
+    the first four steps, and through the sampler every fragment is a slice of
+    an episode the per-env workers collect -- also after the maps are swapped."""
+    import math
+
+    from garage_amd._dtypes import StepType
+    from garage_amd.sampler import (GpuFragmentWorker, GpuVecSampler,
+                                    WorkerFactory)
+    from oracle import sampler as osamp
+    P, n = MAX_EPISODE_LENGTH, len(DESCS)
+    env = GridWorld(['SFFF', 'FHFH', 'FFFH', 'HFFG'], P)
+    worker = GpuFragmentWorker(seed=100, max_episode_length=P, worker_number=0,
+                               n_envs=n, timesteps_per_call=tpc)
+    worker.update_agent(_table_policy(env.spec))
+    worker.update_env(env)
+    for i in range(math.ceil(P / tpc)):
+        eps = worker.rollout()
+        assert sum(eps.lengths) == tpc * n
+        if tpc * i < 4:
+            assert not any(s == StepType.TERMINAL for s in eps.step_types)
+    worker.shutdown()
+
+    envs = [GridWorld(d, P) for d in DESCS]
+    wf = WorkerFactory(seed=100, n_workers=1, max_episode_length=P,
+                       worker_class=GpuFragmentWorker,
+                       worker_args=dict(n_envs=n, timesteps_per_call=tpc))
+    vec = GpuVecSampler.from_worker_factory(wf, _table_policy(env.spec), [envs])
+    true = osamp.OracleLocalSampler(Scripted(), [GridWorld(d, P) for d in DESCS],
+                                    max_episode_length=P, n_workers=n,
+                                    worker_class=osamp.OracleDefaultWorker)
+    for update_true, update_vec in (
+            (None, None),
+            ([GridWorld(d, P) for d in FRAG_OTHER],
+             [[GridWorld(d, P) for d in FRAG_OTHER]])):
+        want = set(_slices(true.obtain_samples(0, 400, None, update_true), tpc))
+        got = vec.obtain_samples(0, 50, None, update_vec)
+        assert sum(got.lengths) >= 50
+        for piece in _slices(got, tpc):
+            assert piece in want, piece
+    vec.shutdown_worker()
