@@ -145,8 +145,9 @@ def _slices(eps, size):
     """Every episode cut into consecutive pieces of ``size`` steps
     (test_fragment_worker.py:51-82), as (actions, observations) -- what the
     reference's ``eps_eq`` compares.  (Last observations are left out as there:
-    ``DefaultWorker`` records the observation BEFORE an episode's final step as its
-    last one, ``default_worker.py:120-131``, the vectorised workers the one after.)"""
+    for a TERMINAL ending ``DefaultWorker`` records the observation BEFORE the final
+    step as the last one, ``default_worker.py:108-121``, the vectorised workers the
+    one after.)"""
     out, start = [], 0
     obs, act = np.asarray(eps.observations), np.asarray(eps.actions)
     for L in eps.lengths:
