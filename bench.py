@@ -190,8 +190,9 @@ def cpu_baseline(cfg, n_envs, seed=1):
     # thread per logical CPU of the whole machine) oversubscribes it badly
     torch.set_num_threads(max(1, min(CPU_THREADS, os.cpu_count() or 1)))
     rng = np.random.RandomState(seed)
+    discrete = bool(cfg.get('discrete'))
     polp = nets.init_gaussian_mlp(rng, nets.POLICY_PREFIX, O, A, cfg['hidden'],
-                                  min_std=1e-6)
+                                  min_std=None if discrete else 1e-6)
     vfp = nets.init_gaussian_mlp(rng, nets.VALUE_PREFIX, O, 1, cfg['hidden'])
     S = n_envs * T
     # the sample keeps the GPU run's minibatch size when the config fixes it
@@ -202,7 +203,8 @@ def cpu_baseline(cfg, n_envs, seed=1):
                      minibatch_size=mb, policy_lr=HYPER['lr'],
                      vf_lr=HYPER['lr'], discount=HYPER['discount'],
                      gae_lambda=HYPER['gae_lambda'],
-                     lr_clip_range=HYPER['lr_clip_range'])
+                     lr_clip_range=HYPER['lr_clip_range'],
+                     policy_kind='categorical' if discrete else 'gaussian')
 
     class Agent:
 
@@ -211,13 +213,18 @@ def cpu_baseline(cfg, n_envs, seed=1):
 
         def get_actions(self, obs):
             with torch.no_grad():
-                dist, info = nets.policy_forward(
-                    algo.policy, torch.from_numpy(np.asarray(obs, np.float32)))
+                x = torch.from_numpy(np.asarray(obs, np.float32))
+                if discrete:
+                    dist = nets.categorical_dist(algo.policy,
+                                                 nets.POLICY_PREFIX, x)
+                    return dist.sample().numpy(), {}
+                dist, info = nets.policy_forward(algo.policy, x)
                 return dist.sample().numpy(), {
                     k: v.numpy() for k, v in info.items()
                 }
 
-    envs = [oenvs.SyntheticEnv(i, O, A, T, min_len=cfg['min_len'], seed=seed)
+    envs = [oenvs.SyntheticEnv(i, O, A, T, min_len=cfg['min_len'], seed=seed,
+                               discrete=discrete)
             for i in range(n_envs)]
     sampler = osamp.OracleLocalSampler(
         Agent(), [envs], max_episode_length=T, n_workers=1,
@@ -442,8 +449,7 @@ def main():
                  avg_launch_us=r['total_ms'] * 1e3 / r['launches'])
             for r in rows[7:9] if r['launches'] > 0
         ]
-    if args.cpu_envs > 0 and world == 1 and args.algo == 'ppo' \
-            and not cfg.get('discrete'):
+    if args.cpu_envs > 0 and world == 1 and args.algo == 'ppo':
         line['cpu_baseline'] = cpu_baseline(cfg, min(args.cpu_envs,
                                                      cfg['n_envs']))
     print(json.dumps(line))
