@@ -341,6 +341,9 @@ __device__ __forceinline__ void gemm_mainloop(const GemmParams& p, float* lds,
             b[j][q] = Bs[(8 * g + 4 * half + q) * LDB_S + wn0 + 32 * j + l31];
         }
       }
+      // the wave that is about to issue MFMAs goes ahead of co-resident waves that
+      // are still loading / storing tiles (-0.8 % per C3 iteration, 2 x A/B)
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -349,6 +352,7 @@ __device__ __forceinline__ void gemm_mainloop(const GemmParams& p, float* lds,
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[j][q],
                                                              acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
     }
     if (do_colsum) {
       const float* T = p.colsum_of_b ? Bs : As;

@@ -14,5 +14,4 @@ build() {  # name, flags...
   echo built $name
 }
 build occ6 -DGA_GEMM_WAVES_PER_EU=6 &
-build occ5 -DGA_GEMM_WAVES_PER_EU=5 &
 wait
