@@ -314,9 +314,10 @@ __device__ __forceinline__ void gemm_mainloop(const GemmParams& p, float* lds,
     // Groups of 4 MFMAs over 8 physical k: lane half h feeds k = 8g + 4h + q
     // to step q (any k <-> slot map is valid as long as A and B agree), so a
     // k-contiguous operand is ONE ds_read_b128 per 4 MFMAs.
-#pragma unroll
-    for (int g = 0; g < BKT / 8; ++g) {
-      float a[TM][4], b[TN][4];
+    // (reading the operands of group g + 1 before issuing the MFMAs of group g was
+    // measured: no gain -- 146.0 / 148.2 vs 145.2 / 144.7 ms -- the other waves of
+    // the SIMD cover the LDS round trip already)
+    auto read_frags = [&](float (&a)[TM][4], float (&b)[TN][4], int g) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         if (A_KC) {
@@ -341,6 +342,8 @@ __device__ __forceinline__ void gemm_mainloop(const GemmParams& p, float* lds,
             b[j][q] = Bs[(8 * g + 4 * half + q) * LDB_S + wn0 + 32 * j + l31];
         }
       }
+    };
+    auto issue = [&](const float (&a)[TM][4], const float (&b)[TN][4]) {
       // the wave that is about to issue MFMAs goes ahead of co-resident waves that
       // are still loading / storing tiles (-0.8 % per C3 iteration, 2 x A/B)
       __builtin_amdgcn_s_setprio(1);
@@ -353,6 +356,12 @@ __device__ __forceinline__ void gemm_mainloop(const GemmParams& p, float* lds,
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[j][q],
                                                              acc[i][j], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
+    };
+#pragma unroll
+    for (int g = 0; g < BKT / 8; ++g) {
+      float a[TM][4], b[TN][4];
+      read_frags(a, b, g);
+      issue(a, b);
     }
     if (do_colsum) {
       const float* T = p.colsum_of_b ? Bs : As;
