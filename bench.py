@@ -5,6 +5,11 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
+Without a launcher (``WORLD_SIZE`` unset) ``--gpus N > 1`` starts the N ranks
+itself: N fresh child processes with a torchrun-style environment, before this
+process has touched the GPU; it relays rank 0's JSON line and exits non-zero
+if any rank does.
+
 One "step" = one PPO iteration: a rollout of ``n_envs x T`` synthetic env steps
 through ``GpuVecSampler`` followed by one ``PPO._train_once`` (value baselines,
 GAE scan, advantage centring, E epochs x 32 minibatches of policy updates, then
@@ -21,7 +26,8 @@ import sys
 import time
 
 import numpy as np
-import torch
+
+torch = None  # imported in main(), after the self-launch decision
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -109,8 +115,7 @@ def build_engine(cfg, comm, seed=1, algo_name='ppo'):
     vf = GaussianMLPValueFunction(env.spec, hidden_sizes=cfg['hidden'])
     sampler = GpuVecSampler(pol, env, max_episode_length=T, n_workers=1,
                             worker_class=GpuVecWorker, seed=seed + rank,
-                            worker_args=dict(n_envs=n,
-                                             store_agent_infos=False))
+                            worker_args=dict(n_envs=n))
     S = n * T
     mb = S // n_minibatches(cfg)
     opt = (torch.optim.Adam, dict(lr=HYPER['lr']))
@@ -246,6 +251,56 @@ def cpu_baseline(cfg, n_envs, seed=1):
                     os.cpu_count()))
 
 
+def self_launch(n):
+    """Run this command as ``n`` ranks (one child process per GPU) and relay
+    rank 0's output.  The parent never initialises the GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r),
+                   WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        procs.append(subprocess.Popen(
+            [sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+            env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    rc = 0
+    try:
+        pending = set(range(n))
+        while pending and rc == 0:
+            time.sleep(0.2)
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0:
+                    print('bench.py: rank {} exited with code {}'.format(
+                        r, code), file=sys.stderr)
+                    rc = code if code > 0 else 1
+    finally:
+        for p in procs:  # a failed rank leaves its peers in a collective
+            if p.poll() is None:
+                if rc == 0:
+                    p.wait()
+                else:
+                    p.terminate()
+        out = procs[0].stdout.read().decode()
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    p.wait(10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -279,13 +334,18 @@ def main():
                     'the other on one stream (isolated per-kernel timings)')
     args = ap.parse_args()
 
-    from garage_amd.distributed import init_from_env
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(args.gpus))
+    global torch
+    import torch
+
+    from garage_amd.distributed import gradient_exchange, init_from_env
     comm = init_from_env()
     world = comm.world_size if comm is not None else 1
     rank = comm.rank if comm is not None else 0
-    if world != args.gpus and rank == 0:
-        print('warning: --gpus {} but WORLD_SIZE {}'.format(args.gpus, world),
-              file=sys.stderr)
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus {} but WORLD_SIZE is {}'.format(
+            args.gpus, world))
     cfg = CONFIGS[args.config]
     algo, sampler, pol, S = build_engine(cfg, comm, algo_name=args.algo)
     algo.overlap_updates = not args.no_overlap
@@ -360,7 +420,8 @@ def main():
             'workload': ('{}: obs {} act {}, {} envs/GPU x T={}, '
                          'MLP{} policy + value, {} E={} x {} minibatches, '
                          'gamma {} lambda {} clip {} Adam lr {}, device '
-                         'minibatch permutation, policy/value passes {}').format(
+                         'minibatch permutation, agent_infos (mean, log_std) '
+                         'stored, policy/value passes {}').format(
                             cfg['name'], cfg['obs_dim'], cfg['act_dim'],
                             cfg['n_envs'], cfg['T'], cfg['hidden'],
                             'PPO' if args.algo == 'ppo' else
@@ -374,6 +435,9 @@ def main():
             'parallelism': 'dp{}'.format(world),
         },
     }
+    exchange, rccl_ranks = gradient_exchange(algo)
+    line['grad_allreduce'] = exchange
+    line['rccl_ranks'] = rccl_ranks
     if rows is not None:
         gemms = [r for r in rows[:6] if r['launches'] > 0]
         dom = max(gemms, key=lambda r: r['total_ms'])

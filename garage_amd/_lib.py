@@ -76,7 +76,8 @@ class UpdateArgs(C.Structure):
                 ('clip', c_f32), ('ent_coeff', c_f32), ('ent_flags', c_i32),
                 ('losses', ptr), ('loss_scratch', ptr), ('workspace', ptr),
                 ('comm', ptr), ('world', c_i32), ('double_softmax', c_i32),
-                ('grad_scale', c_f32)]
+                ('grad_scale', c_f32), ('n_mb', c_i64),
+                ('grad_scales_host', ptr)]
 
 
 # name -> (restype, argtypes); mirrors include/garage_amd.h one to one.
@@ -188,10 +189,13 @@ SIGNATURES = {
     'ga_update_epoch_pair': (c_int, [C.POINTER(UpdateArgs), ptr,
                                      C.POINTER(UpdateArgs), ptr]),
     'ga_set_allreduce_hook': (None, [ptr]),
+    'ga_comm_available': (c_int, []),
     'ga_comm_unique_id': (c_int, [ptr]),
     'ga_comm_init_rank': (ptr, [ptr, c_int, c_int]),
     'ga_comm_allreduce_sum_f32': (c_int, [ptr, ptr, c_i64, ptr]),
+    'ga_comm_count': (c_int, [ptr]),
     'ga_comm_destroy': (c_int, [ptr]),
+    'ga_set_ordered_allreduce': (c_int, [c_int]),
     'ga_prof_enable': (c_int, [c_int]),
     'ga_prof_collect': (c_int, [C.POINTER(c_f64), c_int]),
 }

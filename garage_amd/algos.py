@@ -19,7 +19,7 @@ from garage_amd._dtypes import (DeviceEpisodeBatch, StepType, is_discrete,
 from garage_amd._lib import call, dptr, stream_ptr
 from garage_amd.engine import (HALF_LOG_2PI, center_advantages, gae_scan,
                                pad_rows, reduction_workspace, round4)
-from garage_amd.optimizers import OptimizerWrapper
+from garage_amd.optimizers import OptimizerWrapper, data_parallel_plan
 from garage_amd.policies import GaussianMLPPolicy
 
 
@@ -451,11 +451,11 @@ class VPG:
         for opt in (self._policy_optimizer, self._vf_optimizer):
             opt.dp_grad_scale = share
             mb = opt._minibatch_size
-            opt.dp_minibatches = (None if mb is None else
-                                  -(-max(counts) // int(mb)))
-            if mb is not None and min(counts) < opt.dp_minibatches:
-                raise RuntimeError('a rank holds fewer samples than there are '
-                                   'minibatches per pass')
+            opt.dp_minibatches = opt.dp_grad_scales = None
+            if mb is None:
+                continue
+            opt.dp_minibatches, opt.dp_grad_scales = data_parallel_plan(
+                counts, mb, self._comm.rank)
         return share
 
     def _normalise_advantages(self, adv):
@@ -664,11 +664,19 @@ class VPG:
         a.loss_scratch = scratch.data_ptr()
         a.workspace = reduction_workspace(dev, tag).data_ptr()
         comm = getattr(opt, 'native_comm', None)
+        keep = [scratch]
         if comm is not None:
             a.comm, a.world = comm.handle, comm.world_size
             a.grad_scale = float(opt.dp_grad_scale)
-        n_mb = 1 if mb is None else -(-S // mb)
-        return a, scratch, n_mb
+        n_mb = len(opt.minibatch_bounds(S)) - 1
+        if mb is not None and opt.dp_minibatches:
+            a.n_mb = n_mb  # even split: the same count on every rank
+            if opt.dp_grad_scales is not None:
+                scales = np.ascontiguousarray(opt.dp_grad_scales, np.float32)
+                assert scales.size == n_mb
+                a.grad_scales_host = scales.ctypes.data
+                keep.append(scales)
+        return a, keep, n_mb
 
     def _train_native_serial(self, batch, adv, returns, old_ll):
         """Policy pass then value pass on the current stream (the reference's

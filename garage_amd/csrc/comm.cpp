@@ -19,6 +19,7 @@ struct Api {
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t,
                             ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 } g;
 
@@ -34,6 +35,7 @@ bool load_api() {
   g.CommInitRank = (decltype(g.CommInitRank))dlsym(g.handle, "ncclCommInitRank");
   g.AllReduce = (decltype(g.AllReduce))dlsym(g.handle, "ncclAllReduce");
   g.CommDestroy = (decltype(g.CommDestroy))dlsym(g.handle, "ncclCommDestroy");
+  g.CommCount = (decltype(g.CommCount))dlsym(g.handle, "ncclCommCount");
   g.GetErrorString =
       (decltype(g.GetErrorString))dlsym(g.handle, "ncclGetErrorString");
   if (!g.GetUniqueId || !g.CommInitRank || !g.AllReduce || !g.CommDestroy) {
@@ -51,6 +53,8 @@ int allreduce_hook(void* comm, float* buf, int64_t n, void* stream) {
 }  // namespace
 
 static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+
+extern "C" int ga_comm_available(void) { return load_api() ? 1 : 0; }
 
 extern "C" int ga_comm_unique_id(void* id128_host) {
   if (!id128_host || !load_api()) return -1;
@@ -85,6 +89,19 @@ extern "C" int ga_comm_allreduce_sum_f32(void* comm, float* buf, int64_t n,
     return -1;
   }
   return allreduce_hook(comm, buf, n, (void*)stream);
+}
+
+extern "C" int ga_comm_count(void* comm) {
+  if (!comm || !load_api() || !g.CommCount) {
+    ga_set_error("ga_comm_count: bad arguments");
+    return -1;
+  }
+  int n = 0;
+  if (g.CommCount((ncclComm_t)comm, &n) != ncclSuccess) {
+    ga_set_error("ncclCommCount failed");
+    return -2;
+  }
+  return n;
 }
 
 extern "C" int ga_comm_destroy(void* comm) {

@@ -61,14 +61,42 @@ extern "C" int ga_set_small_step(int on) {
   return 0;
 }
 
+// ga_update_epoch_pair, data parallel: all-reduces of the two networks in one
+// total order per GPU (see include/garage_amd.h)
+static int g_ordered_allreduce = 1;
+extern "C" int ga_set_ordered_allreduce(int on) {
+  g_ordered_allreduce = on != 0;
+  return 0;
+}
+
 namespace {
+
+// events chaining the two networks' all-reduces; created once per process
+// (re-recorded every step: a stream wait captures the record it was issued after)
+struct ArOrder {
+  hipEvent_t wait_for = nullptr;  // recorded after the other network's last all-reduce
+  hipEvent_t record = nullptr;    // recorded after this one
+};
+hipEvent_t g_ar_events[2] = {nullptr, nullptr};
+
+bool ar_events_ready() {
+  for (int i = 0; i < 2; ++i) {
+    if (!g_ar_events[i] &&
+        hipEventCreateWithFlags(&g_ar_events[i], hipEventDisableTiming) != hipSuccess) {
+      g_ar_events[i] = nullptr;
+      return false;
+    }
+  }
+  return true;
+}
 
 int check_args(const ga_update_args* a) {
   if (!a || !a->desc || !a->params || !a->X || !a->workspace) {
     ga_set_error("ga_update_epoch: null pointer");
     return -1;
   }
-  if (a->S <= 0 || (a->perm && a->mb <= 0)) {
+  if (a->S <= 0 || (a->perm && a->mb <= 0 && a->n_mb <= 0) || a->n_mb < 0 ||
+      (a->perm && a->n_mb > a->S)) {
     ga_set_error("ga_update_epoch: bad sizes");
     return -1;
   }
@@ -76,17 +104,37 @@ int check_args(const ga_update_args* a) {
 }
 
 int64_t n_minibatches(const ga_update_args* a) {
+  if (a->perm && a->n_mb > 0) return a->n_mb;
   const int64_t mb = a->perm ? a->mb : a->S;
   return (a->S + mb - 1) / mb;
 }
 
-int run_minibatch(const ga_update_args* a, int64_t k, ga_stream_t stream) {
+// rows the caller sized the activation workspaces for (its largest minibatch)
+int64_t workspace_rows(const ga_update_args* a) {
+  if (!a->perm) return a->S;
+  if (a->n_mb > 0) return (a->S + a->n_mb - 1) / a->n_mb;
+  return a->mb < a->S ? a->mb : a->S;
+}
+
+// ids [start, start + M) of the pass's permutation form minibatch k
+void minibatch_range(const ga_update_args* a, int64_t k, int64_t* start, int64_t* M) {
+  if (a->perm && a->n_mb > 0) {  // even split: a common count on every rank
+    *start = k * a->S / a->n_mb;
+    *M = (k + 1) * a->S / a->n_mb - *start;
+    return;
+  }
   const int64_t mb = a->perm ? a->mb : a->S;
-  const int64_t n_mb = n_minibatches(a);
+  *start = k * mb;
+  *M = (*start + mb <= a->S) ? mb : a->S - *start;
+}
+
+int run_minibatch(const ga_update_args* a, int64_t k, ga_stream_t stream,
+                  const ArOrder* order = nullptr) {
+  int64_t start, M;
+  minibatch_range(a, k, &start, &M);
   const int L = a->desc->n_layers;
   const int out_w = a->desc->dims[L];
-  const int64_t M = (k == n_mb - 1) ? (a->S - k * mb) : mb;
-  const int32_t* idx = a->perm ? a->perm + k * mb : nullptr;
+  const int32_t* idx = a->perm ? a->perm + start : nullptr;
   const int64_t splits = ga_mlp_backward_splits(a->desc, M);
   if (splits > a->max_splits) {
     ga_set_error("ga_update_epoch: slab workspace too small");
@@ -98,7 +146,7 @@ int run_minibatch(const ga_update_args* a, int64_t k, ga_stream_t stream) {
   // they hold min(S, mb) x 2H floats each, enough from 32 rows up)
   if (g_small_step && !g_fuse_head && !a->comm && a->kind >= 0 && a->kind <= 2 &&
       (a->algo == 0 || a->algo == 1) && a->acts && a->dacts &&
-      (a->perm ? a->mb : a->S) >= 32 &&
+      workspace_rows(a) >= 32 &&
       ga_small_step_supported(L, a->desc->dims, M)) {
     ga_small_step_args s;
     memset(&s, 0, sizeof(s));
@@ -178,8 +226,10 @@ int run_minibatch(const ga_update_args* a, int64_t k, ga_stream_t stream) {
   }
   // data parallel: the global gradient is the sample-count weighted sum of the
   // rank gradients (mean over the union of the shards)
-  rc = ga_reduce_slabs_f32(a->slabs, splits, a->n_flat, a->n_flat, a->grad_scale,
-                           a->grads, stream);
+  const float scale = (a->grad_scales_host && a->perm && a->n_mb > 0)
+                          ? a->grad_scales_host[k] : a->grad_scale;
+  rc = ga_reduce_slabs_f32(a->slabs, splits, a->n_flat, a->n_flat, scale, a->grads,
+                           stream);
   if (rc) return rc;
   if (!a->learn_std) {
     if (hipMemsetAsync(a->grads, 0, sizeof(float), (hipStream_t)stream) !=
@@ -192,9 +242,19 @@ int run_minibatch(const ga_update_args* a, int64_t k, ga_stream_t stream) {
     ga_set_error("ga_update_epoch: no all-reduce hook installed");
     return -1;
   }
+  if (order && order->wait_for &&
+      hipStreamWaitEvent((hipStream_t)stream, order->wait_for, 0) != hipSuccess) {
+    ga_set_error("ga_update_epoch: hipStreamWaitEvent failed");
+    return -2;
+  }
   rc = g_allreduce(a->comm, a->grads, a->n_flat, stream);
   if (rc) {
     ga_set_error("ga_update_epoch: all-reduce failed (%d)", rc);
+    return -2;
+  }
+  if (order && order->record &&
+      hipEventRecord(order->record, (hipStream_t)stream) != hipSuccess) {
+    ga_set_error("ga_update_epoch: hipEventRecord failed");
     return -2;
   }
   return ga_adam_step_f32(a->params, a->grads, a->exp_avg, a->exp_avg_sq, a->n_flat,
@@ -227,13 +287,22 @@ extern "C" int ga_update_epoch_pair(const ga_update_args* a, ga_stream_t stream_
     return -1;
   }
   const int64_t na = n_minibatches(a), nb = n_minibatches(b);
+  ArOrder oa, ob;
+  if (g_ordered_allreduce && a->comm && b->comm) {
+    if (!ar_events_ready()) {
+      ga_set_error("ga_update_epoch_pair: cannot create events");
+      return -2;
+    }
+    oa.wait_for = g_ar_events[1]; oa.record = g_ar_events[0];
+    ob.wait_for = g_ar_events[0]; ob.record = g_ar_events[1];
+  }
   for (int64_t k = 0; k < (na > nb ? na : nb); ++k) {
     if (k < na) {
-      rc = run_minibatch(a, k, stream_a);
+      rc = run_minibatch(a, k, stream_a, &oa);
       if (rc) return rc;
     }
     if (k < nb) {
-      rc = run_minibatch(b, k, stream_b);
+      rc = run_minibatch(b, k, stream_b, &ob);
       if (rc) return rc;
     }
   }

@@ -78,7 +78,14 @@ def init_from_env(backend=None):
 class NativeComm:
     """RCCL communicator owned by ``libgarage_amd`` (``ga_comm_*``), so the C++
     epoch loop can all-reduce gradients without returning to Python.  The
-    128-byte unique id is created on rank 0 and broadcast with torch."""
+    128-byte unique id is created on rank 0 and broadcast with torch.
+
+    Construction is collective and so is its failure: after each step that can
+    fail locally (creating the id on rank 0, ``ncclCommInitRank`` on every rank)
+    the ranks all-reduce an ok flag, so either every rank holds a communicator
+    or every rank raises -- no rank is left waiting in a broadcast its peer
+    never enters.
+    """
 
     def __init__(self, comm):
         import ctypes as C
@@ -86,17 +93,36 @@ class NativeComm:
         from garage_amd import _lib
         lib = _lib.load()
         raw = (C.c_ubyte * 128)()
-        if comm.rank == 0:
-            if lib.ga_comm_unique_id(raw) != 0:
-                raise RuntimeError(lib.ga_last_error().decode())
+        # ncclCommInitRank is itself collective: a rank that cannot even load
+        # librccl must be known before anybody enters it
+        self._agree(comm, bool(lib.ga_comm_available()), 'loading librccl')
+        err = ''
+        if comm.rank == 0 and lib.ga_comm_unique_id(raw) != 0:
+            err = lib.ga_last_error().decode()
+        self._agree(comm, not err, 'ga_comm_unique_id: ' + err)
         t = torch.tensor(list(raw), dtype=torch.uint8, device='cuda')
         comm.broadcast(t, src=0)
         raw = (C.c_ubyte * 128)(*t.cpu().tolist())
         self.handle = lib.ga_comm_init_rank(raw, comm.rank, comm.world_size)
-        if not self.handle:
-            raise RuntimeError(lib.ga_last_error().decode())
+        err = '' if self.handle else lib.ga_last_error().decode()
+        try:
+            self._agree(comm, bool(self.handle), 'ga_comm_init_rank: ' + err)
+        except RuntimeError:
+            if self.handle:
+                lib.ga_comm_destroy(self.handle)
+                self.handle = None
+            raise
         self.world_size = comm.world_size
         self.rank = comm.rank
+        self.rccl_ranks = int(lib.ga_comm_count(self.handle))
+
+    @staticmethod
+    def _agree(comm, ok, what):
+        flag = torch.tensor([1.0 if ok else 0.0], device='cuda')
+        comm.all_reduce(flag, 'min')
+        if float(flag.item()) < 1.0:
+            raise RuntimeError('native RCCL communicator: a rank failed in ' +
+                               what)
 
 
 def combine_moments(stats, comm):
@@ -132,17 +158,32 @@ def shard_algo(algo, comm):
         # the two passes run on two streams and a communicator's collectives
         # must be issued in one order on every rank
         opt.native_comm = None
-        if use_rccl:
+        if use_rccl and os.environ.get('GARAGE_AMD_NATIVE_COMM', '1') != '0':
             try:
                 opt.native_comm = NativeComm(comm)
-            except Exception as exc:  # pragma: no cover - needs >1 GPU
+            except RuntimeError as exc:  # pragma: no cover - needs >1 GPU
                 # fall back to the Python-driven minibatch loop, which
                 # all-reduces through torch.distributed (same results, more
-                # host overhead); every rank takes the same branch because
-                # ncclCommInitRank fails or succeeds collectively
+                # host overhead); NativeComm raises on every rank or on none
                 import warnings
                 warnings.warn('native RCCL communicator unavailable ({}); '
                               'using torch.distributed for the gradient '
                               'all-reduce'.format(exc))
     algo._old_policy.sync(algo.policy)
     return algo
+
+
+def gradient_exchange(algo):
+    """How ``algo``'s optimizer steps exchange gradients, for run records:
+    ``(description, rccl_ranks)``; ``rccl_ranks`` is what RCCL itself reports
+    for the library-owned communicators (``None`` without them)."""
+    if getattr(algo, '_comm', None) is None:
+        return 'none (one process)', None
+    opts = (algo._policy_optimizer, algo._vf_optimizer)
+    native = [getattr(o, 'native_comm', None) for o in opts]
+    if all(n is not None for n in native):
+        return ('rccl all-reduce inside the C++ epoch loop (one library-owned '
+                'communicator per network)', min(n.rccl_ranks for n in native))
+    backend = dist.get_backend(algo._comm.group)
+    return ('torch.distributed all-reduce ({}) from the Python minibatch loop'
+            ' (FALLBACK: no native communicator)'.format(backend), None)

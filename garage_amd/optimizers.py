@@ -58,6 +58,28 @@ def _parse_optimizer(optimizer):
                 eps=kwargs.get('eps', 1e-8))
 
 
+def data_parallel_plan(counts, minibatch_size, rank):
+    """Minibatch plan of one pass when rank ``r`` holds ``counts[r]`` samples.
+
+    Every rank must take the same number of optimizer steps (each issues one
+    gradient all-reduce), whatever its own count: ``K = ceil(max(counts) /
+    minibatch_size)`` minibatches per pass, rank ``r``'s minibatch ``k`` = ids
+    ``[k * counts[r] // K, (k + 1) * counts[r] // K)`` of its permutation.
+    Global minibatch ``k`` is the union of the ranks' ``k``-th minibatches
+    (SURVEY.md section 8e), so its mean gradient weights rank ``r`` by
+    ``rows_r,k / sum_r rows_r,k``.  Returns ``(K, scales[K] float32)`` for
+    ``rank``; raises if some rank could not fill ``K`` minibatches.
+    """
+    counts = [int(c) for c in counts]
+    K = -(-max(counts) // int(minibatch_size))
+    if min(counts) < K:
+        raise RuntimeError('a rank holds fewer samples than there are '
+                           'minibatches per pass')
+    sizes = np.asarray([[(k + 1) * c // K - k * c // K for k in range(K)]
+                        for c in counts], dtype=np.float64)
+    return K, (sizes[rank] / sizes.sum(axis=0)).astype(np.float32)
+
+
 class OptimizerWrapper:
     """Adam over one module's flat parameter buffer + minibatch iteration.
 
@@ -92,6 +114,10 @@ class OptimizerWrapper:
         # and this rank's share of the global sample count
         self.dp_minibatches = None
         self.dp_grad_scale = 1.0
+        # per-minibatch shares (rows of this rank's minibatch k / rows of the
+        # global minibatch k); None: dp_grad_scale for every step
+        self.dp_grad_scales = None
+        self._cur_grad_scale = None
 
     def __getstate__(self):
         state = self.__dict__.copy()
@@ -137,18 +163,36 @@ class OptimizerWrapper:
         Same number, sizes and -- in ``'numpy'`` mode -- contents as the
         minibatches ``get_minibatch`` of the reference yields for ``n`` rows.
         """
-        mb = self.local_minibatch_size(n)
+        bounds = self.minibatch_bounds(n)
         for perm in self.epoch_permutations(n):
+            self._cur_grad_scale = None
             if perm is None:
                 yield None
                 continue
-            for k in range(-(-n // mb)):
-                yield perm[k * mb:(k + 1) * mb]
+            for k in range(len(bounds) - 1):
+                if self.dp_grad_scales is not None:
+                    self._cur_grad_scale = float(self.dp_grad_scales[k])
+                yield perm[bounds[k]:bounds[k + 1]]
+
+    def minibatch_bounds(self, n):
+        """``b`` with minibatch ``k`` = ids ``[b[k], b[k+1])`` of a pass over
+        ``n`` rows.  Single process: ``BatchDataset``'s ``ceil(n / mb)``
+        minibatches of ``mb`` ids, the last one partial.  Data parallel: ranks
+        hold different ``n`` but must take the same number of optimizer steps
+        (one gradient all-reduce each), so the ids are split into exactly
+        ``dp_minibatches`` parts at ``k * n // dp_minibatches``."""
+        if self._minibatch_size is None:
+            return [0, int(n)]
+        if self.dp_minibatches:
+            K = int(self.dp_minibatches)
+            return [k * int(n) // K for k in range(K + 1)]
+        mb = int(self._minibatch_size)
+        return list(range(0, int(n), mb)) + [int(n)]
 
     def local_minibatch_size(self, n):
-        """Rows per minibatch on this rank.  Single process: ``minibatch_size``.
-        Data parallel: every rank must run the same number of minibatches, so
-        the local size is ``ceil(n / dp_minibatches)``."""
+        """Rows of the largest minibatch on this rank (workspace sizing).
+        Single process: ``minibatch_size``; data parallel:
+        ``ceil(n / dp_minibatches)`` (see :meth:`minibatch_bounds`)."""
         if self._minibatch_size is None:
             return None
         if self.dp_minibatches:
@@ -173,8 +217,11 @@ class OptimizerWrapper:
         if self._hyper['kind'] != 'adam':
             raise NotImplementedError(
                 'the conjugate-gradient step is driven by garage_amd.algos.TRPO')
-        self.net.reduce_grads(scale=self.dp_grad_scale
-                              if self.grad_hook is not None else 1.0)
+        scale = 1.0
+        if self.grad_hook is not None:
+            scale = (self.dp_grad_scale if self._cur_grad_scale is None
+                     else self._cur_grad_scale)
+        self.net.reduce_grads(scale=scale)
         if not getattr(self._module, '_learn_std', True):
             self.net.grads[0:1].zero_()
         if self.grad_hook is not None:

@@ -29,7 +29,7 @@ extern "C" {
 
 typedef void* ga_stream_t; /* hipStream_t */
 
-int ga_abi_version(void);
+int ga_abi_version(void); /* 2 */
 const char* ga_last_error(void);
 
 /* ---- returns + GAE(lambda) -------------------------------------------------
@@ -435,6 +435,15 @@ typedef struct {
   int32_t double_softmax;    /* kind 2 */
   float grad_scale;          /* with comm: this rank's share S_local / S_global of the
                                 minibatch, applied before the all-reduce(sum) */
+  int64_t n_mb;              /* > 0 (with perm): the S ids of the pass are split into
+                                exactly n_mb minibatches, minibatch k = ids
+                                [k*S/n_mb, (k+1)*S/n_mb) -- data parallel ranks hold
+                                different S but must issue the same number of
+                                all-reduces; 0: ceil(S/mb) minibatches of mb ids,
+                                the last one partial (BatchDataset) */
+  const float* grad_scales_host; /* optional HOST array [n_mb]: per-minibatch
+                                replacement of grad_scale (rows of this rank's
+                                minibatch k / rows of the global minibatch k) */
 } ga_update_args;
 int ga_update_epoch(const ga_update_args* args, ga_stream_t stream);
 /* The policy pass and the value-function pass of one epoch, minibatch by
@@ -455,10 +464,20 @@ int ga_update_epoch_pair(const ga_update_args* a, ga_stream_t stream_a,
  * standing in for the second rank) installs its own. */
 typedef int (*ga_allreduce_fn)(void* comm, float* buf, int64_t n, void* stream);
 void ga_set_allreduce_hook(ga_allreduce_fn fn);
+int ga_comm_available(void); /* 1 if librccl could be loaded in this process */
 int ga_comm_unique_id(void* id128_host);
 void* ga_comm_init_rank(const void* id128_host, int rank, int world);
 int ga_comm_allreduce_sum_f32(void* comm, float* buf, int64_t n, ga_stream_t stream);
+/* ranks of the communicator as RCCL reports them (ncclCommCount); < 0 on error */
+int ga_comm_count(void* comm);
 int ga_comm_destroy(void* comm);
+/* ga_update_epoch_pair with communicators: the two networks' all-reduces sit on two
+ * streams and two communicators.  1 (default): every all-reduce waits (HIP event)
+ * for the previously enqueued one of the OTHER network, so each GPU executes them
+ * in the host's issue order, identical on every rank -- no rank can sit in network
+ * A's collective while its peer sits in network B's.  0: no such edges (the two
+ * collectives may run concurrently; they are small enough to co-reside). */
+int ga_set_ordered_allreduce(int on);
 
 /* ---- measurement ----------------------------------------------------------
  * Optional HIP-event timing of every GEMM / scan launch on its own stream

@@ -143,10 +143,13 @@ class OraclePPO:
         new = self._dist(self.policy, obs)
         return torch.distributions.kl.kl_divergence(old, new).mean()
 
-    def _update_policy(self, obs_flat, actions_flat, adv_flat, used):
+    def _update_policy(self, obs_flat, actions_flat, adv_flat, used,
+                       stream=None):
         """``vpg.py:244-245`` + ``_train_policy`` (``:250-272``)."""
         S = obs_flat.shape[0]
-        for ids in minibatch_index_stream(S, self.mb, self.epochs):
+        if stream is None:
+            stream = minibatch_index_stream(S, self.mb, self.epochs)
+        for ids in stream:
             sel = slice(None) if ids is None else ids
             self.policy_opt.zero_grad()
             loss = self._policy_loss(obs_flat[sel], actions_flat[sel],
@@ -157,12 +160,16 @@ class OraclePPO:
                 used.append(ids)
 
     # -- one iteration -----------------------------------------------------
-    def train_once(self, batch, record_minibatches=False):
+    def train_once(self, batch, record_minibatches=False,
+                   minibatch_ids=None):
         """``VPG._train_once`` on an :class:`oracle.batch.OracleEpisodeBatch`.
 
         Returns a dict with the 9 logged scalars (``vpg.py:186-199``), the
         intermediate tensors the parity tests compare, and (optionally) the
         minibatch id arrays in the order they were consumed.
+        ``minibatch_ids = {'policy': [ids, ...], 'vf': [ids, ...]}`` replaces
+        the ``BatchDataset`` streams by explicit id arrays (SURVEY.md section
+        8e: the data-parallel tests feed the union of the ranks' minibatches).
         """
         obs = torch.Tensor(batch.padded_observations)
         rewards = torch.Tensor(batch.padded_rewards)
@@ -188,8 +195,11 @@ class OraclePPO:
         used = {'policy': [], 'vf': []}
         # vpg.py:244-248 -- policy first, all epochs; then the value function.
         self._update_policy(obs_flat, actions_flat, adv_flat,
-                            used['policy'] if record_minibatches else None)
-        for ids in minibatch_index_stream(S, self.mb, self.epochs):
+                            used['policy'] if record_minibatches else None,
+                            None if minibatch_ids is None
+                            else minibatch_ids['policy'])
+        for ids in (minibatch_index_stream(S, self.mb, self.epochs)
+                    if minibatch_ids is None else minibatch_ids['vf']):
             sel = slice(None) if ids is None else ids
             self.vf_opt.zero_grad()
             loss = nets.value_loss(self.value, obs_flat[sel],

@@ -42,3 +42,29 @@ def test_bench_line_has_the_contract_fields():
     assert c['kind'] == 'port' and c['value'] > 0
     g = line['roofline_gae_scan']
     assert g['bound'] == 'hbm' and g['unit'] == 'GB/s'
+    assert line['grad_allreduce'].startswith('none') and \
+        line['rccl_ranks'] is None
+
+
+@pytest.mark.timeout(900)
+def test_bench_gpus_2_starts_two_ranks_by_itself():
+    """The driver's one-line command for N > 1 without torchrun: the parent spawns
+    the ranks before touching the GPU and relays rank 0's line.  On a one-GPU box
+    the two ranks share the device and exchange over gloo (the RCCL path needs two
+    GPUs), which the line must say -- the fallback is never silent."""
+    env = {k: v for k, v in os.environ.items()
+           if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    env['GARAGE_AMD_BACKEND'] = 'gloo'
+    out = subprocess.run(
+        [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2',
+         '--config', 'c1', '--steps', '1', '--warmup', '1', '--cpu-envs', '0',
+         '--no-roofline'],
+        cwd=ROOT, env=env, capture_output=True, text=True, timeout=850)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['config']['parallelism'] == 'dp2'
+    assert 'FALLBACK' in line['grad_allreduce'] and 'gloo' in line['grad_allreduce']
+    assert line['rccl_ranks'] is None
+    assert line['value'] > 0

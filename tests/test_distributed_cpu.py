@@ -132,3 +132,25 @@ def test_gradient_average_two_ranks():
 @pytest.mark.timeout(180)
 def test_broadcast_and_barrier_two_ranks():
     _run(_broadcast)
+
+
+@pytest.mark.timeout(240)
+def test_bench_starts_its_own_ranks_and_fails_loudly_without_a_gpu():
+    """``python bench.py --gpus 2`` with no launcher around it starts two ranks
+    itself (torchrun-style environment, gloo here) -- and since the product has
+    no CPU fallback each rank dies in ``require_gpu``, which the parent must
+    report as a non-zero exit, not as an ``n_gpus: 1`` line."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'),
+                          '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                         cwd=root, env=env, capture_output=True, text=True,
+                         timeout=200)
+    assert out.returncode != 0
+    assert 'rank 0 exited with code' in out.stderr or \
+        'rank 1 exited with code' in out.stderr
+    assert 'no CPU fallback' in out.stderr
+    assert '"n_gpus"' not in out.stdout

@@ -25,8 +25,9 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _make_shard(rank):
+def _make_shard(rank, n_eps=N_EPS):
     rng = np.random.RandomState(100 + rank)
+    N_EPS = n_eps
     lens = rng.randint(3, P + 1, size=N_EPS)
     lens[0] = P
     S = int(lens.sum())
@@ -43,7 +44,7 @@ def _make_shard(rank):
 
 
 def _rank_main(rank, world, port, q, init_pol, init_vf, algo_name='ppo',
-               backend='gloo'):
+               backend='gloo', minibatch=None, n_eps=None):
     try:
         os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank),
                           WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
@@ -84,10 +85,12 @@ def _rank_main(rank, world, port, q, init_pol, init_vf, algo_name='ppo',
         else:
             algo = PPO(env_spec=spec, policy=pol, value_function=vf,
                        sampler=None,
-                       policy_optimizer=OptimizerWrapper(opt, pol, 3, None),
-                       vf_optimizer=OptimizerWrapper(opt, vf, 3, None))
+                       policy_optimizer=OptimizerWrapper(opt, pol, 3,
+                                                         minibatch),
+                       vf_optimizer=OptimizerWrapper(opt, vf, 3, minibatch))
         shard_algo(algo, comm)
-        d = _make_shard(rank)
+        d = _make_shard(rank, *([] if n_eps is None else [n_eps[rank]]))
+        np.random.seed(50 + rank)  # the rank's host permutation stream
         st = np.asarray([StepType(int(s)) for s in d['step_types']],
                         dtype=object)
         batch = EpisodeBatch(env_spec=spec, episode_infos={},
@@ -103,6 +106,7 @@ def _rank_main(rank, world, port, q, init_pol, init_vf, algo_name='ppo',
         out['native_comm'] = algo._policy_optimizer.native_comm is not None \
             and algo._vf_optimizer.native_comm is not None
         out['native_loop'] = bool(algo._native_update_ok())
+        out['adam_steps'] = (pol.net.adam_steps, vf.net.adam_steps)
         if algo_name == 'trpo':
             out['accepted'] = algo.last_cg['accepted']
         import torch.distributed as dist
@@ -161,6 +165,83 @@ def test_two_rank_ppo_equals_single_process_oracle():
                   'vf/LossBefore', 'vf/LossAfter'):
             assert np.isclose(got['tab'][k], want[k], atol=2e-5, rtol=2e-5), \
                 (rank, k, got['tab'][k], want[k])
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_minibatch_ppo_with_unequal_shards_equals_oracle():
+    """Ranks with different sample counts and the reference-default minibatch
+    of 64 (``ppo.py:65-76``): both ranks take the same number of optimizer steps
+    (``data_parallel_plan``: an even split into K minibatches per pass, one
+    all-reduce each), every step's gradient is the mean over the union of the
+    ranks' k-th minibatches, and the result equals the single-process oracle
+    fed those unions as explicit id arrays."""
+    from garage_amd.optimizers import data_parallel_plan
+    from oracle import batch as ob
+    from oracle import networks as nets
+    from oracle.ppo import OraclePPO
+    rng = np.random.RandomState(0)
+    init_pol = nets.init_gaussian_mlp(rng, nets.POLICY_PREFIX, O, A, (16, 16),
+                                      min_std=1e-6)
+    init_vf = nets.init_gaussian_mlp(rng, nets.VALUE_PREFIX, O, 1, (16, 16))
+    n_eps, mb, E = (41, 47), 64, 3
+    shards = [_make_shard(r, n_eps[r]) for r in range(2)]
+    counts = [int(s['lengths'].sum()) for s in shards]
+    K = data_parallel_plan(counts, mb, 0)[0]
+    # the case the old ceil(n / ceil(n / K)) rule got wrong on one rank
+    assert counts[0] != counts[1] and K >= 4
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_main,
+                         args=(r, 2, port, q, init_pol, init_vf, 'ppo', 'gloo',
+                               mb, n_eps))
+             for r in range(2)]
+    for p in procs:
+        p.start()
+    results = {}
+    for _ in range(2):
+        rank, status, out = q.get(timeout=240)
+        assert status == 'ok', status
+        results[rank] = out
+    for p in procs:
+        p.join(30)
+    for rank in (0, 1):
+        assert results[rank]['adam_steps'] == (E * K, E * K)
+
+    # the union of the ranks' k-th minibatches as ids of the concatenated batch
+    ids = {'policy': [[] for _ in range(E * K)], 'vf': [[] for _ in range(E * K)]}
+    base = 0
+    for r, n in enumerate(counts):
+        np.random.seed(50 + r)
+        for which in ('policy', 'vf'):  # SURVEY.md Q8: policy draws first
+            perm = np.arange(n)
+            np.random.shuffle(perm)
+            for e in range(E):
+                for k in range(K):
+                    ids[which][e * K + k].append(
+                        base + perm[k * n // K:(k + 1) * n // K])
+                np.random.shuffle(perm)
+        base += n
+    ids = {w: [np.concatenate(parts) for parts in v] for w, v in ids.items()}
+    cat = {k: np.concatenate([s[k] for s in shards]) for k in shards[0]}
+    batch = ob.OracleEpisodeBatch(max_episode_length=P, **cat)
+    oracle = OraclePPO(init_pol, init_vf, max_episode_length=P,
+                       max_optimization_epochs=E, minibatch_size=mb,
+                       policy_lr=1e-3, vf_lr=1e-3)
+    want = oracle.train_once(batch, minibatch_ids=ids)
+    wp, wv = oracle.state()
+    for rank in (0, 1):
+        got = results[rank]
+        for k, v in wp.items():
+            assert np.allclose(got[k], v, atol=3e-6), (rank, k)
+        for k, v in wv.items():
+            assert np.allclose(got['vf:' + k], v, atol=3e-6), (rank, k)
+        for k in ('policy/LossBefore', 'policy/LossAfter', 'policy/KL',
+                  'vf/LossBefore', 'vf/LossAfter'):
+            assert np.isclose(got['tab'][k], want[k], atol=2e-5, rtol=2e-5), \
+                (rank, k, got['tab'][k], want[k])
+    for k in wp:  # replicas stay bit-identical
+        assert np.array_equal(results[0][k], results[1][k]), k
 
 
 class _TwinComm:

@@ -208,6 +208,48 @@ def test_numpy_minibatch_stream_equals_batchdataset_semantics():
         assert np.array_equal(a, b)
 
 
+def test_data_parallel_ranks_take_the_same_number_of_optimizer_steps():
+    """one gradient all-reduce per optimizer step, so ranks
+    with different sample counts must still run the same number of minibatches
+    (ceil(n / ceil(n / K)) != K in general: 9900 and 9921 samples at the
+    reference-default minibatch of 64 gave 155 and 156 steps before)."""
+    import torch
+
+    from garage_amd.optimizers import OptimizerWrapper, data_parallel_plan
+    rng = np.random.RandomState(0)
+    pairs = [(9900, 9921), (10000, 10000), (64, 1), (65, 130)]
+    pairs += [tuple(rng.randint(9000, 11000, size=2)) for _ in range(200)]
+    pairs += [tuple(rng.randint(100, 400, size=3)) for _ in range(50)]
+    for counts in pairs:
+        if min(counts) < -(-max(counts) // 64):
+            with pytest.raises(RuntimeError, match='fewer samples'):
+                data_parallel_plan(counts, 64, 0)
+            continue
+        plans = [data_parallel_plan(counts, 64, r) for r in range(len(counts))]
+        K = plans[0][0]
+        assert all(p[0] == K for p in plans)
+        total = np.sum([p[1].astype(np.float64) for p in plans], axis=0)
+        assert np.allclose(total, 1.0, atol=1e-6)
+        sizes = []
+        for r, n in enumerate(counts):
+            opt = OptimizerWrapper(torch.optim.Adam, None, 2, 64)
+            opt.dp_minibatches, opt.dp_grad_scales = plans[r]
+            b = opt.minibatch_bounds(n)
+            assert len(b) == K + 1 and b[0] == 0 and b[-1] == n
+            assert all(b[k + 1] > b[k] for k in range(K))
+            assert opt.local_minibatch_size(n) == max(np.diff(b))
+            sizes.append(np.diff(b))
+        sizes = np.asarray(sizes, dtype=np.float64)
+        for r in range(len(counts)):
+            assert np.allclose(plans[r][1], sizes[r] / sizes.sum(axis=0),
+                               atol=1e-7)
+    # single process: BatchDataset's minibatches, the last one partial
+    opt = OptimizerWrapper(torch.optim.Adam, None, 1, 5)
+    assert opt.minibatch_bounds(23) == [0, 5, 10, 15, 20, 23]
+    assert opt.minibatch_bounds(20) == [0, 5, 10, 15, 20]
+    assert OptimizerWrapper(torch.optim.Adam, None).minibatch_bounds(7) == [0, 7]
+
+
 def test_step_types_as_uint8_fast_and_fallback_paths():
     """Object arrays of the enum singletons (what garage's EpisodeBatch holds),
     integer arrays, mixed objects (plain ints among the members) and empties."""
