@@ -13,11 +13,11 @@ FLAGS := --offload-arch=$(ARCH) -O3 -fPIC -std=c++17 -Wall -Wno-unused-function
 
 all: $(OUT)/libgarage_amd.so
 
-$(OUT)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/prof.h
+$(OUT)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/prof.h $(CSRC)/small_step.h
 	@mkdir -p $(OUT)
 	$(HIPCC) $(FLAGS) -c $< -o $@
 
-$(OUT)/%.o: $(CSRC)/%.cpp $(CSRC)/prof.h include/garage_amd.h
+$(OUT)/%.o: $(CSRC)/%.cpp $(CSRC)/prof.h $(CSRC)/small_step.h include/garage_amd.h
 	@mkdir -p $(OUT)
 	$(HIPCC) $(FLAGS) -x hip -c $< -o $@
 

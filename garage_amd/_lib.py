@@ -98,6 +98,8 @@ SIGNATURES = {
     'ga_set_fused_head_forward': (c_int, [c_int]),
     'ga_set_small_m_gemm': (c_int, [c_int]),
     'ga_set_small_step': (c_int, [c_int]),
+    'ga_set_small_step_resident_cap': (c_int, [c_int]),
+    'ga_set_small_step_max_polls': (c_int, [c_int]),
     'ga_small_step_launches': (c_i64, []),
     'ga_small_step_debug': (c_int, [ptr]),
     'ga_set_one_launch_losses': (c_int, [c_int]),

@@ -381,10 +381,20 @@ class VPG:
         pl_b, pl_a, vl_b, vl_a, kl_b, kl_a = scalars.cpu().tolist()
         # the one-launch small-minibatch step raises the last workspace slot if
         # one of its grid barriers ever gave up (its results are then garbage)
+        # (such a launch, and every later one, returns before any parameter is
+        # written: the networks hold the last complete optimizer step)
+        faulted = False
         for tag in (0, 1):
-            if float(reduction_workspace(dev, tag)[-1]) != 0.0:
-                raise RuntimeError('ga_small_step: a grid barrier timed out; '
-                                   'disable it with ga_set_small_step(0)')
+            ws = reduction_workspace(dev, tag)
+            if float(ws[-1]) != 0.0:
+                ws[-2:].zero_()  # re-arm the barrier words for the next call
+                faulted = True
+        if faulted:
+            raise RuntimeError(
+                'ga_small_step: a grid barrier timed out; the optimizer steps '
+                'from that point on were skipped (parameters are those of the '
+                'last complete step). Disable the one-launch step with '
+                'ga_set_small_step(0).')
         tab = logger.tabular
         with tab.prefix(self.policy.name):
             tab.record('/LossBefore', pl_b)

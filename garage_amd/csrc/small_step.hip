@@ -27,6 +27,7 @@
 // per-layer path.  Same formulas as losses.hip / gemm.hip; sums are taken in a
 // different order, so results agree to rounding, not bit for bit.
 #include "common.h"
+#include "small_step.h"
 
 namespace {
 
@@ -62,7 +63,8 @@ struct SmallStepParams {
   // (zero between launches)
   float* xh2; float* xdz; unsigned* bar;
   float* loss_out;
-  int* fault;  // set when a barrier gave up
+  int* fault;  // set when a barrier gave up (the launch then wrote no parameter)
+  int max_polls;
   long long* dbg;  // optional: cycle counter of workgroup 0 at the phase boundaries
 };
 
@@ -109,33 +111,49 @@ __device__ __forceinline__ void ss_adam_n(const SmallStepParams& a, const float 
   }
 }
 
-// Sense-reversing grid barrier on {count, flag}: the last arrival clears the count
-// and flips the flag.  Two barriers per launch (senses 1, 0) leave both words at 0.
-// A waiter gives up after ~2^22 polls (a grid that is not co-resident would never
-// arrive): it raises *fault and the launch finishes with garbage instead of hanging.
-__device__ __forceinline__ void ss_grid_barrier(const SmallStepParams& p, unsigned sense) {
+// Grid barrier on {count, phase}: the last arrival clears the count and moves the
+// phase word old_v -> new_v with a compare-and-swap; waiters poll until the word
+// leaves old_v.  Two barriers per launch (0 -> 1, 1 -> 0) leave both words at 0.
+// A waiter that runs out of polls (a grid that is not co-resident would never
+// arrive) tries old_v -> SS_ABORT with the same compare-and-swap, so ONE atomic
+// word decides for the whole grid whether a barrier was passed or the launch is
+// abandoned: whoever swaps first wins and every workgroup reads the same verdict.
+// An abandoned launch returns before any parameter or moment is written (all Adam
+// writes sit behind barrier 2), raises *fault and leaves the phase word at
+// SS_ABORT, which makes later launches return at their first barrier too: the
+// parameters stay those of the last complete step until the host has looked
+// (VPG._train_once checks the fault word and re-arms the barrier words).
+constexpr unsigned SS_ABORT = 2u;
+__device__ __forceinline__ bool ss_grid_barrier(const SmallStepParams& p, unsigned old_v,
+                                                unsigned new_v, int* verdict) {
   __syncthreads();
   if (threadIdx.x == 0) {
     __threadfence();
+    unsigned seen;
     const unsigned t = atomicAdd(p.bar, 1u);
     if (t == gridDim.x - 1) {
       __hip_atomic_store(p.bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __threadfence();
-      __hip_atomic_store(p.bar + 1, sense, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned prev = atomicCAS(p.bar + 1, old_v, new_v);
+      seen = prev == old_v ? new_v : prev;
     } else {
       int polls = 0;
-      while (__hip_atomic_load(p.bar + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) !=
-             sense) {
+      while ((seen = __hip_atomic_load(p.bar + 1, __ATOMIC_ACQUIRE,
+                                       __HIP_MEMORY_SCOPE_AGENT)) == old_v) {
         __builtin_amdgcn_s_sleep(2);
-        if (++polls > (1 << 22)) {
-          atomicExch(p.fault, 1);
+        if (++polls > p.max_polls) {
+          const unsigned prev = atomicCAS(p.bar + 1, old_v, SS_ABORT);
+          seen = prev == old_v ? SS_ABORT : prev;
           break;
         }
       }
     }
+    if (seen != new_v) atomicExch(p.fault, 1);
+    *verdict = seen == new_v;
   }
   __syncthreads();
   __threadfence();
+  return *verdict != 0;
 }
 
 typedef float ss_f32x16 __attribute__((ext_vector_type(16)));
@@ -193,6 +211,7 @@ __global__ __launch_bounds__(SS_THREADS) void small_step_kernel(SmallStepParams 
   __shared__ float bias_s[SS_HMAX + SS_COLS + 8];  // b1 (all), b2 (own), b_head
   __shared__ float whs[8 * SS_COLS];               // W_head[:, own] (0 beyond A)
   __shared__ float dlogstd_s;
+  __shared__ int verdict_s;
 
   SS_MARK(0);
   const int tid = threadIdx.x;
@@ -410,7 +429,7 @@ __global__ __launch_bounds__(SS_THREADS) void small_step_kernel(SmallStepParams 
     p.xh2[(int64_t)blockIdx.x * SS_ROWS * 8 + e] = sacc;
   }
   SS_MARK(3);
-  ss_grid_barrier(p, 1u);
+  if (!ss_grid_barrier(p, 0u, 1u, &verdict_s)) return;
   SS_MARK(4);
 
   // ---- B.1: head outputs (every workgroup): the workgroups' shares in workgroup
@@ -657,7 +676,7 @@ __global__ __launch_bounds__(SS_THREADS) void small_step_kernel(SmallStepParams 
   if (tid < SS_COLS)
     for (int rr = 0; rr < SS_ROWS; ++rr) g_b1 += dzown[rr * SS_LDO + tid];
   SS_MARK(7);
-  ss_grid_barrier(p, 0u);
+  if (!ss_grid_barrier(p, 1u, 0u, &verdict_s)) return;
   SS_MARK(8);
 
   // ---- C.1: all columns of dZ2 into LDS (over H1), then own columns of
@@ -770,28 +789,50 @@ __global__ __launch_bounds__(SS_THREADS) void small_step_kernel(SmallStepParams 
 // ---------------------------------------------------------------------------
 // host side (called by update.cpp; not part of the C ABI)
 // ---------------------------------------------------------------------------
-struct ga_small_step_args {
-  float* params; float* exp_avg; float* exp_avg_sq;
-  int64_t w_off[3], b_off[3];
-  int in_w, H, out_w, M;
-  const float* X; int64_t ldx; const int32_t* idx;
-  int kind; int double_softmax;
-  const float* actions; int64_t lda; const float* old_ll; const float* adv;
-  const float* returns;
-  int algo; float clip;
-  int has_min, has_max; float min_log_std, max_log_std;
-  float ent_coeff; int ent_flags;
-  int64_t step; double lr, beta1, beta2, eps;
-  int learn_std;
-  float* xh2; float* xdz;  // [64][H] floats each
-  unsigned* bar; float* loss_out; int* fault;
-};
-
 extern "C" int ga_small_step_supported(int n_layers, const int* dims, int64_t M) {
   if (n_layers != 3) return 0;
   const int in_w = dims[0], H = dims[1], out_w = dims[3];
   return dims[2] == H && H % 32 == 0 && H >= 32 && H <= SS_HMAX && in_w >= 1 &&
          in_w <= 32 && out_w >= 1 && out_w <= 8 && M >= 1 && M <= SS_ROWS;
+}
+
+// Residency: the grid barriers need all H / 16 workgroups of a launch (and of the
+// other chain's concurrent launch) on the device at once.  A plain launch of a
+// grid the device can hold becomes resident whatever else is queued (nothing that
+// runs waits for it), so the check is grid x concurrent <= CUs x the occupancy
+// query's workgroups per CU -- one per CU at 152 KB of LDS -- with the query's
+// known over-count of one (MI355X_MICROARCH.md, residency) taken off when it
+// reports more than one.  Shapes that fail it take the per-layer path.
+static int g_resident_cap = -1;  // workgroups the device holds; -1 = not asked yet
+static int g_resident_cap_forced = -1;
+extern "C" int ga_set_small_step_resident_cap(int workgroups) {
+  g_resident_cap_forced = workgroups;  // tests: 0 forces the per-layer path; < 0 = ask
+  return 0;
+}
+extern "C" int ga_small_step_resident(int H, int concurrent) {
+  if (g_resident_cap < 0) {
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) !=
+            hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, small_step_kernel,
+                                                     SS_THREADS, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      g_resident_cap = 0;
+    } else {
+      if (per_cu > 1) --per_cu;
+      g_resident_cap = cus * per_cu;
+    }
+  }
+  const int cap = g_resident_cap_forced >= 0 ? g_resident_cap_forced : g_resident_cap;
+  return (H / SS_COLS) * concurrent <= cap;
+}
+
+static int g_max_polls = 1 << 22;
+// tests: 0 makes every waiter give up at once, i.e. forces the abort path
+extern "C" int ga_set_small_step_max_polls(int polls) {
+  g_max_polls = polls < 0 ? (1 << 22) : polls;
+  return 0;
 }
 
 static int64_t g_launches = 0;
@@ -809,7 +850,8 @@ extern "C" int ga_small_step_debug(long long* host_out16) {
 }
 extern "C" int64_t ga_small_step_launches(void) { return g_launches; }
 
-extern "C" int ga_small_step(const ga_small_step_args* a, hipStream_t stream) {
+extern "C" int ga_small_step(const ga_small_step_args* a, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
   GA_REQUIRE(a && a->params && a->exp_avg && a->exp_avg_sq && a->X && a->xh2 && a->xdz &&
                  a->bar && a->loss_out && a->fault,
              "ga_small_step: null pointer");
@@ -845,6 +887,7 @@ extern "C" int ga_small_step(const ga_small_step_args* a, hipStream_t stream) {
   p.eps = (float)a->eps;
   p.learn_std = a->learn_std;
   p.dbg = g_dbg;
+  p.max_polls = g_max_polls;
   p.xh2 = a->xh2; p.xdz = a->xdz; p.bar = a->bar; p.loss_out = a->loss_out; p.fault = a->fault;
   hipLaunchKernelGGL(small_step_kernel, dim3((unsigned)(a->H / SS_COLS)),
                      dim3(SS_THREADS), 0, stream, p);

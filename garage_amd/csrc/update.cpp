@@ -16,6 +16,7 @@
 #include <string.h>
 
 #include "../../include/garage_amd.h"
+#include "small_step.h"
 
 void ga_set_error(const char* fmt, ...);
 
@@ -35,24 +36,6 @@ extern "C" int ga_set_fused_head_loss(int on) {
 }
 
 // small_step.hip: one launch per optimizer step for minibatches of <= 64 rows
-struct ga_small_step_args {
-  float* params; float* exp_avg; float* exp_avg_sq;
-  int64_t w_off[3], b_off[3];
-  int in_w, H, out_w, M;
-  const float* X; int64_t ldx; const int32_t* idx;
-  int kind; int double_softmax;
-  const float* actions; int64_t lda; const float* old_ll; const float* adv;
-  const float* returns;
-  int algo; float clip;
-  int has_min, has_max; float min_log_std, max_log_std;
-  float ent_coeff; int ent_flags;
-  int64_t step; double lr, beta1, beta2, eps;
-  int learn_std;
-  float* xh2; float* xdz;
-  unsigned* bar; float* loss_out; int* fault;
-};
-extern "C" int ga_small_step_supported(int n_layers, const int* dims, int64_t M);
-extern "C" int ga_small_step(const ga_small_step_args* a, ga_stream_t stream);
 extern "C" int64_t ga_reduction_partials_doubles(void);
 
 static int g_small_step = 1;
@@ -147,7 +130,8 @@ int run_minibatch(const ga_update_args* a, int64_t k, ga_stream_t stream,
   if (g_small_step && !g_fuse_head && !a->comm && a->kind >= 0 && a->kind <= 2 &&
       (a->algo == 0 || a->algo == 1) && a->acts && a->dacts &&
       workspace_rows(a) >= 32 &&
-      ga_small_step_supported(L, a->desc->dims, M)) {
+      ga_small_step_supported(L, a->desc->dims, M) &&
+      ga_small_step_resident(a->desc->dims[1], 2)) {
     ga_small_step_args s;
     memset(&s, 0, sizeof(s));
     s.params = a->params; s.exp_avg = a->exp_avg; s.exp_avg_sq = a->exp_avg_sq;

@@ -115,9 +115,19 @@ int ga_set_small_m_gemm(int on);
  * Adam -- in ONE launch of H / 16 workgroups with two grid barriers
  * (small_step.hip) instead of ten dependent launches.  Same formulas, other
  * summation orders: results agree to rounding.  The last slot of the reduction
- * workspace is raised when a barrier gave up (never seen; the step is then
- * garbage).  Default on; 0 = per-layer path. */
+ * workspace is raised when a barrier gave up (never seen); that launch and every
+ * later one then leave the parameters untouched.  Default on; 0 = per-layer
+ * path. */
 int ga_set_small_step(int on);
+/* Test hooks of that path.  resident_cap: workgroups the device is taken to hold
+ * at once (< 0: ask the occupancy query; 0 forces the per-layer path -- the
+ * fallback for shapes whose two concurrent grids would not be co-resident).
+ * max_polls: polls after which a waiter at a grid barrier abandons the launch
+ * (< 0: default 2^22; 0 forces the abort path).  An abandoned launch writes no
+ * parameter; the fault word stays raised and later launches return at once until
+ * the caller has cleared the last two workspace slots. */
+int ga_set_small_step_resident_cap(int workgroups);
+int ga_set_small_step_max_polls(int polls);
 int64_t ga_small_step_launches(void); /* launches so far (tests, diagnostics) */
 /* Developer hook (tools/small_step_phases.py): the first call arms the recording
  * and returns 1; later calls synchronise and copy 16 timestamps (100 MHz wall

@@ -255,3 +255,67 @@ def test_categorical_small_steps_vs_oracle_and_per_layer_path(kw):
         scale = float(out[0][i].abs().max())
         d = float((out[1][i] - out[0][i]).abs().max())
         assert scale > 1e-2 and d < 1e-4 * scale + 4e-5, (i, d, scale)
+
+
+def test_forced_fallback_takes_the_per_layer_path():
+    """Shapes whose two concurrent grids the device could not hold at once (the
+    grid barriers need every workgroup resident) take the per-layer launches:
+    forced here by telling the library the device holds no workgroup at all."""
+    from garage_amd import _lib
+    lib = _lib.load()
+    case = 'c3_default_minibatch'
+    spec, data, batch, P = _problem(case)
+    res = {}
+    try:
+        for cap in (-1, 0):
+            lib.ga_set_small_step_resident_cap(cap)
+            algo, pol, vf = _algo(case, spec)
+            n0 = int(lib.ga_small_step_launches())
+            np.random.seed(5)
+            algo._train_once(0, batch)
+            torch.cuda.synchronize()
+            launches = int(lib.ga_small_step_launches()) - n0
+            assert (launches > 0) == (cap < 0)
+            res[cap] = (pol.net.params.clone(), vf.net.params.clone())
+    finally:
+        lib.ga_set_small_step_resident_cap(-1)
+    lib.ga_set_small_step(0)
+    try:
+        algo, pol, vf = _algo(case, spec)
+        np.random.seed(5)
+        algo._train_once(0, batch)
+    finally:
+        lib.ga_set_small_step(1)
+    # the fallback IS the per-layer path: same bits
+    assert torch.equal(res[0][0], pol.net.params)
+    assert torch.equal(res[0][1], vf.net.params)
+    for i in (0, 1):
+        d = (res[-1][i] - res[0][i]).abs()
+        assert float(d.max()) < 5e-4 and float(d.mean()) < 2e-7
+
+
+def test_a_barrier_that_gives_up_leaves_the_parameters_untouched():
+    """``max_polls = 0``: the first workgroup to wait at a grid barrier abandons
+    the launch (one compare-and-swap decides for the whole grid).  Nothing may be
+    written to parameters or moments by that launch or by the later ones of the
+    iteration, ``_train_once`` must raise, and the next iteration must work."""
+    from garage_amd import _lib
+    lib = _lib.load()
+    case = 'c3_default_minibatch'
+    spec, data, batch, P = _problem(case)
+    algo, pol, vf = _algo(case, spec)
+    before = [t.clone() for net in (pol.net, vf.net)
+              for t in (net.params, net.exp_avg, net.exp_avg_sq)]
+    lib.ga_set_small_step_max_polls(0)
+    try:
+        np.random.seed(5)
+        with pytest.raises(RuntimeError, match='grid barrier timed out'):
+            algo._train_once(0, batch)
+    finally:
+        lib.ga_set_small_step_max_polls(-1)
+    after = [t for net in (pol.net, vf.net)
+             for t in (net.params, net.exp_avg, net.exp_avg_sq)]
+    for a, b in zip(before, after):
+        assert torch.equal(a, b)
+    # re-armed: a fresh pair of networks trains as usual afterwards
+    test_small_minibatch_steps_match_oracle_and_per_layer_path(case)
