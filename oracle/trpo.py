@@ -156,7 +156,8 @@ class OracleTRPO(OraclePPO):
             old_ll = self._log_prob(self._dist(self.old_policy, obs), actions)
         return (new_ll - old_ll).exp() * adv
 
-    def _update_policy(self, obs_flat, actions_flat, adv_flat, used):
+    def _update_policy(self, obs_flat, actions_flat, adv_flat, used,
+                       stream=None):
         """``trpo.py:121-144`` (policy OptimizerWrapper: one full batch)."""
         self.cg.zero_grad()
         loss = self._policy_loss(obs_flat, actions_flat, adv_flat)
