@@ -27,7 +27,74 @@ import time
 
 import numpy as np
 
-torch = None  # imported in main(), after the self-launch decision
+
+def self_launch(n):
+    """Run this command as ``n`` ranks (one child process per GPU) and relay
+    rank 0's output.  The parent never initialises the GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r),
+                   WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        procs.append(subprocess.Popen(
+            [sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+            env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    rc = 0
+    try:
+        pending = set(range(n))
+        while pending and rc == 0:
+            time.sleep(0.2)
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0:
+                    print('bench.py: rank {} exited with code {}'.format(
+                        r, code), file=sys.stderr)
+                    rc = code if code > 0 else 1
+    finally:
+        for p in procs:  # a failed rank leaves its peers in a collective
+            if p.poll() is None:
+                if rc == 0:
+                    p.wait()
+                else:
+                    p.terminate()
+        out = procs[0].stdout.read().decode()
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    p.wait(10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    return rc
+
+
+
+def _requested_gpus(argv):
+    for i, arg in enumerate(argv):
+        if arg == '--gpus' and i + 1 < len(argv):
+            return int(argv[i + 1])
+        if arg.startswith('--gpus='):
+            return int(arg.split('=', 1)[1])
+    return 1
+
+
+if __name__ == '__main__' and 'WORLD_SIZE' not in os.environ \
+        and _requested_gpus(sys.argv[1:]) > 1:
+    # no launcher around us: become the launcher BEFORE torch (or anything that
+    # could initialise the GPU) is imported into this process
+    sys.exit(self_launch(_requested_gpus(sys.argv[1:])))
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -251,56 +318,6 @@ def cpu_baseline(cfg, n_envs, seed=1):
                     os.cpu_count()))
 
 
-def self_launch(n):
-    """Run this command as ``n`` ranks (one child process per GPU) and relay
-    rank 0's output.  The parent never initialises the GPU."""
-    import socket
-    import subprocess
-    with socket.socket() as sock:
-        sock.bind(('127.0.0.1', 0))
-        port = sock.getsockname()[1]
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r),
-                   WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
-        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        procs.append(subprocess.Popen(
-            [sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
-            env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr))
-    rc = 0
-    try:
-        pending = set(range(n))
-        while pending and rc == 0:
-            time.sleep(0.2)
-            for r in sorted(pending):
-                code = procs[r].poll()
-                if code is None:
-                    continue
-                pending.discard(r)
-                if code != 0:
-                    print('bench.py: rank {} exited with code {}'.format(
-                        r, code), file=sys.stderr)
-                    rc = code if code > 0 else 1
-    finally:
-        for p in procs:  # a failed rank leaves its peers in a collective
-            if p.poll() is None:
-                if rc == 0:
-                    p.wait()
-                else:
-                    p.terminate()
-        out = procs[0].stdout.read().decode()
-        for p in procs:
-            if p.poll() is None:
-                try:
-                    p.wait(10)
-                except subprocess.TimeoutExpired:
-                    p.kill()
-    sys.stdout.write(out)
-    sys.stdout.flush()
-    return rc
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -333,11 +350,6 @@ def main():
                     help='run the policy and value-function passes one after '
                     'the other on one stream (isolated per-kernel timings)')
     args = ap.parse_args()
-
-    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
-        sys.exit(self_launch(args.gpus))
-    global torch
-    import torch
 
     from garage_amd.distributed import gradient_exchange, init_from_env
     comm = init_from_env()

@@ -54,7 +54,8 @@ def _build(cfg, n_envs, E, mb, seed=3, lr=2.5e-4):
     return algo, sampler, pol, vf
 
 
-def _oracle_iterations(cfg, n_envs, E, mb, iterations, atol_params):
+def _oracle_iterations(cfg, n_envs, E, mb, iterations, atol_params,
+                       linear_adam=False):
     import bench
     from oracle import batch as ob
     from oracle.ppo import OraclePPO
@@ -65,6 +66,14 @@ def _oracle_iterations(cfg, n_envs, E, mb, iterations, atol_params):
         pol.state_dict(), vf.state_dict(), max_episode_length=T,
         policy_kind='categorical' if cfg.get('discrete') else 'gaussian',
         max_optimization_epochs=E, minibatch_size=mb)
+    if linear_adam:
+        # Adam with beta1 = beta2 = 0, eps = 1 moves a parameter by
+        # -lr g / (|g| + 1): linear in small gradients, so the parameters expose
+        # the gradients themselves instead of their signs
+        for o in (algo._policy_optimizer, algo._vf_optimizer):
+            o._hyper.update(betas=(0.0, 0.0), eps=1.0, lr=1e-2)
+        for o in (oracle.policy_opt, oracle.vf_opt):
+            o.param_groups[0].update(betas=(0.0, 0.0), eps=1.0, lr=1e-2)
     for it in range(iterations):
         eps = sampler.obtain_samples(it, n_envs * T, None)
         host = ob.OracleEpisodeBatch(
@@ -84,10 +93,21 @@ def _oracle_iterations(cfg, n_envs, E, mb, iterations, atol_params):
             assert np.isclose(algo.last_tabular[k], want[k], atol=1e-5,
                               rtol=1e-5), (k, it, algo.last_tabular[k], want[k])
         wp, wv = oracle.state()
-        for k, v in pol.state_dict().items():
-            assert np.allclose(v.numpy(), wp[k], atol=atol_params), (k, it)
-        for k, v in vf.state_dict().items():
-            assert np.allclose(v.numpy(), wv[k], atol=atol_params), (k, it)
+        if linear_adam:
+            for state, ref in ((pol.state_dict(), wp), (vf.state_dict(), wv)):
+                for k, v in state.items():
+                    d = np.abs(v.numpy() - np.asarray(ref[k]))
+                    assert d.max() <= atol_params, (k, it, d.max())
+            continue
+        # Adam moves a parameter by lr m / (sqrt(v) + 1e-8): where a gradient is
+        # itself ~1e-8 its last bits (summation order) decide a sizeable part of
+        # lr, so single elements of wide layers sit further apart than the bulk;
+        # the bulk is held to 1/10 of the bound
+        for state, ref in ((pol.state_dict(), wp), (vf.state_dict(), wv)):
+            for k, v in state.items():
+                d = np.abs(v.numpy() - np.asarray(ref[k]))
+                assert d.max() <= atol_params, (k, it, d.max(), d.mean())
+                assert d.mean() <= 0.1 * atol_params, (k, it, d.max(), d.mean())
     return eps
 
 
@@ -117,9 +137,18 @@ def test_c5_shape_iteration_matches_oracle():
     40 envs -> >= 10240 samples, minibatches of 2560 rows (128x128 tiles with
     ragged last tiles), two iterations against the oracle."""
     eps = _oracle_iterations('c5', n_envs=40, E=2, mb=2560, iterations=2,
-                             atol_params=2e-6)
+                             atol_params=1e-4)
     lens = np.asarray(eps.lengths)
     assert lens.min() >= 32 and lens.max() <= 256 and len(set(lens)) > 10
+
+
+def test_c5_shape_gradients_match_oracle():
+    """The same iteration with the linear-regime Adam: every parameter of the
+    three 512-wide layers within 1e-6 of the oracle's after 8 optimizer steps per
+    network, i.e. the gradients themselves agree (the default-Adam test above can
+    only bound single elements by a fraction of lr)."""
+    _oracle_iterations('c5', n_envs=40, E=2, mb=2560, iterations=1,
+                       atol_params=1e-6, linear_adam=True)
 
 
 def _snapshot(algo):
