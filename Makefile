@@ -6,18 +6,18 @@ HIPCC ?= /opt/rocm/bin/hipcc
 ARCH  ?= gfx950
 CSRC  := garage_amd/csrc
 OUT   := garage_amd/_C
-HIPS  := gae_scan gemm skinny losses rollout policy_fused small_step
+HIPS  := gae_scan gemm skinny losses rollout policy_fused small_step fused_train
 CPPS  := errors prof update comm rollout_loop
 OBJS  := $(patsubst %,$(OUT)/%.o,$(HIPS) $(CPPS))
 FLAGS := --offload-arch=$(ARCH) -O3 -fPIC -std=c++17 -Wall -Wno-unused-function
 
 all: $(OUT)/libgarage_amd.so
 
-$(OUT)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/prof.h $(CSRC)/small_step.h
+$(OUT)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/prof.h $(CSRC)/small_step.h $(CSRC)/gemm_core.h $(CSRC)/loss_rows.h $(CSRC)/fused_train.h
 	@mkdir -p $(OUT)
 	$(HIPCC) $(FLAGS) -c $< -o $@
 
-$(OUT)/%.o: $(CSRC)/%.cpp $(CSRC)/prof.h $(CSRC)/small_step.h include/garage_amd.h
+$(OUT)/%.o: $(CSRC)/%.cpp $(CSRC)/prof.h $(CSRC)/small_step.h $(CSRC)/fused_train.h include/garage_amd.h
 	@mkdir -p $(OUT)
 	$(HIPCC) $(FLAGS) -x hip -c $< -o $@
 

@@ -77,7 +77,8 @@ class UpdateArgs(C.Structure):
                 ('losses', ptr), ('loss_scratch', ptr), ('workspace', ptr),
                 ('comm', ptr), ('world', c_i32), ('double_softmax', c_i32),
                 ('grad_scale', c_f32), ('n_mb', c_i64),
-                ('grad_scales_host', ptr)]
+                ('grad_scales_host', ptr), ('partials', ptr),
+                ('partials_floats', c_i64), ('phase', c_i32)]
 
 
 # name -> (restype, argtypes); mirrors include/garage_amd.h one to one.
@@ -188,6 +189,8 @@ SIGNATURES = {
     'ga_permutation_i32': (c_int, [c_i64, c_u64, ptr, ptr]),
     'ga_episode_sums_f32': (c_int, [ptr, ptr, c_i64, ptr, ptr]),
     'ga_update_epoch': (c_int, [C.POINTER(UpdateArgs), ptr]),
+    'ga_update_partials_floats': (c_i64, [C.POINTER(MlpDesc), c_i64]),
+    'ga_set_fused_train': (c_int, [c_int]),
     'ga_update_epoch_pair': (c_int, [C.POINTER(UpdateArgs), ptr,
                                      C.POINTER(UpdateArgs), ptr]),
     'ga_set_allreduce_hook': (None, [ptr]),

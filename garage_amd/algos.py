@@ -623,8 +623,9 @@ class VPG:
         return True
 
     def _update_args(self, opt, module, kind, batch, adv, returns, old_ll,
-                     tag):
-        """``ga_update_args`` of one network (kept alive by the caller)."""
+                     tag, rows=None):
+        """``ga_update_args`` of one network (kept alive by the caller);
+        ``rows``: size the workspaces for minibatches of that many rows."""
         from garage_amd import _lib
         import ctypes as C
         # head layer inside the loss kernel (opt-in; same switch as the Python
@@ -634,7 +635,9 @@ class VPG:
         net = module.net
         S = batch.n_samples
         mb = opt.local_minibatch_size(S)
-        net._workspace(S if mb is None else min(S, mb))
+        if rows is None:
+            rows = S if mb is None else min(S, mb)
+        net._workspace(rows)
         dev = net.device
         a = _lib.UpdateArgs()
         a.desc = C.pointer(net._desc)
@@ -675,6 +678,12 @@ class VPG:
         a.workspace = reduction_workspace(dev, tag).data_ptr()
         comm = getattr(opt, 'native_comm', None)
         keep = [scratch]
+        # fused step kernels (last hidden layer + head + loss in one launch, ...)
+        # for minibatches a few tiles and up; VPG's single full-batch step of a
+        # million rows would need a scratch of its own size for nothing
+        part = net.train_partials(rows) if rows <= (1 << 17) else None
+        if part is not None:
+            a.partials, a.partials_floats = part.data_ptr(), part.numel()
         if comm is not None:
             a.comm, a.world = comm.handle, comm.world_size
             a.grad_scale = float(opt.dp_grad_scale)
@@ -756,21 +765,50 @@ class VPG:
         del keep_p, keep_v
 
     def _train_policy(self, batch, adv, old_ll, idx):
-        M = batch.n_samples if idx is None else int(idx.numel())
-        net = self.policy.net
-        loss, _, dout = self._policy_loss_pass(batch, adv, old_ll, M, idx,
-                                               want_grad=True)
-        net.backward(batch.obs_dev, M, dout, row_idx=idx)
-        self._policy_optimizer.step()
-        return loss
+        """``vpg.py:250-272``: one optimizer step on the rows ``idx``."""
+        return self._minibatch_step(self._policy_optimizer, self.policy, 0,
+                                    batch, adv, None, old_ll, idx)
 
     def _train_value_function(self, batch, returns, idx):
+        """``vpg.py:274-293``."""
+        return self._minibatch_step(self._vf_optimizer, self._value_function,
+                                    1, batch, None, returns, None, idx)
+
+    def _minibatch_step(self, opt, module, kind, batch, adv, returns, old_ll,
+                        idx):
+        """One step through the same entry point as the native epoch loop
+        (``ga_update_epoch`` with a pass of one minibatch), so both produce the
+        same bits.  With a gradient hook (data parallel over a backend the
+        library cannot call) the native part stops at the reduced gradient
+        (``phase = 1``); the exchange and Adam follow here."""
+        import ctypes as C
+        net = module.net
         M = batch.n_samples if idx is None else int(idx.numel())
-        net = self._value_function.net
-        loss, _, dout = self._value_loss_pass(batch, returns, M, idx,
-                                              want_grad=True)
-        net.backward(batch.obs_dev, M, dout, row_idx=idx)
-        self._vf_optimizer.step()
+        a, keep, _ = self._update_args(opt, module, kind, batch, adv, returns,
+                                       old_ll, 0, rows=M)
+        a.S, a.mb, a.n_mb = M, M, 0
+        a.perm = None if idx is None else idx.data_ptr()
+        if idx is None:
+            a.S = batch.n_samples
+        a.grad_scales_host = None
+        a.comm = None
+        hook = opt.grad_hook
+        a.phase = 1 if hook is not None else 0
+        if hook is not None:
+            a.grad_scale = float(opt.dp_grad_scale
+                                 if opt._cur_grad_scale is None
+                                 else opt._cur_grad_scale)
+        loss = torch.empty(1, dtype=torch.float32, device=net.device)
+        a.losses = loss.data_ptr()
+        a.step0 = net.adam_steps
+        call('ga_update_epoch', C.byref(a), stream_ptr())
+        if hook is not None:
+            hook(net.grads)
+            h = opt._hyper
+            net.adam_step(h['lr'], h['betas'], h['eps'])
+        else:
+            net.adam_steps += 1
+        del keep
         return loss
 
     # -- log_performance (_functions.py:233-275) --------------------------------

@@ -1,0 +1,49 @@
+// Entry points of the fused optimizer-step kernels (fused_train.hip) and of the MLP
+// layer ranges they combine with (gemm.hip), used by the epoch loop (update.cpp).
+// Not part of the C ABI: ga_update_epoch* is what callers see.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct ga_fused_loss_args {
+  int kind;                  // 0 Gaussian policy, 1 value NLL, 2 categorical policy
+  const float* actions; int64_t lda;
+  const float* old_ll; const float* adv; const float* returns;
+  const int32_t* idx;        // minibatch row m is sample idx[m] (null: m)
+  const float* log_std; int has_min, has_max; float min_log_std, max_log_std;
+  int A;                     // head width
+  int algo; float clip; float ent_coeff; int ent_flags;
+  int double_softmax;
+};
+
+struct ga_fused_region {
+  int64_t beg, n;            // flat parameter range [beg, beg + n)
+  const float* src;          // partial 0 of element 0
+  int64_t stride;            // floats between partials
+  int n_part;
+};
+
+extern "C" {
+int ga_fused_width_ok(int width);       // 64, 128 or 256 units
+int64_t ga_fused_tiles(int64_t M);      // workgroups (= partial sets) for M rows
+// last hidden layer + head + loss + gradient seed + head weight-gradient shares;
+// hpart: [tiles][8 * width + 8] floats, lpart: [tiles][2] doubles
+int ga_fused_fwd_head_loss(const float* A, int64_t lda, const int32_t* a_idx,
+                           const float* W, int64_t ldw, const float* bias, int64_t M,
+                           int width, int K, const float* head_W, int64_t head_ldw,
+                           const float* head_bias, const ga_fused_loss_args* loss,
+                           float* dZ, int64_t lddz, float* hpart, double* lpart,
+                           hipStream_t stream);
+// data gradient into the first hidden layer + first-layer weight / bias gradient
+// shares; wpart: [tiles][width * round4(in_w) + width] floats
+int ga_fused_dgrad_wgrad0(const float* dZ2, int64_t lddz, const float* W2, int64_t ldw,
+                          int64_t M, int width, int K, const float* H1, int64_t ldh,
+                          const float* X, int64_t ldx, const int32_t* idx, int in_w,
+                          float* wpart, hipStream_t stream);
+int ga_reduce_regions_adam(const ga_fused_region* regions, int n_regions, float* params,
+                           float* grads, float* exp_avg, float* exp_avg_sq, int64_t step,
+                           double lr, double beta1, double beta2, double eps, float scale,
+                           int do_adam, int zero_slot0, const double* lpart, int n_lpart,
+                           int64_t M, const ga_fused_loss_args* loss, float* loss_out,
+                           hipStream_t stream);
+}

@@ -1,0 +1,716 @@
+// Fused kernels of one optimizer step (gfx950): the streaming passes around the
+// MFMA GEMMs of VPG._train_policy / _train_value_function (torch/algos/vpg.py
+// :250-293) folded into the GEMMs' epilogues, so that the activation of the last
+// hidden layer, its data gradient's narrow products and the data gradient of the
+// first hidden layer never travel through HBM.
+//
+//   fwd_head_loss_kernel   last hidden layer  H = tanh(A W^T + b)  on 64-row tiles
+//       that span the layer's whole width (64, 128 or 256 units), then -- on the
+//       staged rows, before anything leaves the CU -- the head layer (<= 8
+//       outputs: torch/modules/multi_headed_mlp_module.py:136-151), the loss row
+//       by row with its gradient seed (loss_rows.h: ppo.py:96-132, vpg.py:434-454,
+//       gaussian_mlp_value_function.py:81-98), the data gradient of this layer
+//       dZ = (dout W_head) (1 - H^2) and this workgroup's share of the head's
+//       weight / bias gradient  dW_head = dout^T H.  Written: dZ [M x width] and a
+//       few KB of partial sums per workgroup.  H itself is never stored.
+//       Replaces: head GEMM, loss kernel, loss finalize, head weight-gradient +
+//       data-gradient streaming kernel (4 launches, 2 passes over [M x width]).
+//
+//   dgrad_wgrad0_kernel    data gradient into the FIRST hidden layer
+//       dZ1 = (dZ2 W2) (1 - H1^2)  on 64-row tiles spanning H1's whole width, then
+//       this workgroup's share of the first layer's weight and bias gradient
+//       dW1 = dZ1^T X,  db1 = 1^T dZ1  (X: <= 32 observation columns, gathered).
+//       dZ1 is never stored.  Replaces the first-layer weight-gradient streaming
+//       kernel and one [M x width] store + load.
+//
+//   reduce_regions_adam_kernel   the optimizer step over per-region partial sums
+//       (split-K slabs of the weight-gradient GEMMs, per-workgroup partials of
+//       the two kernels above), each element summed in a fixed order by `ways`
+//       adjacent lanes; one extra block finishes the loss (batch sums -> loss
+//       value, log-std gradient) and steps the log-std slot.
+//       torch.optim.Adam arithmetic as in losses.hip.
+//
+// Everything is exact fp32 on v_mfma_f32_32x32x2_f32 with fixed summation orders
+// (bitwise reproducible run to run); orders differ from the unfused kernels, so
+// the two paths agree to rounding, not bit for bit.
+#include "common.h"
+#include <hip/hip_ext.h>
+
+#include "prof.h"
+
+#include "gemm_core.h"
+#include "loss_rows.h"
+#include "fused_train.h"
+
+namespace {
+
+constexpr int FT_ROWS = 64;  // rows per workgroup tile
+
+struct FwdLossParams {
+  GemmParams g;          // A, lda, a_idx, B (= W [BN][ldb]), bias, M, N (= BN), K
+  const float* head_W;   // [A][head_ldw]
+  int64_t head_ldw;
+  const float* head_bias;
+  LossRowArgs loss;
+  float* dZ;             // [M][lddz]
+  int64_t lddz;
+  float* hpart;          // [gx][8 * BN + 8]: dW_head (j major), then db_head
+  double* lpart;         // [gx][2]
+};
+
+typedef const __attribute__((address_space(4))) float* ft_uniform_ptr;
+
+// (two 512-thread workgroups per CU need <= 128 registers: the second bound is waves
+// per SIMD)
+template <int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N,
+                             WAVES_M * WAVES_N == 8 ? 4 : 2) void fwd_head_loss_kernel(
+    FwdLossParams p) {
+  constexpr int NT = 64 * WAVES_M * WAVES_N;
+  constexpr int WM = FT_ROWS / WAVES_M, WN = BN / WAVES_N;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int LDK = BK + PAD;
+  constexpr int A_FLOATS = FT_ROWS * LDK, B_FLOATS = BN * LDK;
+  constexpr int LDC = BN + 4;
+  constexpr int STAGE_FLOATS = FT_ROWS * LDC;
+  constexpr int TILE_FLOATS =
+      A_FLOATS + B_FLOATS > STAGE_FLOATS ? A_FLOATS + B_FLOATS : STAGE_FLOATS;
+  constexpr int SEGS = NT / 64, CPS = BN / SEGS, HN = 8;
+  constexpr int PL = SEGS < 4 ? SEGS : 4;
+  constexpr int AUX_FLOATS = PL * 64 * HN > HN * BN ? PL * 64 * HN : HN * BN;
+  static_assert(SEGS <= 2 * PL, "two reduction steps");
+  static_assert((FT_ROWS * (BN / 4)) % NT == 0, "whole quads per thread");
+  __shared__ __attribute__((aligned(16))) float lds[TILE_FLOATS + AUX_FLOATS];
+  __shared__ __attribute__((aligned(16))) float outl[FT_ROWS * HN];
+  __shared__ __attribute__((aligned(16))) float doutl[FT_ROWS * HN];
+  float* stage = lds;
+  float* aux = lds + TILE_FLOATS;  // head partial planes, later W_head [8][BN]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm0 = (wave / WAVES_N) * WM;
+  const int wn0 = (wave % WAVES_N) * WN;
+  const int m0 = blockIdx.x * FT_ROWS;
+  const int M = p.g.M;
+  const LossRowArgs& L = p.loss;
+
+  // the sample of this lane's row (wave 0 computes the loss rows): loads issued
+  // now, consumed after the k-loop
+  float act[8];
+  float adv = 0.f, old_ll = 0.f, ret = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) act[j] = 0.f;
+  const bool live = m0 + lane < M;
+  if (wave == 0) {
+    const int m = min(m0 + lane, M - 1);
+    const int64_t src = L.idx ? (int64_t)L.idx[m] : (int64_t)m;
+    if (L.kind == 1) {
+      ret = L.returns[src];
+    } else {
+      adv = L.adv[src];
+      if (L.algo != 1) old_ll = L.old_ll[src];
+      const float* arow = L.actions + src * L.lda;
+      if (L.kind == 2) {
+        act[0] = arow[0];
+      } else {
+        // action rows are padded to a multiple of 4 floats (16-B aligned)
+        const float4 a0 = *reinterpret_cast<const float4*>(arow);
+        act[0] = a0.x; act[1] = a0.y; act[2] = a0.z; act[3] = a0.w;
+        if (L.A > 4) {
+          const float4 a1 = *reinterpret_cast<const float4*>(arow + 4);
+          act[4] = a1.x; act[5] = a1.y; act[6] = a1.z; act[7] = a1.w;
+        }
+      }
+    }
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float csum = 0.f;
+  const bool full = m0 + FT_ROWS <= M;
+  if (full)
+    gemm_mainloop<FT_ROWS, BN, WAVES_M, WAVES_N, true, true, BK, true>(
+        p.g, lds, acc, csum, false, m0, 0, 0, p.g.K, wm0, wn0);
+  else
+    gemm_mainloop<FT_ROWS, BN, WAVES_M, WAVES_N, true, true, BK, false>(
+        p.g, lds, acc, csum, false, m0, 0, 0, p.g.K, wm0, wn0);
+
+  // ---- E1: accumulators -> staged rows [64][BN + 4]
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rr = wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        stage[rr * LDC + wn0 + 32 * j + (lane & 31)] = acc[i][j][r];
+      }
+  __syncthreads();
+  // ---- E2: H = tanh(. + bias), kept in the stage only
+#pragma unroll
+  for (int q = 0; q < FT_ROWS * (BN / 4) / NT; ++q) {
+    const int e = tid + NT * q;
+    const int rr = e / (BN / 4), c4 = e % (BN / 4);
+    float4 v = *reinterpret_cast<const float4*>(stage + rr * LDC + 4 * c4);
+    const float4 b = *reinterpret_cast<const float4*>(p.g.bias + 4 * c4);
+    v.x = tanh_fast(v.x + b.x); v.y = tanh_fast(v.y + b.y);
+    v.z = tanh_fast(v.z + b.z); v.w = tanh_fast(v.w + b.w);
+    *reinterpret_cast<float4*>(stage + rr * LDC + 4 * c4) = v;
+  }
+  __syncthreads();
+  // ---- E3: head outputs of the 64 rows (lane = row, wave = a column segment whose
+  //      weights are wave-uniform: scalar loads, v_fmac with an SGPR operand)
+  {
+    const int row = lane, seg = wave;
+    float4 h[CPS / 4];
+#pragma unroll
+    for (int i = 0; i < CPS / 4; ++i)
+      h[i] = *reinterpret_cast<const float4*>(stage + row * LDC + seg * CPS + 4 * i);
+    float a[HN];
+#pragma unroll
+    for (int j = 0; j < HN; ++j) {
+      a[j] = 0.f;
+      if (j < L.A) {
+        ft_uniform_ptr w =
+            (ft_uniform_ptr)(uintptr_t)(p.head_W + (int64_t)j * p.head_ldw + seg * CPS);
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < CPS / 4; ++i) {
+          s0 = fmaf(h[i].x, w[4 * i + 0], s0);
+          s1 = fmaf(h[i].y, w[4 * i + 1], s1);
+          s0 = fmaf(h[i].z, w[4 * i + 2], s0);
+          s1 = fmaf(h[i].w, w[4 * i + 3], s1);
+        }
+        a[j] = s0 + s1;
+      }
+    }
+    float* mine = aux + ((seg % PL) * 64 + row) * HN;
+    if (seg < PL) {
+      *reinterpret_cast<float4*>(mine) = make_float4(a[0], a[1], a[2], a[3]);
+      *reinterpret_cast<float4*>(mine + 4) = make_float4(a[4], a[5], a[6], a[7]);
+    }
+    __syncthreads();
+    if (SEGS > PL) {
+      if (seg >= PL) {
+        float4 lo = *reinterpret_cast<const float4*>(mine);
+        float4 hi = *reinterpret_cast<const float4*>(mine + 4);
+        lo.x += a[0]; lo.y += a[1]; lo.z += a[2]; lo.w += a[3];
+        hi.x += a[4]; hi.y += a[5]; hi.z += a[6]; hi.w += a[7];
+        *reinterpret_cast<float4*>(mine) = lo;
+        *reinterpret_cast<float4*>(mine + 4) = hi;
+      }
+      __syncthreads();
+    }
+    for (int o = tid; o < 64 * HN; o += NT) {
+      const int j = o % HN;
+      float s = 0.f;
+      if (j < L.A) {
+        s = p.head_bias[j];
+#pragma unroll
+        for (int w = 0; w < PL; ++w) s += aux[w * 64 * HN + o];
+      }
+      outl[o] = s;
+    }
+  }
+  __syncthreads();
+  // ---- E4: wave 0: the loss rows (d(loss)/d(head output) -> doutl, batch-sum
+  //      shares -> lpart); the other waves stage W_head [8][BN] over the planes
+  if (wave == 0) {
+    float s = 0.f, inv_var = 1.f;
+    if (L.kind != 2) {
+      s = *L.log_std;
+      if (L.kind == 0) {
+        if (L.has_min && s < L.min_log_std) s = L.min_log_std;
+        if (L.has_max && s > L.max_log_std) s = L.max_log_std;
+      }
+      inv_var = expf(-2.f * s);
+    }
+    float out[8], dout[8];
+    const float4 o0 = *reinterpret_cast<const float4*>(outl + lane * HN);
+    const float4 o1 = *reinterpret_cast<const float4*>(outl + lane * HN + 4);
+    out[0] = o0.x; out[1] = o0.y; out[2] = o0.z; out[3] = o0.w;
+    out[4] = o1.x; out[5] = o1.y; out[6] = o1.z; out[7] = o1.w;
+    double second = 0.0;
+    double first = lr_row(L, s, inv_var, out, act, adv, old_ll, ret, dout, &second);
+    if (!live) {
+      first = 0.0; second = 0.0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dout[j] = 0.f;
+    }
+    *reinterpret_cast<float4*>(doutl + lane * HN) =
+        make_float4(dout[0], dout[1], dout[2], dout[3]);
+    *reinterpret_cast<float4*>(doutl + lane * HN + 4) =
+        make_float4(dout[4], dout[5], dout[6], dout[7]);
+    first = ga_wave_sum(first);
+    second = ga_wave_sum(second);
+    if (lane == 0) {
+      p.lpart[2 * blockIdx.x + 0] = first;
+      p.lpart[2 * blockIdx.x + 1] = second;
+    }
+  } else {
+    for (int e = tid - 64; e < HN * (BN / 4); e += NT - 64) {
+      const int j = e / (BN / 4), c4 = e % (BN / 4);
+      float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (j < L.A)
+        w = *reinterpret_cast<const float4*>(p.head_W + (int64_t)j * p.head_ldw + 4 * c4);
+      *reinterpret_cast<float4*>(aux + j * BN + 4 * c4) = w;
+    }
+  }
+  __syncthreads();
+  // ---- E5: dZ = (dout W_head) (1 - H^2) -> global (the only [M x BN] store)
+#pragma unroll
+  for (int q = 0; q < FT_ROWS * (BN / 4) / NT; ++q) {
+    const int e = tid + NT * q;
+    const int rr = e / (BN / 4), c4 = e % (BN / 4);
+    const float4 h = *reinterpret_cast<const float4*>(stage + rr * LDC + 4 * c4);
+    const float4 d0 = *reinterpret_cast<const float4*>(doutl + rr * HN);
+    const float4 d1 = *reinterpret_cast<const float4*>(doutl + rr * HN + 4);
+    const float dd[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+    float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < HN; ++j) {
+      if (j < L.A) {
+        const float4 w = *reinterpret_cast<const float4*>(aux + j * BN + 4 * c4);
+        z.x = fmaf(dd[j], w.x, z.x); z.y = fmaf(dd[j], w.y, z.y);
+        z.z = fmaf(dd[j], w.z, z.z); z.w = fmaf(dd[j], w.w, z.w);
+      }
+    }
+    z.x *= (1.f - h.x * h.x); z.y *= (1.f - h.y * h.y);
+    z.z *= (1.f - h.z * h.z); z.w *= (1.f - h.w * h.w);
+    if (m0 + rr < M)
+      *reinterpret_cast<float4*>(p.dZ + (int64_t)(m0 + rr) * p.lddz + 4 * c4) = z;
+  }
+  // ---- E6: this workgroup's share of dW_head[j][c] = sum_r dout[r][j] H[r][c]
+  //      (rows beyond M carry dout = 0) and of db_head
+  {
+    constexpr int GROUPS = NT / BN, JPG = HN / GROUPS;
+    const int c = tid % BN, j0 = (tid / BN) * JPG;
+    float g[JPG];
+#pragma unroll
+    for (int jj = 0; jj < JPG; ++jj) g[jj] = 0.f;
+    for (int r = 0; r < FT_ROWS; ++r) {
+      const float h = stage[r * LDC + c];
+#pragma unroll
+      for (int jj = 0; jj < JPG; ++jj) g[jj] = fmaf(doutl[r * HN + j0 + jj], h, g[jj]);
+    }
+    float* hp = p.hpart + (int64_t)blockIdx.x * (HN * BN + HN);
+#pragma unroll
+    for (int jj = 0; jj < JPG; ++jj) hp[(j0 + jj) * BN + c] = g[jj];
+    if (tid < HN) {
+      float b = 0.f;
+      for (int r = 0; r < FT_ROWS; ++r) b += doutl[r * HN + tid];
+      hp[HN * BN + tid] = b;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+struct DgradWgrad0Params {
+  GemmParams g;        // A = dZ2 [M][lda], B = W2 [K][ldb] (n contiguous), M, N = BN, K
+  const float* H;      // tanh outputs of the first hidden layer [M][ldh]
+  int64_t ldh;
+  const float* X;      // observations [*][ldx], in_w valid columns, gathered
+  int64_t ldx;
+  const int32_t* idx;
+  int in_w;            // <= 32
+  float* wpart;        // [gx][BN * ld0 + BN]: dW1 [n][ld0], then db1 [n]
+};
+
+template <int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N,
+                             WAVES_M * WAVES_N == 8 ? 4 : 2) void dgrad_wgrad0_kernel(
+    DgradWgrad0Params p) {
+  constexpr int NT = 64 * WAVES_M * WAVES_N;
+  constexpr int WM = FT_ROWS / WAVES_M, WN = BN / WAVES_N;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int LDK = BK + PAD, LDB_S = BN + PAD;
+  constexpr int A_FLOATS = FT_ROWS * LDK, B_FLOATS = BK * LDB_S;
+  constexpr int LDC = BN + 4;
+  constexpr int STAGE_FLOATS = FT_ROWS * LDC;
+  constexpr int TILE_FLOATS =
+      A_FLOATS + B_FLOATS > STAGE_FLOATS ? A_FLOATS + B_FLOATS : STAGE_FLOATS;
+  constexpr int LDXS = 32;  // staged observation rows: 32 floats (zero beyond in_w)
+  static_assert((FT_ROWS * (BN / 4)) % NT == 0, "whole quads per thread");
+  static_assert(FT_ROWS * (LDXS / 4) <= 2 * NT, "at most two quads of X per thread");
+  __shared__ __attribute__((aligned(16))) float lds[TILE_FLOATS];
+  __shared__ __attribute__((aligned(16))) float xs[FT_ROWS * LDXS];
+  float* stage = lds;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm0 = (wave / WAVES_N) * WM;
+  const int wn0 = (wave % WAVES_N) * WN;
+  const int m0 = blockIdx.x * FT_ROWS;
+  const int M = p.g.M;
+  const int ld0 = (p.in_w + 3) & ~3;
+
+  // the workgroup's observation rows: loads issued now, staged after the k-loop
+  float4 xq[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int e = tid + NT * i;
+    const int rr = min(e / (LDXS / 4), FT_ROWS - 1);
+    const int q = min(e % (LDXS / 4), ld0 / 4 - 1);
+    const int m = min(m0 + rr, M - 1);
+    const int64_t src = p.idx ? (int64_t)p.idx[m] : (int64_t)m;
+    xq[i] = *reinterpret_cast<const float4*>(p.X + src * p.ldx + 4 * q);
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float csum = 0.f;
+  const bool full = m0 + FT_ROWS <= M;
+  if (full)
+    gemm_mainloop<FT_ROWS, BN, WAVES_M, WAVES_N, true, false, BK, true>(
+        p.g, lds, acc, csum, false, m0, 0, 0, p.g.K, wm0, wn0);
+  else
+    gemm_mainloop<FT_ROWS, BN, WAVES_M, WAVES_N, true, false, BK, false>(
+        p.g, lds, acc, csum, false, m0, 0, 0, p.g.K, wm0, wn0);
+
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rr = wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        stage[rr * LDC + wn0 + 32 * j + (lane & 31)] = acc[i][j][r];
+      }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int e = tid + NT * i;
+    if (e < FT_ROWS * (LDXS / 4)) {
+      const int rr = e / (LDXS / 4), q = e % (LDXS / 4);
+      float4 x = xq[i];
+      const bool row_ok = m0 + rr < M;
+      x.x = (row_ok && 4 * q + 0 < p.in_w) ? x.x : 0.f;
+      x.y = (row_ok && 4 * q + 1 < p.in_w) ? x.y : 0.f;
+      x.z = (row_ok && 4 * q + 2 < p.in_w) ? x.z : 0.f;
+      x.w = (row_ok && 4 * q + 3 < p.in_w) ? x.w : 0.f;
+      *reinterpret_cast<float4*>(xs + rr * LDXS + 4 * q) = x;
+    }
+  }
+  __syncthreads();
+  // dZ1 = (dZ2 W2) (1 - H1^2), kept in the stage only (rows beyond M are zero: their
+  // dZ2 rows were masked by the loader)
+#pragma unroll
+  for (int q = 0; q < FT_ROWS * (BN / 4) / NT; ++q) {
+    const int e = tid + NT * q;
+    const int rr = e / (BN / 4), c4 = e % (BN / 4);
+    const int m = min(m0 + rr, M - 1);
+    const float4 h = *reinterpret_cast<const float4*>(p.H + (int64_t)m * p.ldh + 4 * c4);
+    float4 v = *reinterpret_cast<const float4*>(stage + rr * LDC + 4 * c4);
+    v.x *= (1.f - h.x * h.x); v.y *= (1.f - h.y * h.y);
+    v.z *= (1.f - h.z * h.z); v.w *= (1.f - h.w * h.w);
+    *reinterpret_cast<float4*>(stage + rr * LDC + 4 * c4) = v;
+  }
+  __syncthreads();
+  // this workgroup's share of dW1[n][k] = sum_r dZ1[r][n] X[r][k] and of db1[n]
+  {
+    constexpr int GROUPS = NT / BN;         // 2 (or 4 at BN = 64)
+    constexpr int QPG = (LDXS / 4) / GROUPS;  // observation quads per group: 4 (2)
+    const int n = tid % BN, q0 = (tid / BN) * QPG;
+    float4 g[QPG];
+#pragma unroll
+    for (int qq = 0; qq < QPG; ++qq) g[qq] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float b = 0.f;
+    for (int r = 0; r < FT_ROWS; ++r) {
+      const float d = stage[r * LDC + n];
+      b += d;
+#pragma unroll
+      for (int qq = 0; qq < QPG; ++qq) {
+        const float4 x = *reinterpret_cast<const float4*>(xs + r * LDXS + 4 * (q0 + qq));
+        g[qq].x = fmaf(d, x.x, g[qq].x); g[qq].y = fmaf(d, x.y, g[qq].y);
+        g[qq].z = fmaf(d, x.z, g[qq].z); g[qq].w = fmaf(d, x.w, g[qq].w);
+      }
+    }
+    float* wp = p.wpart + (int64_t)blockIdx.x * ((int64_t)BN * ld0 + BN);
+#pragma unroll
+    for (int qq = 0; qq < QPG; ++qq)
+      if (4 * (q0 + qq) < ld0)
+        *reinterpret_cast<float4*>(wp + (int64_t)n * ld0 + 4 * (q0 + qq)) = g[qq];
+    if (tid < BN) wp[(int64_t)BN * ld0 + n] = b;
+  }
+}
+
+// ---------------------------------------------------------------------------
+struct FtAdam {  // losses.hip: AdamParams / adam_update
+  float* p; float* m; float* v;
+  float lerp_w, beta2, one_minus_beta2, neg_step_size, bc2_sqrt, eps;
+};
+__device__ __forceinline__ void ft_adam_update(const FtAdam& a, float g, float& p,
+                                               float& m, float& v) {
+#pragma clang fp contract(off)
+  const float diff = g - m;
+  m = fmaf(a.lerp_w, diff, m);
+  const float gg = (a.one_minus_beta2 * g) * g;
+  v = v * a.beta2 + gg;
+  const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+  const float num = a.neg_step_size * m;
+  p = p + num / denom;
+}
+
+constexpr int FT_MAX_REGIONS = 16;
+struct FtRegion {
+  int64_t beg;        // first flat parameter index
+  int64_t n;          // elements
+  const float* src;   // partial 0 of element 0
+  int64_t stride;     // floats between consecutive partials
+  int n_part;
+  int ways;           // adjacent lanes that share an element's partials (1, 2, 4, 8)
+  int64_t vbeg;       // first virtual thread (a multiple of 64)
+};
+struct ReduceRegionsParams {
+  FtRegion r[FT_MAX_REGIONS];
+  int n_regions;
+  int64_t n_virtual;
+  FtAdam a;
+  float* grads;       // the reduced (scaled) gradient is also written here
+  float scale;
+  int do_adam;        // 0: stop after writing grads (an all-reduce follows)
+  int zero_slot0;     // the log-std slot is not trained
+  // loss finish (one extra block): batch sums -> loss value, log-std gradient
+  const double* lpart;
+  int n_lpart;
+  int64_t M;
+  LossRowArgs loss;
+  float* loss_out;
+};
+
+__global__ __launch_bounds__(256) void reduce_regions_adam_kernel(ReduceRegionsParams p) {
+  if (blockIdx.x == gridDim.x - 1) {
+    // ---- the loss scalars and the log-std slot (flat index 0), one wave
+    if (threadIdx.x >= 64) return;
+    double first = 0.0, second = 0.0;
+    for (int b = threadIdx.x; b < p.n_lpart; b += 64) {
+      first += p.lpart[2 * b + 0];
+      second += p.lpart[2 * b + 1];
+    }
+    first = ga_wave_sum(first);
+    second = ga_wave_sum(second);
+    if (threadIdx.x != 0) return;
+    float loss, dls;
+    lr_finish(p.loss, first, second, p.M, &loss, &dls);
+    if (p.loss_out) *p.loss_out = loss;
+    float g = p.zero_slot0 ? 0.f : dls * p.scale;
+    p.grads[0] = g;
+    if (p.do_adam) {
+      float pp = p.a.p[0], mm = p.a.m[0], vv = p.a.v[0];
+      ft_adam_update(p.a, g, pp, mm, vv);
+      p.a.p[0] = pp; p.a.m[0] = mm; p.a.v[0] = vv;
+    }
+    return;
+  }
+  const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  // a wave belongs to one region (vbeg are multiples of 64)
+  int ri = -1;
+#pragma unroll 1
+  for (int k = 0; k < p.n_regions; ++k)
+    if (v >= p.r[k].vbeg) ri = k;
+  if (ri < 0) return;
+  const FtRegion& R = p.r[ri];
+  const int ways = R.ways;
+  const int64_t local = v - R.vbeg;
+  const int64_t e = local / ways;
+  const int way = (int)(local % ways);
+  const bool on = e < R.n;
+  const int chunk = (R.n_part + ways - 1) / ways;
+  const int p0 = way * chunk, p1 = min(R.n_part, p0 + chunk);
+  float acc = 0.f;
+  if (on) {
+    const float* s = R.src + e;
+    int k = p0;
+    for (; k + 4 <= p1; k += 4) {
+      const float v0 = s[(int64_t)k * R.stride], v1 = s[(int64_t)(k + 1) * R.stride];
+      const float v2 = s[(int64_t)(k + 2) * R.stride], v3 = s[(int64_t)(k + 3) * R.stride];
+      acc += (v0 + v1) + (v2 + v3);
+    }
+    for (; k < p1; ++k) acc += s[(int64_t)k * R.stride];
+  }
+  // the ways' sums, added in way order (every lane of the wave takes part)
+  const int lane = threadIdx.x & 63;
+  const int base = lane - way;
+  float g = 0.f;
+  for (int w = 0; w < ways; ++w) g += __shfl(acc, base + w, 64);
+  if (!on || way != 0) return;
+  g *= p.scale;
+  const int64_t i = R.beg + e;
+  p.grads[i] = g;
+  if (p.do_adam) {
+    float pp = p.a.p[i], mm = p.a.m[i], vv = p.a.v[i];
+    ft_adam_update(p.a, g, pp, mm, vv);
+    p.a.p[i] = pp; p.a.m[i] = mm; p.a.v[i] = vv;
+  }
+}
+
+int ways_for(int n_part) {
+  int w = 1;
+  while (w < 8 && n_part > 32 * w) w *= 2;
+  return w;
+}
+
+LossRowArgs loss_args(const ga_fused_loss_args* l, int64_t M) {
+  LossRowArgs L;
+  memset(&L, 0, sizeof(L));
+  L.kind = l->kind; L.actions = l->actions; L.lda = l->lda; L.old_ll = l->old_ll;
+  L.adv = l->adv; L.returns = l->returns; L.idx = l->idx; L.log_std = l->log_std;
+  L.has_min = l->has_min; L.has_max = l->has_max; L.min_log_std = l->min_log_std;
+  L.max_log_std = l->max_log_std; L.A = l->A; L.algo = l->algo; L.clip = l->clip;
+  L.ent_coeff = l->ent_coeff; L.ent_regularized = l->ent_flags & 1;
+  L.ent_softplus = (l->ent_flags >> 1) & 1; L.ent_stop_grad = (l->ent_flags >> 2) & 1;
+  L.double_softmax = l->double_softmax;
+  L.invM = 1.f / (float)M;
+  return L;
+}
+
+}  // namespace
+
+extern "C" int ga_fused_width_ok(int width) {
+  return width == 64 || width == 128 || width == 256;
+}
+
+extern "C" int64_t ga_fused_tiles(int64_t M) { return ga_ceil_div(M, FT_ROWS); }
+
+extern "C" int ga_fused_fwd_head_loss(const float* A, int64_t lda, const int32_t* a_idx,
+                                      const float* W, int64_t ldw, const float* bias,
+                                      int64_t M, int width, int K, const float* head_W,
+                                      int64_t head_ldw, const float* head_bias,
+                                      const ga_fused_loss_args* loss, float* dZ,
+                                      int64_t lddz, float* hpart, double* lpart,
+                                      hipStream_t stream) {
+  GA_REQUIRE(A && W && bias && head_W && head_bias && loss && dZ && hpart && lpart,
+             "ga_fused_fwd_head_loss: null pointer");
+  GA_REQUIRE(ga_fused_width_ok(width) && M >= 1 && M < (1ll << 31) && K >= 1 &&
+                 loss->A >= 1 && loss->A <= 8,
+             "ga_fused_fwd_head_loss: unsupported shape");
+  GA_REQUIRE(lda % 4 == 0 && ldw % 4 == 0 && head_ldw % 4 == 0 && lddz % 4 == 0 &&
+                 ga_aligned16(A) && ga_aligned16(W) && ga_aligned16(bias) &&
+                 ga_aligned16(head_W) && ga_aligned16(dZ),
+             "ga_fused_fwd_head_loss: operands must be 16-B aligned quads");
+  GA_REQUIRE(loss->kind == 1 ? loss->returns != nullptr
+                             : (loss->actions && loss->adv &&
+                                (loss->algo == 1 || loss->old_ll) &&
+                                (loss->kind == 2 ||
+                                 (loss->lda % 4 == 0 && ga_aligned16(loss->actions) &&
+                                  loss->lda >= ((loss->A + 3) & ~3)))),
+             "ga_fused_fwd_head_loss: missing / misaligned minibatch arrays");
+  GA_REQUIRE(loss->kind == 2 || loss->log_std, "ga_fused_fwd_head_loss: log_std");
+  GA_REQUIRE(loss->algo == 0 || loss->algo == 1, "ga_fused_fwd_head_loss: algo");
+  FwdLossParams p;
+  memset(&p, 0, sizeof(p));
+  p.g.A = A; p.g.lda = lda; p.g.a_idx = a_idx; p.g.B = W; p.g.ldb = ldw;
+  p.g.M = (int)M; p.g.N = width; p.g.K = K; p.g.bias = bias;
+  p.head_W = head_W; p.head_ldw = head_ldw; p.head_bias = head_bias;
+  p.loss = loss_args(loss, M);
+  p.dZ = dZ; p.lddz = lddz; p.hpart = hpart; p.lpart = lpart;
+  const dim3 grid((unsigned)ga_fused_tiles(M));
+  // algorithmic flops of both layers
+  const double flops = 2.0 * (double)M * width * ((double)K + loss->A);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  ga_prof_events(GA_PROF_FUSED_FWD, flops, &e0, &e1);
+  if (width == 64)
+    hipExtLaunchKernelGGL((fwd_head_loss_kernel<64, 2, 2>), grid, dim3(256), 0, stream,
+                          e0, e1, 0, p);
+  else if (width == 128)
+    hipExtLaunchKernelGGL((fwd_head_loss_kernel<128, 1, 4>), grid, dim3(256), 0, stream,
+                          e0, e1, 0, p);
+  else
+    hipExtLaunchKernelGGL((fwd_head_loss_kernel<256, 1, 8>), grid, dim3(512), 0, stream,
+                          e0, e1, 0, p);
+  GA_CHECK_LAUNCH("fwd_head_loss");
+  return GA_OK;
+}
+
+extern "C" int ga_fused_dgrad_wgrad0(const float* dZ2, int64_t lddz, const float* W2,
+                                     int64_t ldw, int64_t M, int width, int K,
+                                     const float* H1, int64_t ldh, const float* X,
+                                     int64_t ldx, const int32_t* idx, int in_w,
+                                     float* wpart, hipStream_t stream) {
+  GA_REQUIRE(dZ2 && W2 && H1 && X && wpart, "ga_fused_dgrad_wgrad0: null pointer");
+  GA_REQUIRE(ga_fused_width_ok(width) && M >= 1 && M < (1ll << 31) && K >= 1 &&
+                 in_w >= 1 && in_w <= 32,
+             "ga_fused_dgrad_wgrad0: unsupported shape");
+  GA_REQUIRE(lddz % 4 == 0 && ldw % 4 == 0 && ldh % 4 == 0 && ldx % 4 == 0 &&
+                 ldx >= ((in_w + 3) & ~3) && ga_aligned16(dZ2) && ga_aligned16(W2) &&
+                 ga_aligned16(H1) && ga_aligned16(X) && ga_aligned16(wpart),
+             "ga_fused_dgrad_wgrad0: operands must be 16-B aligned quads");
+  DgradWgrad0Params p;
+  memset(&p, 0, sizeof(p));
+  p.g.A = dZ2; p.g.lda = lddz; p.g.B = W2; p.g.ldb = ldw;
+  p.g.M = (int)M; p.g.N = width; p.g.K = K;
+  p.H = H1; p.ldh = ldh; p.X = X; p.ldx = ldx; p.idx = idx; p.in_w = in_w;
+  p.wpart = wpart;
+  const dim3 grid((unsigned)ga_fused_tiles(M));
+  const double flops = 2.0 * (double)M * width * ((double)K + in_w);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  ga_prof_events(GA_PROF_FUSED_DGRAD, flops, &e0, &e1);
+  if (width == 64)
+    hipExtLaunchKernelGGL((dgrad_wgrad0_kernel<64, 2, 2>), grid, dim3(256), 0, stream, e0,
+                          e1, 0, p);
+  else if (width == 128)
+    hipExtLaunchKernelGGL((dgrad_wgrad0_kernel<128, 1, 4>), grid, dim3(256), 0, stream,
+                          e0, e1, 0, p);
+  else
+    hipExtLaunchKernelGGL((dgrad_wgrad0_kernel<256, 1, 8>), grid, dim3(512), 0, stream,
+                          e0, e1, 0, p);
+  GA_CHECK_LAUNCH("dgrad_wgrad0");
+  return GA_OK;
+}
+
+extern "C" int ga_reduce_regions_adam(const ga_fused_region* regions, int n_regions,
+                                      float* params, float* grads, float* exp_avg,
+                                      float* exp_avg_sq, int64_t step, double lr,
+                                      double beta1, double beta2, double eps, float scale,
+                                      int do_adam, int zero_slot0, const double* lpart,
+                                      int n_lpart, int64_t M,
+                                      const ga_fused_loss_args* loss, float* loss_out,
+                                      hipStream_t stream) {
+  GA_REQUIRE(regions && params && grads && exp_avg && exp_avg_sq && lpart && loss,
+             "ga_reduce_regions_adam: null pointer");
+  GA_REQUIRE(n_regions >= 1 && n_regions <= FT_MAX_REGIONS && step >= 1 && n_lpart >= 1,
+             "ga_reduce_regions_adam: bad arguments");
+  ReduceRegionsParams p;
+  memset(&p, 0, sizeof(p));
+  int64_t v = 0;
+  for (int k = 0; k < n_regions; ++k) {
+    GA_REQUIRE(regions[k].src && regions[k].n >= 1 && regions[k].n_part >= 1 &&
+                   regions[k].beg >= 1,
+               "ga_reduce_regions_adam: bad region %d", k);
+    p.r[k].beg = regions[k].beg; p.r[k].n = regions[k].n; p.r[k].src = regions[k].src;
+    p.r[k].stride = regions[k].stride; p.r[k].n_part = regions[k].n_part;
+    p.r[k].ways = ways_for(regions[k].n_part);
+    p.r[k].vbeg = v;
+    v += ga_ceil_div(regions[k].n * p.r[k].ways, 64) * 64;
+  }
+  p.n_regions = n_regions;
+  p.n_virtual = v;
+  p.a.p = params; p.a.m = exp_avg; p.a.v = exp_avg_sq;
+  p.a.lerp_w = (float)(1.0 - beta1);
+  p.a.beta2 = (float)beta2;
+  p.a.one_minus_beta2 = (float)(1.0 - beta2);
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  const double bc2 = 1.0 - pow(beta2, (double)step);
+  p.a.neg_step_size = (float)(-(lr / bc1));
+  p.a.bc2_sqrt = (float)sqrt(bc2);
+  p.a.eps = (float)eps;
+  p.grads = grads; p.scale = scale; p.do_adam = do_adam; p.zero_slot0 = zero_slot0;
+  p.lpart = lpart; p.n_lpart = n_lpart; p.M = M;
+  p.loss = loss_args(loss, M);
+  p.loss_out = loss_out;
+  const unsigned blocks = (unsigned)ga_ceil_div(v, 256) + 1;  // + the loss block
+  hipLaunchKernelGGL(reduce_regions_adam_kernel, dim3(blocks), dim3(256), 0, stream, p);
+  GA_CHECK_LAUNCH("reduce_regions_adam");
+  return GA_OK;
+}

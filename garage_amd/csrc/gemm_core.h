@@ -1,0 +1,294 @@
+// The k-loop shared by the fp32 MFMA GEMM kernels (gemm.hip) and the fused
+// training-step kernels built on it (fused_train.hip): operand-tile loader
+// (global -> registers -> LDS) and the MFMA main loop.  See gemm.hip for the
+// layout notes.
+#pragma once
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;
+constexpr int PAD = 4;
+// One LDS stage per operand tile (37 KB per 128x128 workgroup): a second stage
+// (one barrier per k-step instead of two) measured no faster at the K = 256 shapes
+// of this workload, and the small footprint lets the workgroups of the policy and
+// the value-function update chains co-reside on a CU when they run on two streams.
+
+enum Epilogue { EPI_BIAS_ACT = 0, EPI_MUL_DTANH = 1, EPI_PLAIN = 2 };
+
+// tanh(x) = 1 - 2 / (exp(2x) + 1) on the hardware exp / rcp units: 5 VALU
+// instructions instead of libm's ~30 (64 of these per lane per output tile).
+// Absolute error <= ~1.5e-7 over the whole range, saturates cleanly at +-1.
+__device__ __forceinline__ float tanh_fast(float x) {
+  const float e = __expf(2.f * x);
+  return 1.f - 2.f * __frcp_rn(e + 1.f);
+}
+
+struct GemmParams {
+  const float* A;
+  int64_t lda;           // floats between consecutive memory lines of A
+  const int32_t* a_idx;  // optional gather applied to A's memory-line index
+  const float* B;
+  int64_t ldb;
+  const int32_t* b_idx;
+  float* C;
+  int64_t c_rs, c_cs;    // C(m,n) at C[m * c_rs + n * c_cs]
+  int M, N, K;
+  int epi;
+  const float* bias;     // EPI_BIAS_ACT: per-n bias (may be null)
+  int act;               // 0 identity, 1 tanh
+  const float* H;        // EPI_MUL_DTANH (or EPI_BIAS_ACT with H set): tanh
+  int64_t ldh;           // outputs H[m * ldh + n]; the result is scaled by 1 - H^2
+  int accum;             // 1: add the product to what C already holds
+  int k_per_split;       // multiple of BK
+  int64_t c_split_stride;
+  float* colsum;         // optional: sum_k of operand A (or B) -> colsum[line]
+  int colsum_of_b;       // 0: columns of A tile (index m), 1: of B tile (index n)
+  int64_t colsum_split_stride;
+  int gx, gy, gz;        // logical grid (m blocks, n blocks, splits); 1-D launch
+  // HEAD kernels (the tile spans all N columns): the next, narrow layer is applied to
+  // the staged output rows in the epilogue: head_out[m, j] = head_bias[j] +
+  // sum_n C(m, n) * head_W[j * head_ldw + n],  j < head_n <= 8
+  const float* head_W;
+  int64_t head_ldw;
+  const float* head_bias;
+  int head_n;
+  float* head_out;
+  int64_t head_ld;
+};
+
+// One [BR x BK] operand tile: global -> registers -> LDS.
+//   KC = true : memory line = r (tile row), contiguous along k
+//   KC = false: memory line = k,            contiguous along r
+// Every global load is UNCONDITIONAL (indices are clamped into valid memory and
+// the out-of-range lanes are zeroed when the registers are written to LDS):
+// a load inside a data-dependent branch makes hipcc wait vmcnt(0) right behind
+// it, which serialises the whole tile fetch in front of the MFMAs.  The gathered
+// line numbers (`idx`) are fetched one tile ahead for the same reason.
+// FULL: the workgroup's tile rows are entirely inside the matrices, so the clamps
+// and the zero masks (16 v_cndmask per vector pair and k-step) drop out on every
+// k-step but the last (which may be partial).
+template <int BR, bool KC, int NT, int BKT, bool FULL>
+struct TileLoader {
+  static constexpr int NV = BR * BKT / 4 / NT;  // float4 per thread
+  static constexpr int VPR = BKT / 4;           // vectors per row (KC = true)
+  static constexpr int VPL = BR / 4;            // vectors per line (KC = false)
+  float4 regs[NV];
+  int32_t cur[NV];  // memory line (after the optional gather) of each vector
+  int32_t nxt[NV];
+
+  // lines of the first tile (KC: the rows, fixed for the whole kernel)
+  __device__ __forceinline__ void init(const int32_t* __restrict__ idx, int r0,
+                                       int R, int kbeg, int kend) {
+    const int tid = threadIdx.x;
+    int want[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int f = tid + NT * i;
+      want[i] = KC ? min(r0 + f / VPR, R - 1) : min(kbeg + f / VPL, kend - 1);
+      want[i] = max(want[i], 0);
+    }
+    if (idx) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) cur[i] = idx[want[i]];
+    } else {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) cur[i] = want[i];
+    }
+  }
+
+  // KC = false only: lines of the tile that starts at k0 (one tile ahead)
+  __device__ __forceinline__ void prefetch_lines(const int32_t* __restrict__ idx,
+                                                 int k0, int kend) {
+    if (KC) return;
+    const int tid = threadIdx.x;
+    if (idx) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+        nxt[i] = idx[max(min(k0 + (tid + NT * i) / VPL, kend - 1), 0)];
+    } else {
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+        nxt[i] = max(min(k0 + (tid + NT * i) / VPL, kend - 1), 0);
+    }
+  }
+
+  __device__ __forceinline__ void rotate() {
+    if (KC) return;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) cur[i] = nxt[i];
+  }
+
+  // span = number of valid floats along the contiguous direction (K or R)
+  // tail: this is the (possibly partial) last k-step of the block's k range; a
+  // FULL loader still clamps / masks there, so only the tile's row range has to
+  // be interior for the fast path, not its k range
+  __device__ __forceinline__ void load(const float* __restrict__ base, int64_t ld,
+                                       int r0, int k0, int span, bool tail) {
+    const int tid = threadIdx.x;
+    const int last = max(((span + 3) & ~3) - 4, 0);  // last in-bounds vector
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int f = tid + NT * i;
+      const int c = KC ? (k0 + 4 * (f % VPR)) : (r0 + 4 * (f % VPL));
+      regs[i] = *reinterpret_cast<const float4*>(base + (int64_t)cur[i] * ld +
+                                                 ((FULL && !tail) ? c : min(c, last)));
+    }
+  }
+
+  __device__ __forceinline__ void store(float* __restrict__ tile, int r0, int R,
+                                        int k0, int kend, bool tail) const {
+    constexpr int LD = BR + PAD;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int f = tid + NT * i;
+      float4 v = regs[i];
+      if (KC) {
+        const int r = f / VPR;
+        const int k = 4 * (f % VPR);
+        if (!FULL || tail) {
+          const bool row_ok = (r0 + r) < R;
+          v.x = (row_ok && k0 + k + 0 < kend) ? v.x : 0.f;
+          v.y = (row_ok && k0 + k + 1 < kend) ? v.y : 0.f;
+          v.z = (row_ok && k0 + k + 2 < kend) ? v.z : 0.f;
+          v.w = (row_ok && k0 + k + 3 < kend) ? v.w : 0.f;
+        }
+        // k-contiguous in memory stays k-contiguous in LDS: [BR][BK + PAD],
+        // one ds_write_b128 per vector, conflict free (8 lanes = one 128-B row)
+        *reinterpret_cast<float4*>(tile + r * (BKT + PAD) + k) = v;
+      } else {
+        const int k = f / VPL;
+        const int r = 4 * (f % VPL);
+        if (!FULL || tail) {
+          const bool k_ok = (k0 + k) < kend;
+          v.x = (k_ok && r0 + r + 0 < R) ? v.x : 0.f;
+          v.y = (k_ok && r0 + r + 1 < R) ? v.y : 0.f;
+          v.z = (k_ok && r0 + r + 2 < R) ? v.z : 0.f;
+          v.w = (k_ok && r0 + r + 3 < R) ? v.w : 0.f;
+        }
+        *reinterpret_cast<float4*>(tile + k * LD + r) = v;
+      }
+    }
+  }
+};
+
+// The k-loop of one workgroup: global -> registers -> LDS -> MFMA.  FULL selects the
+// mask-free loader (the caller has checked that this workgroup's tile rows are
+// entirely inside the matrices; the last k-step is masked either way).
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KC, bool B_KC, int BKT,
+          bool FULL, int TM, int TN>
+__device__ __forceinline__ void gemm_mainloop(const GemmParams& p, float* lds,
+                                              f32x16 (&acc)[TM][TN], float& csum,
+                                              bool do_colsum, int m0, int n0,
+                                              int kbeg, int kend, int wm0, int wn0) {
+  constexpr int NT = 64 * WAVES_M * WAVES_N;
+  constexpr int LDA_S = BM + PAD, LDB_S = BN + PAD, LDK = BKT + PAD;
+  constexpr int A_FLOATS = A_KC ? BM * LDK : BKT * LDA_S;
+  const int lane = threadIdx.x & 63;
+  TileLoader<BM, A_KC, NT, BKT, FULL> la;
+  TileLoader<BN, B_KC, NT, BKT, FULL> lb;
+  const int a_span = A_KC ? p.K : p.M;  // valid floats along the contiguous axis
+  const int b_span = B_KC ? p.K : p.N;
+  const int nk = (kend - kbeg + BKT - 1) / BKT;
+  float* As = lds;
+  float* Bs = lds + A_FLOATS;
+  if (nk > 0) {
+    la.init(p.a_idx, m0, p.M, kbeg, kend);
+    lb.init(p.b_idx, n0, p.N, kbeg, kend);
+    const bool t0 = nk == 1;
+    la.load(p.A, p.lda, m0, kbeg, a_span, t0);
+    lb.load(p.B, p.ldb, n0, kbeg, b_span, t0);
+    la.prefetch_lines(p.a_idx, kbeg + BKT, kend);
+    lb.prefetch_lines(p.b_idx, kbeg + BKT, kend);
+    la.store(As, m0, p.M, kbeg, kend, t0);
+    lb.store(Bs, n0, p.N, kbeg, kend, t0);
+  }
+  __syncthreads();
+
+  const int half = lane >> 5, l31 = lane & 31;
+  for (int s = 0; s < nk; ++s) {
+    const bool more = (s + 1 < nk);
+    const bool tail = (s + 2 == nk);  // the tile being fetched is the last one
+    const int k_next = kbeg + (s + 1) * BKT;
+    if (more) {
+      la.rotate();
+      lb.rotate();
+      la.load(p.A, p.lda, m0, k_next, a_span, tail);
+      lb.load(p.B, p.ldb, n0, k_next, b_span, tail);
+      la.prefetch_lines(p.a_idx, k_next + BKT, kend);
+      lb.prefetch_lines(p.b_idx, k_next + BKT, kend);
+    }
+    // Groups of 4 MFMAs over 8 physical k: lane half h feeds k = 8g + 4h + q
+    // to step q (any k <-> slot map is valid as long as A and B agree), so a
+    // k-contiguous operand is ONE ds_read_b128 per 4 MFMAs.
+    // (reading the operands of group g + 1 before issuing the MFMAs of group g was
+    // measured: no gain -- 146.0 / 148.2 vs 145.2 / 144.7 ms -- the other waves of
+    // the SIMD cover the LDS round trip already)
+    auto read_frags = [&](float (&a)[TM][4], float (&b)[TN][4], int g) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        if (A_KC) {
+          const float4 v = *reinterpret_cast<const float4*>(
+              As + (wm0 + 32 * i + l31) * LDK + 8 * g + 4 * half);
+          a[i][0] = v.x; a[i][1] = v.y; a[i][2] = v.z; a[i][3] = v.w;
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            a[i][q] = As[(8 * g + 4 * half + q) * LDA_S + wm0 + 32 * i + l31];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if (B_KC) {
+          const float4 v = *reinterpret_cast<const float4*>(
+              Bs + (wn0 + 32 * j + l31) * LDK + 8 * g + 4 * half);
+          b[j][0] = v.x; b[j][1] = v.y; b[j][2] = v.z; b[j][3] = v.w;
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            b[j][q] = Bs[(8 * g + 4 * half + q) * LDB_S + wn0 + 32 * j + l31];
+        }
+      }
+    };
+    auto issue = [&](const float (&a)[TM][4], const float (&b)[TN][4]) {
+      // the wave that is about to issue MFMAs goes ahead of co-resident waves that
+      // are still loading / storing tiles (-0.8 % per C3 iteration, 2 x A/B)
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[j][q],
+                                                             acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    };
+#pragma unroll
+    for (int g = 0; g < BKT / 8; ++g) {
+      float a[TM][4], b[TN][4];
+      read_frags(a, b, g);
+      issue(a, b);
+    }
+    if (do_colsum) {
+      const float* T = p.colsum_of_b ? Bs : As;
+      const int LD = p.colsum_of_b ? LDB_S : LDA_S;
+      const int W = p.colsum_of_b ? BN : BM;
+      if ((int)threadIdx.x < W) {
+#pragma unroll 8
+        for (int k = 0; k < BKT; ++k) csum += T[k * LD + threadIdx.x];
+      }
+    }
+    __syncthreads();
+    if (more) {
+      la.store(As, m0, p.M, k_next, kend, tail);
+      lb.store(Bs, n0, p.N, k_next, kend, tail);
+      __syncthreads();
+    }
+  }
+}
+
+}  // namespace

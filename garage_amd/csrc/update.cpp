@@ -17,6 +17,7 @@
 
 #include "../../include/garage_amd.h"
 #include "small_step.h"
+#include "fused_train.h"
 
 void ga_set_error(const char* fmt, ...);
 
@@ -37,6 +38,63 @@ extern "C" int ga_set_fused_head_loss(int on) {
 
 // small_step.hip: one launch per optimizer step for minibatches of <= 64 rows
 extern "C" int64_t ga_reduction_partials_doubles(void);
+
+// gemm.hip: the backward pass of layers l_start .. 0 given d(loss)/d(pre-activation)
+// of layer l_start in dacts; fused_first: the data gradient into layer 0's output
+// and layer 0's weight gradient are computed elsewhere (ga_fused_dgrad_wgrad0)
+extern "C" int ga_mlp_backward_range_f32(const ga_mlp_desc* d, const float* params,
+                                         const float* X, int64_t ldx,
+                                         const int32_t* row_idx, int64_t M,
+                                         const float* acts, const float* dout,
+                                         int64_t ldo, float* dacts, float* grad_slabs,
+                                         int64_t slab_stride, int64_t n_splits,
+                                         int l_start, int fused_first,
+                                         ga_stream_t stream);
+
+// The optimizer step with the streaming passes folded into the GEMM epilogues
+// (fused_train.hip) for networks whose last hidden layer is 64 / 128 / 256 wide
+// with a head of <= 8 outputs; 0 = the per-layer kernels (A/B runs, tests).
+static int g_fused_train = 1;
+extern "C" int ga_set_fused_train(int on) {
+  g_fused_train = on != 0;
+  return 0;
+}
+
+namespace {
+struct FusedPlan {
+  bool ok = false;
+  bool first = false;     // data gradient into layer 0 + its weight gradient fused too
+  int64_t tiles = 0;
+  int64_t lpart_off = 0, hpart_off = 0, wpart_off = 0, floats = 0;
+  int64_t hstride = 0, wstride = 0;
+};
+
+// Layout of the partial-sum scratch for M rows (floats): [tiles][2] doubles of loss
+// sums, [tiles][8 W + 8] head shares, [tiles][W1 ld0 + W1] first-layer shares.
+FusedPlan fused_plan(const ga_mlp_desc* d, int64_t M) {
+  FusedPlan f;
+  const int L = d->n_layers;
+  if (L < 2 || L > 8 || M < 1) return f;
+  if (!ga_fused_width_ok(d->dims[L - 1]) || d->dims[L] > 8) return f;
+  f.ok = true;
+  f.tiles = ga_fused_tiles(M);
+  f.first = L >= 3 && ga_fused_width_ok(d->dims[1]) && d->dims[0] <= 32;
+  f.hstride = 8 * (int64_t)d->dims[L - 1] + 8;
+  const int64_t ld0 = (d->dims[0] + 3) & ~3;
+  f.wstride = f.first ? (int64_t)d->dims[1] * ld0 + d->dims[1] : 0;
+  f.lpart_off = 0;
+  f.hpart_off = 4 * f.tiles;
+  f.wpart_off = f.hpart_off + f.tiles * f.hstride;
+  f.floats = f.wpart_off + f.tiles * f.wstride;
+  return f;
+}
+}  // namespace
+
+extern "C" int64_t ga_update_partials_floats(const ga_mlp_desc* d, int64_t M) {
+  if (!d) return 0;
+  const FusedPlan f = fused_plan(d, M);
+  return f.ok ? f.floats : 0;
+}
 
 static int g_small_step = 1;
 extern "C" int ga_set_small_step(int on) {
@@ -111,6 +169,124 @@ void minibatch_range(const ga_update_args* a, int64_t k, int64_t* start, int64_t
   *M = (*start + mb <= a->S) ? mb : a->S - *start;
 }
 
+// the exchange + optimizer tail of a data-parallel step: grads hold this rank's
+// scaled gradient
+int allreduce_and_adam(const ga_update_args* a, int64_t k, ga_stream_t stream,
+                       const ArOrder* order) {
+  if (!g_allreduce) {
+    ga_set_error("ga_update_epoch: no all-reduce hook installed");
+    return -1;
+  }
+  if (order && order->wait_for &&
+      hipStreamWaitEvent((hipStream_t)stream, order->wait_for, 0) != hipSuccess) {
+    ga_set_error("ga_update_epoch: hipStreamWaitEvent failed");
+    return -2;
+  }
+  int rc = g_allreduce(a->comm, a->grads, a->n_flat, stream);
+  if (rc) {
+    ga_set_error("ga_update_epoch: all-reduce failed (%d)", rc);
+    return -2;
+  }
+  if (order && order->record &&
+      hipEventRecord(order->record, (hipStream_t)stream) != hipSuccess) {
+    ga_set_error("ga_update_epoch: hipEventRecord failed");
+    return -2;
+  }
+  return ga_adam_step_f32(a->params, a->grads, a->exp_avg, a->exp_avg_sq, a->n_flat,
+                          a->step0 + k + 1, a->lr, a->beta1, a->beta2, a->eps, stream);
+}
+
+float step_scale(const ga_update_args* a, int64_t k) {
+  if (!a->comm && a->phase != 1) return 1.f;
+  return (a->grad_scales_host && a->perm && a->n_mb > 0) ? a->grad_scales_host[k]
+                                                          : a->grad_scale;
+}
+
+// One optimizer step on the fused kernels: hidden layers 0 .. L-3 per layer, then
+// last hidden layer + head + loss + gradient seed in one launch, the middle
+// layers' backward GEMMs, the data gradient into the first hidden layer with the
+// first layer's weight gradient in one launch, and one reduction + Adam launch.
+int run_minibatch_fused(const ga_update_args* a, const FusedPlan& f, int64_t k,
+                        int64_t M, const int32_t* idx, float* loss_slot,
+                        ga_stream_t stream_, const ArOrder* order) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const ga_mlp_desc* d = a->desc;
+  const int L = d->n_layers;
+  const int out_w = d->dims[L];
+  const int64_t splits = ga_mlp_backward_splits(d, M);
+  if (splits > a->max_splits) {
+    ga_set_error("ga_update_epoch: slab workspace too small");
+    return -1;
+  }
+  auto r4 = [](int v) { return (int64_t)((v + 3) & ~3); };
+  int rc;
+  if (L >= 3) {
+    ga_mlp_desc below = *d;  // layers 0 .. L-3: the hidden layers under the last one
+    below.n_layers = L - 1;
+    rc = ga_mlp_forward_f32(&below, a->params, a->X, a->ldx, idx, M, a->acts, nullptr,
+                            a->ldo, stream_);
+    if (rc) return rc;
+  }
+  ga_fused_loss_args la;
+  memset(&la, 0, sizeof(la));
+  la.kind = a->kind; la.actions = a->actions; la.lda = a->lda; la.old_ll = a->old_ll;
+  la.adv = a->adv; la.returns = a->returns; la.idx = idx; la.log_std = a->params;
+  la.has_min = a->has_min; la.has_max = a->has_max; la.min_log_std = a->min_log_std;
+  la.max_log_std = a->max_log_std; la.A = out_w; la.algo = a->algo; la.clip = a->clip;
+  la.ent_coeff = a->ent_coeff; la.ent_flags = a->ent_flags;
+  la.double_softmax = a->double_softmax;
+  double* lpart = reinterpret_cast<double*>(a->partials + f.lpart_off);
+  float* hpart = a->partials + f.hpart_off;
+  float* wpart = a->partials + f.wpart_off;
+  const int wl = d->dims[L - 1];  // last hidden width
+  const float* Ain = L >= 3 ? a->acts + d->act_off[L - 3] : a->X;
+  rc = ga_fused_fwd_head_loss(Ain, L >= 3 ? r4(d->dims[L - 2]) : a->ldx,
+                              L >= 3 ? nullptr : idx, a->params + d->w_off[L - 2],
+                              r4(d->dims[L - 2]), a->params + d->b_off[L - 2], M, wl,
+                              d->dims[L - 2], a->params + d->w_off[L - 1], r4(wl),
+                              a->params + d->b_off[L - 1], &la,
+                              a->dacts + d->act_off[L - 2], r4(wl), hpart, lpart, stream);
+  if (rc) return rc;
+  rc = ga_mlp_backward_range_f32(d, a->params, a->X, a->ldx, idx, M, a->acts, nullptr,
+                                 a->ldo, a->dacts, a->slabs, a->n_flat, splits, L - 2,
+                                 f.first ? 1 : 0, stream);
+  if (rc) return rc;
+  if (f.first) {
+    rc = ga_fused_dgrad_wgrad0(a->dacts + d->act_off[1], r4(d->dims[2]),
+                               a->params + d->w_off[1], r4(d->dims[1]), M, d->dims[1],
+                               d->dims[2], a->acts + d->act_off[0], r4(d->dims[1]), a->X,
+                               a->ldx, idx, d->dims[0], wpart, stream);
+    if (rc) return rc;
+  }
+  ga_fused_region reg[16];
+  int nr = 0;
+  for (int l = 0; l < L; ++l) {
+    const int64_t wn = (int64_t)d->dims[l + 1] * r4(d->dims[l]);
+    ga_fused_region& w = reg[nr++];
+    ga_fused_region& b = reg[nr++];
+    w.beg = d->w_off[l]; w.n = wn;
+    b.beg = d->b_off[l]; b.n = d->dims[l + 1];
+    if (l == L - 1) {
+      w.src = hpart; b.src = hpart + 8 * (int64_t)wl;
+      w.stride = b.stride = f.hstride; w.n_part = b.n_part = (int)f.tiles;
+    } else if (l == 0 && f.first) {
+      w.src = wpart; b.src = wpart + wn;
+      w.stride = b.stride = f.wstride; w.n_part = b.n_part = (int)f.tiles;
+    } else {
+      w.src = a->slabs + d->w_off[l]; b.src = a->slabs + d->b_off[l];
+      w.stride = b.stride = a->n_flat; w.n_part = b.n_part = (int)splits;
+    }
+  }
+  const bool exchange = a->comm && a->phase != 1;
+  const bool do_adam = !exchange && a->phase != 1;
+  rc = ga_reduce_regions_adam(reg, nr, a->params, a->grads, a->exp_avg, a->exp_avg_sq,
+                              a->step0 + k + 1, a->lr, a->beta1, a->beta2, a->eps,
+                              step_scale(a, k), do_adam ? 1 : 0, !a->learn_std, lpart,
+                              (int)f.tiles, M, &la, loss_slot, stream);
+  if (rc || !exchange) return rc;
+  return allreduce_and_adam(a, k, stream_, order);
+}
+
 int run_minibatch(const ga_update_args* a, int64_t k, ga_stream_t stream,
                   const ArOrder* order = nullptr) {
   int64_t start, M;
@@ -127,7 +303,7 @@ int run_minibatch(const ga_update_args* a, int64_t k, ga_stream_t stream,
   // a minibatch of <= 64 rows through a 2 x H net: the whole step in one launch
   // (the activation workspaces, unused on that path, carry its two exchanges:
   // they hold min(S, mb) x 2H floats each, enough from 32 rows up)
-  if (g_small_step && !g_fuse_head && !a->comm && a->kind >= 0 && a->kind <= 2 &&
+  if (g_small_step && !g_fuse_head && !a->comm && a->phase != 1 && a->kind >= 0 && a->kind <= 2 &&
       (a->algo == 0 || a->algo == 1) && a->acts && a->dacts &&
       workspace_rows(a) >= 32 &&
       ga_small_step_supported(L, a->desc->dims, M) &&
@@ -155,6 +331,12 @@ int run_minibatch(const ga_update_args* a, int64_t k, ga_stream_t stream,
     s.fault = reinterpret_cast<int*>(tail + 1);
     s.loss_out = loss_slot;
     return ga_small_step(&s, stream);
+  }
+  if (g_fused_train && !g_fuse_head && a->partials && a->kind >= 0 && a->kind <= 2 &&
+      (a->algo == 0 || a->algo == 1) && a->acts && a->dacts) {
+    const FusedPlan f = fused_plan(a->desc, M);
+    if (f.ok && f.floats <= a->partials_floats)
+      return run_minibatch_fused(a, f, k, M, idx, loss_slot, stream, order);
   }
   // the head layer (hidden -> means / value) is computed inside the loss kernel
   // when its shape allows: no narrow GEMM launch, no round trip of its output
@@ -201,7 +383,7 @@ int run_minibatch(const ga_update_args* a, int64_t k, ga_stream_t stream,
                            a->dout, a->ldo, a->dacts, a->slabs, a->n_flat, splits,
                            stream);
   if (rc) return rc;
-  if (!a->comm) {
+  if (!a->comm && a->phase != 1) {
     // single process: slab sum and Adam in one launch
     return ga_reduce_adam_f32(a->slabs, splits, a->n_flat, a->params, a->grads,
                               a->exp_avg, a->exp_avg_sq, a->n_flat, a->step0 + k + 1,
@@ -210,10 +392,8 @@ int run_minibatch(const ga_update_args* a, int64_t k, ga_stream_t stream,
   }
   // data parallel: the global gradient is the sample-count weighted sum of the
   // rank gradients (mean over the union of the shards)
-  const float scale = (a->grad_scales_host && a->perm && a->n_mb > 0)
-                          ? a->grad_scales_host[k] : a->grad_scale;
-  rc = ga_reduce_slabs_f32(a->slabs, splits, a->n_flat, a->n_flat, scale, a->grads,
-                           stream);
+  rc = ga_reduce_slabs_f32(a->slabs, splits, a->n_flat, a->n_flat, step_scale(a, k),
+                           a->grads, stream);
   if (rc) return rc;
   if (!a->learn_std) {
     if (hipMemsetAsync(a->grads, 0, sizeof(float), (hipStream_t)stream) !=
@@ -222,28 +402,8 @@ int run_minibatch(const ga_update_args* a, int64_t k, ga_stream_t stream,
       return -2;
     }
   }
-  if (!g_allreduce) {
-    ga_set_error("ga_update_epoch: no all-reduce hook installed");
-    return -1;
-  }
-  if (order && order->wait_for &&
-      hipStreamWaitEvent((hipStream_t)stream, order->wait_for, 0) != hipSuccess) {
-    ga_set_error("ga_update_epoch: hipStreamWaitEvent failed");
-    return -2;
-  }
-  rc = g_allreduce(a->comm, a->grads, a->n_flat, stream);
-  if (rc) {
-    ga_set_error("ga_update_epoch: all-reduce failed (%d)", rc);
-    return -2;
-  }
-  if (order && order->record &&
-      hipEventRecord(order->record, (hipStream_t)stream) != hipSuccess) {
-    ga_set_error("ga_update_epoch: hipEventRecord failed");
-    return -2;
-  }
-  return ga_adam_step_f32(a->params, a->grads, a->exp_avg, a->exp_avg_sq, a->n_flat,
-                          a->step0 + k + 1, a->lr, a->beta1, a->beta2, a->eps,
-                          stream);
+  if (a->phase == 1) return 0;  // the caller exchanges and steps
+  return allreduce_and_adam(a, k, stream, order);
 }
 
 }  // namespace

@@ -138,6 +138,20 @@ class FlatMLP:
                 self._desc.act_off[l] = self.act_off[l] * cap
             self._cap = cap
 
+    def train_partials(self, rows):
+        """Scratch of the fused optimizer-step kernels for minibatches of up to
+        ``rows`` rows (``ga_update_partials_floats``); ``None`` when this
+        network's shapes take the per-layer kernels."""
+        n = int(_lib.load().ga_update_partials_floats(C.byref(self._desc),
+                                                      int(rows)))
+        if n <= 0:
+            return None
+        if getattr(self, '_partials', None) is None or \
+                self._partials.numel() < n:
+            self._partials = torch.zeros(n, dtype=torch.float32,
+                                         device=self.device)
+        return self._partials
+
     def out_view(self, M):
         return self._out[:M * self.ld_out].view(M, self.ld_out)
 

@@ -454,8 +454,30 @@ typedef struct {
   const float* grad_scales_host; /* optional HOST array [n_mb]: per-minibatch
                                 replacement of grad_scale (rows of this rank's
                                 minibatch k / rows of the global minibatch k) */
+  float* partials;           /* optional scratch for the fused step kernels: with at
+                                least ga_update_partials_floats(desc, rows of the
+                                largest minibatch) floats the step takes them (last
+                                hidden layer + head + loss + gradient seed in one
+                                launch, ...; see ga_set_fused_train) */
+  int64_t partials_floats;
+  int32_t phase;             /* 0: whole steps.  1: gradients only -- forward, loss,
+                                backward, slab sum scaled by grad_scale into `grads`;
+                                no all-reduce, no optimizer (the Python minibatch
+                                loop exchanges and steps itself) */
 } ga_update_args;
 int ga_update_epoch(const ga_update_args* args, ga_stream_t stream);
+/* Floats of `partials` scratch the fused step needs for minibatches of up to M rows
+ * of this network; 0: the network's shapes take the per-layer kernels (last hidden
+ * layer not 64 / 128 / 256 wide, or a head of more than 8 outputs). */
+int64_t ga_update_partials_floats(const ga_mlp_desc* desc, int64_t M);
+/* 1 (default): ga_update_epoch* steps take the fused kernels when `partials` is
+ * given and the shapes allow: the last hidden layer, the head layer, the loss with
+ * its gradient seed and the head's weight gradient in ONE launch (the hidden
+ * activation never reaches HBM), the data gradient into the first hidden layer and
+ * the first layer's weight gradient in one launch, one reduction + Adam launch
+ * that also finishes the loss.  Same formulas, other summation orders than the
+ * per-layer kernels (0 selects those): results agree to rounding. */
+int ga_set_fused_train(int on);
 /* The policy pass and the value-function pass of one epoch, minibatch by
  * minibatch alternately on two streams.  The reference runs them back to back
  * (vpg.py:244-248); they share no written state, so the results are identical

@@ -1,0 +1,179 @@
+"""The fused optimizer-step kernels (fused_train.hip) against the per-layer path.
+
+``ga_update_epoch*`` takes the fused kernels by default when the network's last
+hidden layer is 64 / 128 / 256 units wide: last hidden layer + head + loss +
+gradient seed + head weight gradient in one launch, data gradient into the first
+hidden layer + first-layer weight gradient in one launch, one reduction + Adam
+launch (``VPG._train_policy`` / ``_train_value_function``, torch/algos/vpg.py
+:250-293).  Oracle / golden parity of that default path is what every iteration
+test of this suite checks (test_ppo_gpu, test_configs_gpu, test_kernels_gpu ...);
+here the two paths of the library are held against each other gradient by
+gradient, on shapes that exercise every branch: each tile width, one to three
+hidden layers, Gaussian / categorical / value heads, VPG and PPO objectives,
+entropy terms, ragged last tiles, gathered rows.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CASES = {
+    # O, A, hidden, minibatch, discrete, algo keywords
+    'c3_shape': (17, 6, (256, 256), 4096, False, {}),
+    'c2_shape_categorical': (4, 2, (64, 64), 1024, True, {}),
+    'ragged_tiles_128': (9, 3, (128, 128), 1000, False, {}),
+    'three_hidden': (11, 5, (128, 64, 128), 777, False, {}),
+    'one_hidden': (12, 4, (128, ), 640, False, {}),
+    'wide_first_narrow_last': (7, 8, (96, 64), 513, False, {}),
+    'wide_input': (40, 2, (64, 256), 900, False, {}),
+    'vpg': (6, 3, (64, 64), 333, False, {'vpg': True}),
+    'entropy_regularized': (6, 3, (128, 256), 500, False,
+                            {'entropy_method': 'regularized',
+                             'policy_ent_coeff': 0.02,
+                             'use_softplus_entropy': True}),
+    'categorical_max_entropy': (5, 4, (64, 128), 450, True,
+                                {'entropy_method': 'max',
+                                 'policy_ent_coeff': 0.01, 'center_adv': False,
+                                 'stop_entropy_gradient': True}),
+    'full_batch': (8, 2, (64, 64), None, False, {}),
+}
+
+
+def _problem(case):
+    from garage_amd._dtypes import Box, Discrete, EnvSpec, EpisodeBatch, StepType
+    O, A, hidden, mb, discrete, kw = CASES[case]
+    P = 40
+    act_space = Discrete(A) if discrete else Box(-np.inf, np.inf, (A, ))
+    spec = EnvSpec(Box(-np.inf, np.inf, (O, )), act_space, max_episode_length=P)
+    rng = np.random.RandomState(len(case))
+    lens = rng.randint(5, P + 1, size=230)
+    lens[0] = P
+    S = int(lens.sum())
+    st = []
+    for n in lens:
+        t = [1] * n
+        t[0] = 0
+        t[-1] = 3 if n == P else 2
+        st += t
+    acts = (rng.randint(0, A, size=S).astype(np.int64) if discrete else
+            rng.randn(S, A).astype(np.float32))
+    batch = EpisodeBatch(env_spec=spec, episode_infos={},
+                         observations=rng.randn(S, O).astype(np.float32),
+                         last_observations=np.zeros((len(lens), O), np.float32),
+                         actions=acts, rewards=rng.randn(S), env_infos={},
+                         agent_infos={},
+                         step_types=np.asarray([StepType(s) for s in st],
+                                               dtype=object),
+                         lengths=lens.astype('l'))
+    return spec, batch
+
+
+def _algo(case, spec, opt, epochs=1):
+    from garage_amd.algos import PPO, VPG
+    from garage_amd.optimizers import OptimizerWrapper
+    from garage_amd.policies import (CategoricalMLPPolicy, GaussianMLPPolicy,
+                                     GaussianMLPValueFunction)
+    O, A, hidden, mb, discrete, kw = CASES[case]
+    kw = dict(kw)
+    cls = VPG if kw.pop('vpg', False) else PPO
+    torch.manual_seed(3)
+    pol_cls = CategoricalMLPPolicy if discrete else GaussianMLPPolicy
+    pol = pol_cls(spec, hidden_sizes=hidden)
+    vf = GaussianMLPValueFunction(spec, hidden_sizes=hidden)
+    # biases and the log-std away from their zero initialisation
+    for net in (pol.net, vf.net):
+        g = torch.Generator(device='cpu').manual_seed(5)
+        for l in range(len(net.dims) - 1):
+            net.bias(l).copy_(0.1 * torch.randn(net.dims[l + 1], generator=g))
+        if net is vf.net or not discrete:
+            net.params[0] = -0.3
+    algo = cls(env_spec=spec, policy=pol, value_function=vf, sampler=None,
+               policy_optimizer=OptimizerWrapper(opt, pol, epochs, mb),
+               vf_optimizer=OptimizerWrapper(opt, vf, epochs, mb), **kw)
+    return algo, pol, vf
+
+
+@pytest.mark.parametrize('case', sorted(CASES))
+def test_fused_step_gradients_match_per_layer_path(case):
+    """Adam with beta1 = beta2 = 0 and eps = 1 moves a parameter by
+    -lr g / (|g| + 1): (new - old) / lr exposes the gradients of every step of a
+    pass over the batch (several minibatches, the last one ragged)."""
+    from garage_amd import _lib
+    lib = _lib.load()
+    spec, batch = _problem(case)
+    lr = 1e-3
+    out = {}
+    try:
+        for on in (1, 0):
+            lib.ga_set_fused_train(on)
+            algo, pol, vf = _algo(
+                case, spec, (torch.optim.Adam, dict(lr=lr, betas=(0.0, 0.0),
+                                                    eps=1.0)))
+            p0, v0 = pol.net.params.clone(), vf.net.params.clone()
+            np.random.seed(11)
+            algo._train_once(0, batch)
+            out[on] = ((pol.net.params - p0) / lr, (vf.net.params - v0) / lr,
+                       dict(algo.last_tabular))
+    finally:
+        lib.ga_set_fused_train(1)
+    for i in (0, 1):
+        scale = float(out[0][i].abs().max())
+        assert scale > 1e-3  # the pass did move the parameters
+        d = float((out[1][i] - out[0][i]).abs().max())
+        assert d < 1e-4 * scale + 4e-5, (i, d, scale)
+    for k, v in out[0][2].items():
+        assert np.isclose(out[1][2][k], v, rtol=2e-5, atol=2e-6), (k, v,
+                                                                  out[1][2][k])
+
+
+@pytest.mark.parametrize('case', ['c3_shape', 'c2_shape_categorical',
+                                  'three_hidden'])
+def test_fused_step_python_loop_and_native_loop_are_the_same_bits(case):
+    """A subclass that hooks ``_train_policy`` forces the Python minibatch loop,
+    which drives the same entry point one minibatch at a time: same bits as the
+    C++ epoch loop, on one stream and on two."""
+    from garage_amd.algos import PPO
+    spec, batch = _problem(case)
+    opt = (torch.optim.Adam, dict(lr=1e-3))
+    res = []
+    for mode in ('pair', 'serial', 'python'):
+        algo, pol, vf = _algo(case, spec, opt, epochs=2)
+        if mode == 'python':
+            def train_policy(*args, _orig=algo._train_policy):
+                return _orig(*args)
+            # instance attribute is not enough for _native_update_ok: subclass
+            algo.__class__ = type('Hooked', (algo.__class__, ), {
+                '_train_policy': lambda self, *a: PPO._train_policy(self, *a)})
+            assert not algo._native_update_ok()
+        algo.overlap_updates = mode == 'pair'
+        np.random.seed(11)
+        algo._train_once(0, batch)
+        res.append((pol.net.params.clone(), vf.net.params.clone(),
+                    dict(algo.last_tabular)))
+    for other in res[1:]:
+        assert torch.equal(res[0][0], other[0])
+        assert torch.equal(res[0][1], other[1])
+        assert res[0][2] == other[2]
+
+
+def test_fused_step_is_reproducible_and_actually_taken():
+    """Two runs from the same state give the same bits, and switching the fused
+    kernels off changes the bits (i.e. the default path really is the fused one)."""
+    from garage_amd import _lib
+    lib = _lib.load()
+    spec, batch = _problem('c3_shape')
+    opt = (torch.optim.Adam, dict(lr=1e-3))
+    res = []
+    try:
+        for on in (1, 1, 0):
+            lib.ga_set_fused_train(on)
+            algo, pol, vf = _algo('c3_shape', spec, opt, epochs=2)
+            np.random.seed(11)
+            algo._train_once(0, batch)
+            res.append((pol.net.params.clone(), vf.net.params.clone()))
+    finally:
+        lib.ga_set_fused_train(1)
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert not torch.equal(res[0][0], res[2][0])
+    assert float((res[0][0] - res[2][0]).abs().max()) < 5e-4
