@@ -143,7 +143,10 @@ KIND_NAMES = [
     'gae_scan_rows_kernel / gae_scan_kernel',
     'skinny_fwd_kernel (first-layer forward / head data grad; work = bytes)',
     'skinny_wgrad_kernel (first-layer / head weight grad; work = bytes)',
+    'fwd_head_loss_kernel<256,1,8> (last hidden layer + head + loss + seed)',
+    'dgrad_wgrad0_kernel<256,1,8> (data grad + first-layer weight grad)',
 ]
+GEMM_KINDS = (0, 1, 2, 3, 4, 5, 9, 10)  # MFMA kernels: work = flops
 
 
 TRAFFIC_FILE = 'profiles/r01_traffic.json'
@@ -240,11 +243,16 @@ def roofline_pass(algo, sampler, pol, S, itr):
     rows = []
     # layers of at most 64 units run the wide kinds on 64x64 tiles (4 waves)
     small = max(algo.policy.net.hidden_sizes) <= 64
+    width = max(algo.policy.net.hidden_sizes)
     for k in range(n_kinds):
         ms, work, cnt = out[3 * k], out[3 * k + 1], out[3 * k + 2]
         name = KIND_NAMES[k]
         if small:
             name = name.replace('<128,128,2,4,', '<64,64,2,2,')
+        if width == 64:
+            name = name.replace('<256,1,8>', '<64,2,2>')
+        elif width == 128:
+            name = name.replace('<256,1,8>', '<128,1,4>')
         rows.append(dict(kernel=name, total_ms=ms, work=work,
                          launches=int(cnt)))
     return rows
@@ -451,7 +459,7 @@ def main():
     line['grad_allreduce'] = exchange
     line['rccl_ranks'] = rccl_ranks
     if rows is not None:
-        gemms = [r for r in rows[:6] if r['launches'] > 0]
+        gemms = [rows[k] for k in GEMM_KINDS if rows[k]['launches'] > 0]
         dom = max(gemms, key=lambda r: r['total_ms'])
         tflops = dom['work'] / (dom['total_ms'] * 1e-3) / 1e12
         line['roofline'] = {
@@ -485,7 +493,7 @@ def main():
         # all GEMM launches of the iteration against its wall time: with the two
         # update chains overlapped, per-kernel durations include time sharing,
         # so this aggregate is the utilisation figure that adds up
-        all_flops = sum(r['work'] for r in rows[:6])
+        all_flops = sum(rows[k]['work'] for k in GEMM_KINDS)
         agg = all_flops / (ms_per_step * 1e-3) / 1e12
         line['mfma_aggregate'] = {
             'achieved': agg, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',

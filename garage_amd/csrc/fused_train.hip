@@ -26,7 +26,7 @@
 //   reduce_regions_adam_kernel   the optimizer step over per-region partial sums
 //       (split-K slabs of the weight-gradient GEMMs, per-workgroup partials of
 //       the two kernels above), each element summed in a fixed order by `ways`
-//       adjacent lanes; one extra block finishes the loss (batch sums -> loss
+//       lane groups; one extra block finishes the loss (batch sums -> loss
 //       value, log-std gradient) and steps the log-std slot.
 //       torch.optim.Adam arithmetic as in losses.hip.
 //
@@ -465,11 +465,11 @@ __device__ __forceinline__ void ft_adam_update(const FtAdam& a, float g, float& 
 constexpr int FT_MAX_REGIONS = 16;
 struct FtRegion {
   int64_t beg;        // first flat parameter index
-  int64_t n;          // elements
+  int64_t n;          // elements (a multiple of 4)
   const float* src;   // partial 0 of element 0
   int64_t stride;     // floats between consecutive partials
   int n_part;
-  int ways;           // adjacent lanes that share an element's partials (1, 2, 4, 8)
+  int ways;           // lane groups of a wave that share the partials (1, 2, 4, 8)
   int64_t vbeg;       // first virtual thread (a multiple of 64)
 };
 struct ReduceRegionsParams {
@@ -513,45 +513,69 @@ __global__ __launch_bounds__(256) void reduce_regions_adam_kernel(ReduceRegionsP
     }
     return;
   }
+  // A virtual thread = (4 adjacent elements, one of `ways` shares of the partials);
+  // a wave belongs to one region (vbeg are multiples of 64) and covers 64 / ways
+  // quads: lanes [way * Q, (way + 1) * Q) walk the same 16 Q contiguous bytes of
+  // their partials, so every load instruction moves whole 16-B-per-lane segments.
   const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  // a wave belongs to one region (vbeg are multiples of 64)
-  int ri = -1;
+  int ri = 0;
 #pragma unroll 1
-  for (int k = 0; k < p.n_regions; ++k)
+  for (int k = 1; k < p.n_regions; ++k)
     if (v >= p.r[k].vbeg) ri = k;
-  if (ri < 0) return;
   const FtRegion& R = p.r[ri];
   const int ways = R.ways;
-  const int64_t local = v - R.vbeg;
-  const int64_t e = local / ways;
-  const int way = (int)(local % ways);
-  const bool on = e < R.n;
+  const int lane = threadIdx.x & 63;
+  const int Q = 64 / ways;
+  const int way = lane / Q;
+  const int64_t wave0 = (v - lane - R.vbeg) / ways;  // first quad of this wave
+  const int64_t e4 = wave0 + (lane % Q);             // this lane's quad
+  const bool on = 4 * e4 < R.n;
   const int chunk = (R.n_part + ways - 1) / ways;
   const int p0 = way * chunk, p1 = min(R.n_part, p0 + chunk);
-  float acc = 0.f;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   if (on) {
-    const float* s = R.src + e;
+    const float* s = R.src + 4 * e4;
     int k = p0;
     for (; k + 4 <= p1; k += 4) {
-      const float v0 = s[(int64_t)k * R.stride], v1 = s[(int64_t)(k + 1) * R.stride];
-      const float v2 = s[(int64_t)(k + 2) * R.stride], v3 = s[(int64_t)(k + 3) * R.stride];
-      acc += (v0 + v1) + (v2 + v3);
+      const float4 v0 = *reinterpret_cast<const float4*>(s + (int64_t)k * R.stride);
+      const float4 v1 = *reinterpret_cast<const float4*>(s + (int64_t)(k + 1) * R.stride);
+      const float4 v2 = *reinterpret_cast<const float4*>(s + (int64_t)(k + 2) * R.stride);
+      const float4 v3 = *reinterpret_cast<const float4*>(s + (int64_t)(k + 3) * R.stride);
+      acc.x += (v0.x + v1.x) + (v2.x + v3.x);
+      acc.y += (v0.y + v1.y) + (v2.y + v3.y);
+      acc.z += (v0.z + v1.z) + (v2.z + v3.z);
+      acc.w += (v0.w + v1.w) + (v2.w + v3.w);
     }
-    for (; k < p1; ++k) acc += s[(int64_t)k * R.stride];
+    for (; k < p1; ++k) {
+      const float4 v0 = *reinterpret_cast<const float4*>(s + (int64_t)k * R.stride);
+      acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
+    }
   }
   // the ways' sums, added in way order (every lane of the wave takes part)
-  const int lane = threadIdx.x & 63;
-  const int base = lane - way;
-  float g = 0.f;
-  for (int w = 0; w < ways; ++w) g += __shfl(acc, base + w, 64);
+  float g[4] = {0.f, 0.f, 0.f, 0.f};
+  const int peer = lane % Q;
+  for (int w = 0; w < ways; ++w) {
+    g[0] += __shfl(acc.x, peer + w * Q, 64);
+    g[1] += __shfl(acc.y, peer + w * Q, 64);
+    g[2] += __shfl(acc.z, peer + w * Q, 64);
+    g[3] += __shfl(acc.w, peer + w * Q, 64);
+  }
   if (!on || way != 0) return;
-  g *= p.scale;
-  const int64_t i = R.beg + e;
-  p.grads[i] = g;
+  const int64_t i = R.beg + 4 * e4;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) g[j] *= p.scale;
+  *reinterpret_cast<float4*>(p.grads + i) = make_float4(g[0], g[1], g[2], g[3]);
   if (p.do_adam) {
-    float pp = p.a.p[i], mm = p.a.m[i], vv = p.a.v[i];
-    ft_adam_update(p.a, g, pp, mm, vv);
-    p.a.p[i] = pp; p.a.m[i] = mm; p.a.v[i] = vv;
+    float4 p4 = *reinterpret_cast<float4*>(p.a.p + i);
+    float4 m4 = *reinterpret_cast<float4*>(p.a.m + i);
+    float4 v4 = *reinterpret_cast<float4*>(p.a.v + i);
+    float pp[4] = {p4.x, p4.y, p4.z, p4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w},
+          vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ft_adam_update(p.a, g[j], pp[j], mm[j], vv[j]);
+    *reinterpret_cast<float4*>(p.a.p + i) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+    *reinterpret_cast<float4*>(p.a.m + i) = make_float4(mm[0], mm[1], mm[2], mm[3]);
+    *reinterpret_cast<float4*>(p.a.v + i) = make_float4(vv[0], vv[1], vv[2], vv[3]);
   }
 }
 
@@ -685,14 +709,19 @@ extern "C" int ga_reduce_regions_adam(const ga_fused_region* regions, int n_regi
   memset(&p, 0, sizeof(p));
   int64_t v = 0;
   for (int k = 0; k < n_regions; ++k) {
+    // regions are walked 4 elements at a time: the flat layout pads every weight
+    // row and bias vector to a multiple of 4 floats, and the padding of every
+    // partial is zero, so a region is rounded up to whole quads
     GA_REQUIRE(regions[k].src && regions[k].n >= 1 && regions[k].n_part >= 1 &&
-                   regions[k].beg >= 1,
+                   regions[k].beg >= 4 && regions[k].beg % 4 == 0 &&
+                   regions[k].stride % 4 == 0 && ga_aligned16(regions[k].src),
                "ga_reduce_regions_adam: bad region %d", k);
-    p.r[k].beg = regions[k].beg; p.r[k].n = regions[k].n; p.r[k].src = regions[k].src;
+    p.r[k].beg = regions[k].beg; p.r[k].n = (regions[k].n + 3) & ~(int64_t)3;
+    p.r[k].src = regions[k].src;
     p.r[k].stride = regions[k].stride; p.r[k].n_part = regions[k].n_part;
     p.r[k].ways = ways_for(regions[k].n_part);
     p.r[k].vbeg = v;
-    v += ga_ceil_div(regions[k].n * p.r[k].ways, 64) * 64;
+    v += ga_ceil_div(p.r[k].n / 4 * p.r[k].ways, 64) * 64;
   }
   p.n_regions = n_regions;
   p.n_virtual = v;
