@@ -391,6 +391,124 @@ class EpisodeBatch:
         return pad_batch_array(self.step_types, self.lengths,
                                self.env_spec.max_episode_length)
 
+    @property
+    def padded_next_observations(self):
+        """``_dtypes.py:926-934``."""
+        return pad_batch_array(self.next_observations, self.lengths,
+                               self.env_spec.max_episode_length)
+
+    @property
+    def padded_agent_infos(self):
+        """``_dtypes.py:948-961``."""
+        return {
+            k: pad_batch_array(arr, self.lengths,
+                               self.env_spec.max_episode_length)
+            for k, arr in self.agent_infos.items()
+        }
+
+    @property
+    def padded_env_infos(self):
+        """``_dtypes.py:964-977``."""
+        return {
+            k: pad_batch_array(arr, self.lengths,
+                               self.env_spec.max_episode_length)
+            for k, arr in self.env_infos.items()
+        }
+
+    @property
+    def observations_list(self):
+        """``_dtypes.py:877-887``: one ``(T_i, O^*)`` array per episode."""
+        return [self.observations[a:b] for a, b in self._episode_ranges()]
+
+    @property
+    def actions_list(self):
+        """``_dtypes.py:890-900``."""
+        return [self.actions[a:b] for a, b in self._episode_ranges()]
+
+    @property
+    def terminals(self):
+        """``_dtypes.py:381-390`` (inherited from ``TimeStepBatch``): which steps
+        are ``StepType.TERMINAL``."""
+        return np.array([s == StepType.TERMINAL for s in self.step_types])
+
+    def to_list(self):
+        """``_dtypes.py:676-728``: one dictionary per episode."""
+        episodes = []
+        infos = self.episode_infos
+        for i, (a, b) in enumerate(self._episode_ranges()):
+            episodes.append({
+                # (the reference slices the per-step expansion by the episode
+                # index, ``v[i:i + 1]``: kept)
+                'episode_infos': {k: v[i:i + 1] for k, v in infos.items()},
+                'observations': self.observations[a:b],
+                'next_observations': np.concatenate(
+                    (self.observations[1 + a:b], [self.last_observations[i]])),
+                'actions': self.actions[a:b],
+                'rewards': self.rewards[a:b],
+                'env_infos': {k: v[a:b] for k, v in self.env_infos.items()},
+                'agent_infos': {k: v[a:b]
+                                for k, v in self.agent_infos.items()},
+                'step_types': self.step_types[a:b],
+            })
+        return episodes
+
+    @classmethod
+    def from_list(cls, env_spec, paths):
+        """``_dtypes.py:731-800``: episodes given as dictionaries (observations
+        may hold ``T + 1`` rows, or ``next_observations`` may be given; a list of
+        ``dones`` stands in for missing step types)."""
+        lengths = np.asarray([len(p['rewards']) for p in paths])
+        if all(len(p['observations']) == n + 1
+               for p, n in zip(paths, lengths)):
+            last_observations = np.asarray(
+                [p['observations'][-1] for p in paths])
+            observations = np.concatenate(
+                [p['observations'][:-1] for p in paths])
+        else:
+            observations = np.concatenate([p['observations'] for p in paths])
+            if paths[0].get('next_observations') is not None:
+                last_observations = np.asarray(
+                    [p['next_observations'][-1] for p in paths])
+            else:
+                last_observations = np.asarray(
+                    [p['observations'][-1] for p in paths])
+        stacked = _concat_tensor_dict_list(paths)
+        episode_infos = _stack_tensor_dict_list(
+            [p['episode_infos'] for p in paths])
+        if 'dones' in stacked and 'step_types' not in stacked:
+            stacked['step_types'] = np.array(
+                [StepType.TERMINAL if d else StepType.MID
+                 for d in stacked['dones']], dtype=StepType)
+            del stacked['dones']
+        return cls(env_spec=env_spec, episode_infos=episode_infos,
+                   observations=observations,
+                   last_observations=last_observations,
+                   actions=stacked['actions'], rewards=stacked['rewards'],
+                   env_infos=stacked['env_infos'],
+                   agent_infos=stacked['agent_infos'],
+                   step_types=stacked['step_types'], lengths=lengths)
+
+
+def _stack_tensor_dict_list(dicts):
+    """``np/_functions.py:236-259``."""
+    out = {}
+    for k in list(dicts[0].keys()):
+        items = [d[k] if k in d else [] for d in dicts]
+        out[k] = (_stack_tensor_dict_list(items)
+                  if isinstance(dicts[0][k], dict) else np.array(items))
+    return out
+
+
+def _concat_tensor_dict_list(dicts):
+    """``np/_functions.py:296-319``."""
+    out = {}
+    for k in list(dicts[0].keys()):
+        items = [d[k] if k in d else [] for d in dicts]
+        out[k] = (_concat_tensor_dict_list(items)
+                  if isinstance(dicts[0][k], dict) else
+                  np.concatenate(items, axis=0))
+    return out
+
 
 def step_types_as_uint8(step_types):
     """``step_types`` (garage's object array of :class:`StepType`, or integers)
@@ -435,11 +553,13 @@ class DeviceEpisodeBatch(EpisodeBatch):
     def __init__(self, env_spec, *, lengths, obs_dev, last_obs_dev,
                  actions_dev, rewards_dev, step_types_dev, ep_off_dev,
                  head_dev=None, head_name='mean', log_std=None,
-                 discrete=False, extras=None, env_infos=None):
+                 discrete=False, extras=None, env_infos=None,
+                 episode_infos=None):
         # deliberately no base-class __init__: nothing to validate on host
         self.env_spec = env_spec
         self.lengths = np.asarray(lengths, dtype='l')
-        self.episode_infos_by_episode = {}
+        # (N, ...) arrays: what each episode's ``reset()`` reported
+        self.episode_infos_by_episode = dict(episode_infos or {})
         # host arrays of shape (S, ...): what CPU environments reported per step
         self.env_infos = dict(env_infos or {})
         self.obs_dev = obs_dev
@@ -502,7 +622,8 @@ class DeviceEpisodeBatch(EpisodeBatch):
 
     def to_host(self):
         """A plain, validated :class:`EpisodeBatch` copy on the host."""
-        return EpisodeBatch(env_spec=self.env_spec, episode_infos={},
+        return EpisodeBatch(env_spec=self.env_spec,
+                            episode_infos=dict(self.episode_infos_by_episode),
                             observations=self.observations,
                             last_observations=self.last_observations,
                             actions=self.actions, rewards=self.rewards,

@@ -57,7 +57,9 @@ class NormArgs(C.Structure):
                 ('obs_mean', ptr), ('obs_var', ptr), ('obs_alpha', c_f64),
                 ('reward_mean', ptr), ('reward_var', ptr),
                 ('reward_alpha', c_f64), ('reward_scale', c_f64),
-                ('raw_obs', ptr), ('raw_next_obs', ptr)]
+                ('raw_obs', ptr), ('raw_next_obs', ptr), ('act_low', ptr),
+                ('act_high', ptr), ('expected_action_scale', c_f32),
+                ('scaled_action', ptr)]
 
 
 class UpdateArgs(C.Structure):
@@ -161,6 +163,8 @@ SIGNATURES = {
                                           ptr, c_f64, ptr, ptr]),
     'ga_reward_normalize_f64': (c_int, [c_i64, ptr, ptr, ptr, c_f64, c_f64,
                                         c_int, ptr]),
+    'ga_action_rescale_f32': (c_int, [c_i64, c_int, ptr, c_i64, ptr, ptr, c_f32,
+                                      ptr, c_i64, ptr]),
     'ga_policy_head_sample': (c_int, [C.POINTER(HeadArgs), ptr]),
     'ga_policy_step_fused_supported': (c_int, [C.POINTER(MlpDesc)]),
     'ga_policy_step_fused_f32': (c_int, [C.POINTER(MlpDesc), ptr,

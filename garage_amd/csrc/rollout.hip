@@ -837,6 +837,39 @@ extern "C" int ga_obs_normalize_f64(int64_t n, int obs_dim, float* obs, int64_t 
                                    stream);
 }
 
+// NormalizedEnv.step's action rescale (envs/normalized_env.py:90-100): fp32, one
+// rounding per numpy operation (no fused multiply-add), np.clip's comparisons (a
+// NaN stays a NaN)
+__global__ __launch_bounds__(256) void action_rescale_kernel(
+    int64_t n, int A, const float* __restrict__ act, int64_t lda,
+    const float* __restrict__ lb, const float* __restrict__ ub, float scale,
+    float* __restrict__ out, int64_t ldo) {
+#pragma clang fp contract(off)
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n * A) return;
+  const int64_t r = i / A;
+  const int j = (int)(i % A);
+  const float a = act[r * lda + j];
+  const float lo = lb[j], hi = ub[j];
+  const float slope = (0.5f * (hi - lo)) / scale;
+  float v = lo + (a + scale) * slope;
+  v = v < lo ? lo : (v > hi ? hi : v);
+  out[r * ldo + j] = v;
+}
+
+extern "C" int ga_action_rescale_f32(int64_t n, int A, const float* actions, int64_t lda,
+                                     const float* low, const float* high,
+                                     float expected_action_scale, float* out,
+                                     int64_t ldo, hipStream_t stream) {
+  GA_REQUIRE(actions && low && high && out, "ga_action_rescale_f32: null pointer");
+  GA_REQUIRE(n > 0 && A > 0 && lda >= A && ldo >= A, "ga_action_rescale_f32: bad sizes");
+  hipLaunchKernelGGL(action_rescale_kernel, dim3((unsigned)ga_ceil_div(n * A, 256)),
+                     dim3(256), 0, stream, n, A, actions, lda, low, high,
+                     expected_action_scale, out, ldo);
+  GA_CHECK_LAUNCH("action_rescale");
+  return GA_OK;
+}
+
 extern "C" int ga_reward_normalize_f64(int64_t n, float* reward, double* mean,
                                        double* var, double alpha, double scale,
                                        int normalize, hipStream_t stream) {

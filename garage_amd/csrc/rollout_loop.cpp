@@ -22,6 +22,11 @@ extern "C" int ga_rollout_synth_steps(const ga_mlp_desc* desc, const float* para
     ga_set_error("ga_rollout_synth_steps: null pointer");
     return -1;
   }
+  if (norm && norm->act_low && (!norm->act_high || !norm->scaled_action || env->discrete)) {
+    ga_set_error("ga_rollout_synth_steps: action rescale needs bounds, scratch and a "
+                 "continuous action space");
+    return -1;
+  }
   const bool norm_obs = norm && norm->normalize_obs;
   if (norm_obs && (!raw_a || !raw_b)) {
     ga_set_error("ga_rollout_synth_steps: observation normalisation needs the raw "
@@ -57,7 +62,17 @@ extern "C" int ga_rollout_synth_steps(const ga_mlp_desc* desc, const float* para
       nm.raw_obs = raw_cur;
       nm.raw_next_obs = raw_nxt;
     }
-    rc = ga_synth_env_step_record_norm(env, &r, norm ? &nm : nullptr, h.action, h.lda,
+    const float* env_action = h.action;
+    if (norm && nm.act_low) {
+      // NormalizedEnv.step: the wrapped env sees the rescaled, clipped action; the
+      // batch keeps the policy's own (normalized_env.py:90-114)
+      rc = ga_action_rescale_f32(env->n, env->act_dim, h.action, h.lda, nm.act_low,
+                                 nm.act_high, nm.expected_action_scale,
+                                 nm.scaled_action, h.lda, stream);
+      if (rc) return rc;
+      env_action = nm.scaled_action;
+    }
+    rc = ga_synth_env_step_record_norm(env, &r, norm ? &nm : nullptr, env_action, h.lda,
                                        cur, stream);
     if (rc) return rc;
     float* t = cur;

@@ -87,7 +87,8 @@ class SyntheticVecEnv(VecEnv):
     """
 
     def __init__(self, n_envs, obs_dim, act_dim, max_episode_length, *,
-                 min_len=None, seed=0, discrete=False, env_id0=0, device=None):
+                 min_len=None, seed=0, discrete=False, env_id0=0, device=None,
+                 action_bounds=None):
         self.n_envs = int(n_envs)
         self._obs_dim = int(obs_dim)
         self._act_dim = int(act_dim)
@@ -97,8 +98,11 @@ class SyntheticVecEnv(VecEnv):
                         if min_len is None else int(min_len))
         self.seed = int(seed)
         self.env_id0 = int(env_id0)
+        # action_bounds = (low, high): the declared Box of a continuous action
+        # space (what ``normalize`` rescales to); the dynamics do not change
+        lo, hi = (-np.inf, np.inf) if action_bounds is None else action_bounds
         act_space = (Discrete(act_dim) if discrete else Box(
-            -np.inf, np.inf, (act_dim, )))
+            lo, hi, (act_dim, )) if np.isscalar(lo) else Box(lo, hi))
         self.spec = EnvSpec(Box(-np.inf, np.inf, (obs_dim, )), act_space,
                             max_episode_length=self.max_episode_length)
         self._init_device(device)
@@ -164,22 +168,41 @@ class NormalizedVecEnv(VecEnv):
     policy sees -- first observations, next observations and terminal ones --
     with the statistics updated *by that observation* (``:144-147``).  Rewards
     are scaled by ``scale_reward`` and optionally normalised the same way.
-    Action normalisation (``:90-100``) needs finite action bounds and is left to
-    the wrapped env.
+    Actions of a ``Box`` action space whose bounds pass the reference's test
+    (``:92-94``: no ``-inf`` in ``low`` **or in ``high``** -- its check of the
+    upper bound compares with ``-inf`` too, which is kept) are rescaled from
+    ``[-expected_action_scale, expected_action_scale]`` to ``[low, high]`` and
+    clipped before the wrapped env steps on them (``:90-100``); the batch keeps
+    the policy's own actions, as ``EnvStep.action`` does (``:109``).  Same
+    keywords, order and defaults as ``garage.envs.normalize``.
     """
 
-    def __init__(self, env, scale_reward=1., normalize_reward=False,
-                 normalize_obs=False, obs_alpha=0.001, reward_alpha=0.001):
+    def __init__(self, env, scale_reward=1., normalize_obs=False,
+                 normalize_reward=False, expected_action_scale=1.,
+                 flatten_obs=True, obs_alpha=0.001, reward_alpha=0.001):
         self._env = env
         self.n_envs = env.n_envs
         self.spec = env.spec
         self._scale_reward = float(scale_reward)
         self._normalize_reward = bool(normalize_reward)
         self._normalize_obs = bool(normalize_obs)
+        self._expected_action_scale = float(expected_action_scale)
+        # observations of a device batch are flat rows either way
+        self._flatten_obs = bool(flatten_obs)
         self._obs_alpha = float(obs_alpha)
         self._reward_alpha = float(reward_alpha)
         dev = env.device
         self.device = dev
+        self._act_low = self._act_high = self._scaled = None
+        space = env.spec.action_space
+        if isinstance(space, Box):
+            lb = np.asarray(space.low, dtype=np.float32).reshape(-1)
+            ub = np.asarray(space.high, dtype=np.float32).reshape(-1)
+            if np.all(lb != -np.inf) and np.all(ub != -np.inf):
+                self._act_low = torch.from_numpy(lb.copy()).to(dev)
+                self._act_high = torch.from_numpy(ub.copy()).to(dev)
+                self._scaled = torch.zeros(self.n_envs, round4(lb.size),
+                                           dtype=torch.float32, device=dev)
         n, O = self.n_envs, env.obs_dim
         self._obs_mean = torch.zeros(n, O, dtype=torch.float64, device=dev)
         self._obs_var = torch.ones(n, O, dtype=torch.float64, device=dev)
@@ -207,6 +230,10 @@ class NormalizedVecEnv(VecEnv):
         """Pass-through of a wrapped CPU env batch's per-step ``env_info``."""
         return getattr(self._env, 'last_env_infos', None)
 
+    def pop_finished_episode_infos(self):
+        pop = getattr(self._env, 'pop_finished_episode_infos', None)
+        return pop() if pop is not None else []
+
     def advance(self):
         self._env.advance()
         if self._normalize_obs:
@@ -229,6 +256,13 @@ class NormalizedVecEnv(VecEnv):
         self._norm(self._env.obs, self.obs)
 
     def step_all(self, actions):
+        if self._act_low is not None:
+            A = self._act_low.numel()
+            call('ga_action_rescale_f32', self.n_envs, A, dptr(actions),
+                 actions.stride(0), dptr(self._act_low), dptr(self._act_high),
+                 self._expected_action_scale, dptr(self._scaled),
+                 self._scaled.stride(0), stream_ptr())
+            actions = self._scaled
         self._env.step_all(actions)
         self._norm(self._env.next_obs, self.next_obs)
         if self._normalize_reward or self._scale_reward != 1.0:
@@ -256,6 +290,11 @@ class NormalizedVecEnv(VecEnv):
                                        self._reward_var.data_ptr())
         a.reward_alpha, a.reward_scale = (self._reward_alpha,
                                           self._scale_reward)
+        if self._act_low is not None:
+            a.act_low, a.act_high = (self._act_low.data_ptr(),
+                                     self._act_high.data_ptr())
+            a.expected_action_scale = self._expected_action_scale
+            a.scaled_action = self._scaled.data_ptr()
         return a
 
     def close(self):
@@ -269,8 +308,12 @@ class HostVecEnv(VecEnv):
     (``_environment.py:237-276``): ``reset() -> (obs, episode_info)`` and
     ``step(action) -> EnvStep`` with ``.reward``, ``.observation``,
     ``.step_type``.  Stepping stays a host loop (that is what those simulators
-    are); observations / rewards cross PCIe once per step through pinned
-    staging buffers, and everything downstream stays on the device.
+    are).  Per step the actions come down through a pinned buffer (the one
+    stream synchronisation of the step: the simulators need them), the
+    simulators write observations / rewards / step types straight into numpy
+    views of pinned staging buffers, and those go up with asynchronous copies
+    on the worker's stream -- the next step's synchronisation is what makes the
+    staging buffers reusable.  Everything downstream stays on the device.
     """
 
     def __init__(self, envs, spec=None, device=None):
@@ -282,55 +325,94 @@ class HostVecEnv(VecEnv):
         self._h_obs = torch.zeros(n, ldo, dtype=torch.float32).pin_memory()
         self._h_rew = torch.zeros(n, dtype=torch.float32).pin_memory()
         self._h_st = torch.zeros(n, dtype=torch.uint8).pin_memory()
+        self._h_done = torch.zeros(n, dtype=torch.uint8).pin_memory()
+        self._h_act = None  # pinned, sized at the first step
+        # numpy views of the pinned buffers: the simulators' outputs land in
+        # page-locked memory without a per-element tensor operation
+        self._np_obs = self._h_obs.numpy()
+        self._np_rew = self._h_rew.numpy()
+        self._np_st = self._h_st.numpy()
         self.discrete = is_discrete(self.spec.action_space)
+        self._obs_discrete = is_discrete(self.spec.observation_space)
         # the last step's ``EnvStep.env_info`` per env (None when every env
         # reported an empty dict); the worker files them per rollout column and
         # packs them into ``EpisodeBatch.env_infos`` (vec_worker.py:192-193)
         self.last_env_infos = None
+        # ``reset()[1]`` of the episode each env is in (default_worker.py:94-96),
+        # and -- since the last call of pop_finished_episode_infos -- those of the
+        # episodes that ended, as (env index, episode_info)
+        self._episode_info = [{} for _ in range(n)]
+        self._finished = []
 
     def _put_obs(self, i, obs):
         # discrete observation spaces are seen one-hot by the networks, as
         # ``observation_space.flatten`` makes them for garage's policies
         # (torch/policies/stochastic_policy.py:70-74)
-        space = self.spec.observation_space
-        if is_discrete(space):
-            flat = np.zeros(space.flat_dim, dtype=np.float32)
-            flat[int(obs)] = 1.0
+        row = self._np_obs[i]
+        if self._obs_discrete:
+            row[:] = 0.0
+            row[int(obs)] = 1.0
         else:
             flat = np.asarray(obs, dtype=np.float32).reshape(-1)
-        self._h_obs[i, :flat.shape[0]] = torch.from_numpy(flat)
+            row[:flat.shape[0]] = flat
+
+    def _reset_member(self, i):
+        obs, info = self.envs[i].reset()
+        self._put_obs(i, obs)
+        self._episode_info[i] = dict(info or {})
 
     def reset_all(self):
-        for i, env in enumerate(self.envs):
-            self._put_obs(i, env.reset()[0])
-        self.obs.copy_(self._h_obs)
+        torch.cuda.current_stream().synchronize()  # staging buffers are free
+        for i in range(self.n_envs):
+            self._reset_member(i)
+        self._finished = []
+        self.obs.copy_(self._h_obs, non_blocking=True)
 
     def step_all(self, actions):
-        acts = actions.cpu().numpy()
+        if self._h_act is None or self._h_act.shape != actions.shape:
+            self._h_act = torch.zeros(actions.shape,
+                                      dtype=torch.float32).pin_memory()
+        self._h_act.copy_(actions, non_blocking=True)
+        # the one synchronisation of the step (it also retires the previous
+        # step's uploads from the staging buffers written below)
+        torch.cuda.current_stream().synchronize()
+        acts = self._h_act.numpy()
         infos, any_info = [], False
+        width = self.act_width
         for i, env in enumerate(self.envs):
-            a = int(acts[i, 0]) if self.discrete else acts[i, :self.act_width]
+            a = int(acts[i, 0]) if self.discrete else acts[i, :width]
             es = env.step(a)
             self._put_obs(i, es.observation)
-            self._h_rew[i] = float(es.reward)
-            self._h_st[i] = int(es.step_type)
+            self._np_rew[i] = es.reward
+            self._np_st[i] = int(es.step_type)
             info = getattr(es, 'env_info', None) or {}
             any_info = any_info or bool(info)
             infos.append(info)
         self.last_env_infos = infos if any_info else None
-        self.next_obs.copy_(self._h_obs)
-        self.reward.copy_(self._h_rew)
-        self.step_type.copy_(self._h_st)
+        self.next_obs.copy_(self._h_obs, non_blocking=True)
+        self.reward.copy_(self._h_rew, non_blocking=True)
+        self.step_type.copy_(self._h_st, non_blocking=True)
 
     def reset_where(self, done):
-        mask = done.cpu().numpy()
-        idx = np.nonzero(mask)[0]
+        self._h_done.copy_(done, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        idx = np.nonzero(self._h_done.numpy())[0]
         if idx.size == 0:
             return
-        self._h_obs.copy_(self.next_obs)  # keep rows that are not reset
+        # the staging buffer still holds the rows just uploaded to next_obs
+        # unless somebody else wrote that tensor (hold() after advance()):
+        # fetch them so that rows which are not reset keep their state
+        self._h_obs.copy_(self.next_obs)
         for i in idx:
-            self._put_obs(int(i), self.envs[int(i)].reset()[0])
-        self.next_obs.copy_(self._h_obs)
+            self._finished.append((int(i), self._episode_info[int(i)]))
+            self._reset_member(int(i))
+        self.next_obs.copy_(self._h_obs, non_blocking=True)
+
+    def pop_finished_episode_infos(self):
+        """``(env index, episode_info)`` of the episodes that ended since the
+        last call, in the order they were reset."""
+        out, self._finished = self._finished, []
+        return out
 
     def close(self):
         for env in self.envs:

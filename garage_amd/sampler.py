@@ -277,6 +277,9 @@ class GpuVecWorker:
             'done': torch.zeros(n, dtype=torch.uint8, device=dev),
             # per column: the n ``env_info`` dicts of a CPU env batch (or None)
             'infos': [None] * tcap,
+            # column -> {env index: episode_info} for the episodes that ended
+            # there (CPU env batches whose resets report any)
+            'ep_infos': {},
         }
         if ldo != env.obs_dim:
             b['obs'].zero_()      # padding columns feed the GEMMs: keep them 0
@@ -320,6 +323,11 @@ class GpuVecWorker:
         r = self._record_args(b, col)
         call('ga_record_step', C.byref(r), s)
         env.reset_where(b['done'])
+        pop = getattr(env, 'pop_finished_episode_infos', None)
+        if pop is not None:
+            finished = pop()
+            if finished:
+                b['ep_infos'][col] = dict(finished)
         env.advance()
         self._global_step += 1
 
@@ -486,7 +494,26 @@ class GpuVecWorker:
             head_name='mean' if gaussian else 'prob',
             log_std=pol.clamped_log_std() if gaussian else None,
             discrete=is_discrete(self.env.spec.action_space),
-            env_infos=self._packed_env_infos(b, src, tcap))
+            env_infos=self._packed_env_infos(b, src, tcap),
+            episode_infos=self._packed_episode_infos(b, ep_env, ep_end))
+
+    @staticmethod
+    def _packed_episode_infos(b, ep_env, ep_end):
+        """``episode_infos`` of the packed batch: per key an ``(N, ...)`` array,
+        row ``e`` = what ``reset()`` reported for episode ``e``
+        (``default_worker.py:94-96,158-161``; the reference's ``VecWorker`` loses
+        them after an env's first episode, SURVEY.md Q23 -- the intended
+        ``DefaultWorker`` layout is kept here)."""
+        log = b.get('ep_infos')
+        if not log or not any(info for col in log.values()
+                              for info in col.values()):
+            return {}
+        envs = ep_env.cpu().numpy()
+        ends = ep_end.cpu().numpy()
+        rows = [log.get(int(c), {}).get(int(e), {})
+                for e, c in zip(envs, ends)]
+        keys = next(r for r in rows if r).keys()
+        return {k: np.asarray([r[k] for r in rows]) for k in keys}
 
     @staticmethod
     def _packed_env_infos(b, src, tcap):
@@ -540,6 +567,9 @@ class GpuVecWorker:
             if old[k] is not None:
                 new[k][:, :keep] = old[k][:, col - keep:col]
         new['infos'][:keep] = old['infos'][col - keep:col]
+        new['ep_infos'] = {c - (col - keep): v
+                           for c, v in old['ep_infos'].items()
+                           if c >= col - keep}
         self._api_buf, self._api_col = new, keep
 
     def step_episode(self):
@@ -675,7 +705,26 @@ class GpuFragmentWorker(GpuVecWorker):
             head_name='mean' if gaussian else 'prob',
             log_std=pol.clamped_log_std() if gaussian else None,
             discrete=is_discrete(self.env.spec.action_space),
-            env_infos=self._packed_env_infos(b, src, tcap))
+            env_infos=self._packed_env_infos(b, src, tcap),
+            episode_infos=self._packed_episode_infos(b, ep_env, ep_end))
+
+    @staticmethod
+    def _packed_episode_infos(b, ep_env, ep_end):
+        """``episode_infos`` of the packed batch: per key an ``(N, ...)`` array,
+        row ``e`` = what ``reset()`` reported for episode ``e``
+        (``default_worker.py:94-96,158-161``; the reference's ``VecWorker`` loses
+        them after an env's first episode, SURVEY.md Q23 -- the intended
+        ``DefaultWorker`` layout is kept here)."""
+        log = b.get('ep_infos')
+        if not log or not any(info for col in log.values()
+                              for info in col.values()):
+            return {}
+        envs = ep_env.cpu().numpy()
+        ends = ep_end.cpu().numpy()
+        rows = [log.get(int(c), {}).get(int(e), {})
+                for e, c in zip(envs, ends)]
+        keys = next(r for r in rows if r).keys()
+        return {k: np.asarray([r[k] for r in rows]) for k in keys}
 
 
 class GpuVecSampler:

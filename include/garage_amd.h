@@ -308,6 +308,13 @@ int ga_obs_normalize_from_f64(int64_t n, int obs_dim, const float* src, float* d
 int ga_reward_normalize_f64(int64_t n, float* reward, double* mean, double* var,
                             double alpha, double scale, int normalize,
                             ga_stream_t stream);
+/* NormalizedEnv.step's action rescale for a Box with finite bounds
+ * (envs/normalized_env.py:90-100): out = clip(low + (a + s) * (0.5 (high - low) / s),
+ * low, high) in fp32, s = expected_action_scale; low / high: device float[A]. */
+int ga_action_rescale_f32(int64_t n, int A, const float* actions, int64_t lda,
+                          const float* low, const float* high,
+                          float expected_action_scale, float* out, int64_t ldo,
+                          ga_stream_t stream);
 
 /* dist.sample() of StochasticPolicy.get_actions
  * (torch/policies/stochastic_policy.py:46-89) + the per-env list appends of
@@ -372,6 +379,12 @@ typedef struct ga_norm_args {
   double reward_alpha, reward_scale;
   const float* raw_obs;  /* [n, ldo] the wrapped env's current observations */
   float* raw_next_obs;   /* [n, ldo] where its next observations go */
+  /* action rescale (normalized_env.py:90-100) when act_low != NULL: the wrapped env
+   * steps on scaled_action (scratch [n, lda]) = ga_action_rescale_f32(policy action) */
+  const float* act_low;  /* [act_dim] */
+  const float* act_high;
+  float expected_action_scale;
+  float* scaled_action;
 } ga_norm_args;
 int ga_synth_env_step_record_norm(const ga_synth_env* env, const ga_record_args* rec,
                                   const ga_norm_args* norm, const float* actions,

@@ -226,3 +226,39 @@ class TaskEnv(CountingEnv):
             info['task_name'] = self.task_name
         return EnvStepLite(es.action, es.reward, es.observation, info,
                            es.step_type)
+
+
+class ActionEchoEnv:
+    """Fixture for ``NormalizedEnv``'s action and reward paths
+    (``envs/normalized_env.py:90-132,153-164``): remembers every action it is
+    stepped with (what the wrapper hands the wrapped env after rescaling and
+    clipping), observation ``[t, 2 t, -t] + env_id``, reward
+    ``0.25 t + sum(action)`` in float64, fixed-length episodes."""
+
+    def __init__(self, env_id, act_dim, max_episode_length):
+        self.env_id = env_id
+        self.act_dim = act_dim
+        self.max_episode_length = max_episode_length
+        self.received = []
+        self._t = None
+
+    def _obs(self):
+        t = float(self._t)
+        return np.array([t, 2 * t, -t], dtype=np.float32) + np.float32(
+            self.env_id)
+
+    def reset(self):
+        self._t = 0
+        return self._obs(), {}
+
+    def step(self, action):
+        a = np.array(action, dtype=np.float32).reshape(-1)[:self.act_dim]
+        self.received.append(a.copy())
+        self._t += 1
+        reward = 0.25 * (self._t - 1) + float(np.sum(a.astype(np.float64)))
+        step_type = StepType.get_step_type(self._t, self.max_episode_length,
+                                           False)
+        return EnvStepLite(action, reward, self._obs(), {}, step_type)
+
+    def close(self):
+        pass

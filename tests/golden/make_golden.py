@@ -241,6 +241,79 @@ def gen_padding_and_steptypes():
     save('padding_steptypes', **out)
 
 
+def gen_episode_batch_methods():
+    """The EpisodeBatch accessors beyond the PPO path (``_dtypes.py:381-390,
+    676-977``): per-episode lists, padded infos / next observations, terminals,
+    ``to_list`` and a ``from_list`` round trip (all three observation layouts)."""
+    out = {}
+    P = 7
+    spec = EnvSpec(akro.Box(-np.inf, np.inf, (3, )),
+                   akro.Box(-np.inf, np.inf, (2, )), max_episode_length=P)
+    rng = np.random.RandomState(8)
+    lens = [4, 7, 1, 3]
+    eps = make_ragged_batch(rng, spec, lens, 3, 2)
+    S = int(np.sum(lens))
+    eps = EpisodeBatch(
+        env_spec=spec,
+        episode_infos={'goal': rng.randn(len(lens), 2),
+                       'task': np.arange(len(lens))},
+        observations=eps.observations, last_observations=eps.last_observations,
+        actions=eps.actions, rewards=eps.rewards,
+        env_infos={'success': (rng.rand(S) > 0.5), 'pos': rng.randn(S, 2)},
+        agent_infos={'mean': rng.randn(S, 2).astype(np.float32)},
+        step_types=eps.step_types, lengths=eps.lengths)
+    out.update(batch_arrays('in_', eps))
+    out['in_ep_goal'] = eps.episode_infos_by_episode['goal']
+    out['in_ep_task'] = eps.episode_infos_by_episode['task']
+    out['in_env_success'] = eps.env_infos['success']
+    out['in_env_pos'] = eps.env_infos['pos']
+    out['in_agent_mean'] = eps.agent_infos['mean']
+    out['P'] = np.asarray(P)
+    out['terminals'] = eps.terminals
+    out['padded_next_observations'] = eps.padded_next_observations
+    out['padded_actions'] = eps.padded_actions
+    out['padded_step_types'] = np.asarray(
+        [[int(s) for s in row] for row in eps.padded_step_types])
+    out['padded_agent_mean'] = eps.padded_agent_infos['mean']
+    out['padded_env_pos'] = eps.padded_env_infos['pos']
+    out['padded_env_success'] = eps.padded_env_infos['success']
+    out['next_observations'] = eps.next_observations
+    out['episode_infos_goal'] = eps.episode_infos['goal']
+    for i, (o, a) in enumerate(zip(eps.observations_list, eps.actions_list)):
+        out['list%d_obs' % i], out['list%d_act' % i] = o, a
+    for i, d in enumerate(eps.to_list()):
+        for k in ('observations', 'next_observations', 'actions', 'rewards'):
+            out['tolist%d_%s' % (i, k)] = d[k]
+        out['tolist%d_step_types' % i] = np.asarray(
+            [int(s) for s in d['step_types']])
+        out['tolist%d_ep_goal' % i] = d['episode_infos']['goal']
+        out['tolist%d_env_pos' % i] = d['env_infos']['pos']
+        out['tolist%d_agent_mean' % i] = d['agent_infos']['mean']
+    # from_list: paths with T + 1 observations / with next_observations / bare,
+    # and `dones` in place of step types
+    paths = []
+    for i, d in enumerate(eps.to_list()):
+        paths.append(dict(
+            episode_infos={'goal': eps.episode_infos_by_episode['goal'][i]},
+            observations=np.concatenate([d['observations'],
+                                         d['next_observations'][-1:]]),
+            actions=d['actions'], rewards=d['rewards'],
+            env_infos=d['env_infos'], agent_infos=d['agent_infos'],
+            dones=np.asarray([int(s) == 2 for s in d['step_types']])))
+    back = EpisodeBatch.from_list(spec, paths)
+    out.update(batch_arrays('tp1_', back))
+    out['tp1_ep_goal'] = back.episode_infos_by_episode['goal']
+    paths2 = [dict(p, observations=p['observations'][:-1],
+                   next_observations=d['next_observations'])
+              for p, d in zip(paths, eps.to_list())]
+    back2 = EpisodeBatch.from_list(spec, paths2)
+    out.update(batch_arrays('nxt_', back2))
+    paths3 = [dict(p, observations=p['observations'][:-1]) for p in paths]
+    back3 = EpisodeBatch.from_list(spec, paths3)
+    out['bare_last_observations'] = back3.last_observations
+    save('episode_batch_methods', **out)
+
+
 def gen_sampler():
     out = {}
     P = 6
@@ -625,6 +698,66 @@ def gen_normalized_env():
          alpha=np.asarray(0.001))
 
 
+ACTION_CASES = {
+    # act low, act high, expected_action_scale, normalize_reward, scale_reward
+    'symmetric': ([-2., -1.], [2., 3.], 1.0, True, 0.5),
+    'wide_expected_scale': ([-1., 0.], [1., 10.], 2.5, True, 1.0),
+    'scale_only': ([-0.5, -0.5], [0.5, 0.5], 1.0, False, 3.0),
+    # normalized_env.py:93 tests `ub != -inf`: a half-open Box is rescaled too and
+    # every action becomes +inf (or NaN where a + scale == 0)
+    'upper_unbounded': ([-1., -1.], [np.inf, np.inf], 1.0, False, 1.0),
+    'unbounded': ([-np.inf, -np.inf], [np.inf, np.inf], 1.0, True, 2.0),
+}
+
+
+def action_sequence(n_steps=9):
+    rng = np.random.RandomState(21)
+    a = (rng.randn(n_steps, 2) * 1.5).astype(np.float32)
+    a[3] = [-1.0, 1.0]   # the ends of the expected range
+    a[4] = [-7.5, 4.0]   # far outside: clipped
+    return a
+
+
+def gen_normalized_env_actions():
+    """Action rescale + clip and reward normalisation of the real
+    ``garage.envs.normalize`` (``envs/normalized_env.py:90-132,153-164``)."""
+    from garage.envs import normalize
+    P = 6
+    out = {'actions': action_sequence(), 'P': np.asarray(P)}
+
+    class BoundedRefEnv(RefEnv):
+
+        def __init__(self, inner, low, high):
+            super().__init__(inner, 3, 2, P)
+            self._act_space = akro.Box(np.asarray(low, np.float32),
+                                       np.asarray(high, np.float32))
+            self._spec = EnvSpec(self._obs_space, self._act_space,
+                                 max_episode_length=P)
+
+    for tag, (low, high, s, norm_r, scale_r) in ACTION_CASES.items():
+        inner = oenvs.ActionEchoEnv(1, 2, P)
+        env = normalize(BoundedRefEnv(inner, low, high), scale_reward=scale_r,
+                        normalize_reward=norm_r, expected_action_scale=s)
+        env.reset()
+        rewards, means, variances, echoed = [], [], [], []
+        for t, a in enumerate(out['actions']):
+            if t == P:
+                env.reset()
+            es = env.step(a)
+            rewards.append(es.reward)
+            echoed.append(np.asarray(es.action))
+            means.append(env._reward_mean)
+            variances.append(env._reward_var)
+        out[tag + '_received'] = np.asarray(inner.received)
+        out[tag + '_echoed'] = np.asarray(echoed)
+        out[tag + '_rewards'] = np.asarray(rewards, dtype=np.float64)
+        out[tag + '_reward_mean'] = np.asarray(means, dtype=np.float64)
+        out[tag + '_reward_var'] = np.asarray(variances, dtype=np.float64)
+        out[tag + '_cfg'] = np.asarray(list(low) + list(high) +
+                                       [s, float(norm_r), scale_r])
+    save('normalized_env_actions', **out)
+
+
 def gen_log_performance():
     out = {}
     spec = EnvSpec(akro.Box(-1, 1, (3, )), akro.Box(-1, 1, (2, )),
@@ -692,10 +825,12 @@ if __name__ == '__main__':
     gen_returns()
     gen_advantages()
     gen_padding_and_steptypes()
+    gen_episode_batch_methods()
     gen_sampler()
     gen_networks()
     gen_compute_advantage()
     gen_train_once()
     gen_normalized_env()
+    gen_normalized_env_actions()
     gen_log_performance()
     gen_multitask()

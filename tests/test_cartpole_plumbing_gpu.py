@@ -98,3 +98,49 @@ def test_cartpole_ppo_learns_through_the_host_env_adapter():
     # policy must be clearly better (the reference's tests assert return > 0)
     assert returns[0] < 40
     assert max(returns[-3:]) > 2.0 * returns[0], returns
+
+
+def test_episode_infos_of_cpu_envs_reach_the_batch():
+    """``reset()[1]`` of per-env CPU objects (goal-conditioned / multi-task envs)
+    ends up in ``EpisodeBatch.episode_infos_by_episode`` as ``(N, ...)`` arrays,
+    one row per episode in batch order -- ``DefaultWorker``'s layout
+    (``sampler/default_worker.py:94-96,158-161``); the reference's ``VecWorker``
+    loses them after an env's first episode."""
+    from garage_amd._dtypes import Box, EnvSpec
+    from garage_amd.policies import GaussianMLPPolicy
+    from garage_amd.sampler import GpuVecSampler, GpuVecWorker
+    from oracle.envs import CountingEnv
+    P, n = 6, 5
+
+    class GoalEnv(CountingEnv):
+
+        def reset(self):
+            obs, _ = super().reset()
+            return obs, {'goal': np.array([self.env_id, self._episode],
+                                          dtype=np.float32),
+                         'task': self.env_id * 10 + self._episode}
+
+    cyc = [[3, 6, 2], [4, 4, 4], [6, 1, 5], [2, 2, 6], [1, 3, 1]]
+    envs = [GoalEnv(i, cyc[i], P) for i in range(n)]
+    spec = EnvSpec(Box(-np.inf, np.inf, (3, )), Box(-np.inf, np.inf, (2, )),
+                   max_episode_length=P)
+    torch.manual_seed(0)
+    pol = GaussianMLPPolicy(spec, hidden_sizes=(8, 8))
+    sampler = GpuVecSampler(pol, [envs], max_episode_length=P, n_workers=1,
+                            worker_class=GpuVecWorker, seed=1,
+                            worker_args=dict(n_envs=n))
+    for call in range(2):  # the second call starts from in-flight episodes
+        eps = sampler.obtain_samples(call, 60, None)
+        lens = np.asarray(eps.lengths)
+        starts = np.concatenate([[0], np.cumsum(lens)[:-1]])
+        first_obs = eps.observations[starts]          # [env, episode, t = 0]
+        goal = eps.episode_infos_by_episode['goal']
+        task = eps.episode_infos_by_episode['task']
+        assert goal.shape == (len(lens), 2) and task.shape == (len(lens), )
+        assert np.array_equal(goal, first_obs[:, :2])
+        assert np.array_equal(task, first_obs[:, 0] * 10 + first_obs[:, 1])
+        per_step = eps.episode_infos['goal']
+        assert per_step.shape == (int(lens.sum()), 2)
+        assert np.array_equal(per_step, eps.observations[:, :2])
+        host = eps.to_host()
+        assert np.array_equal(host.episode_infos_by_episode['goal'], goal)

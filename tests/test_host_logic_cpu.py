@@ -277,3 +277,87 @@ def test_discrete_space_flatten_is_one_hot():
     assert np.array_equal(sp.flatten_n([0, 4]),
                           [[1, 0, 0, 0, 0], [0, 0, 0, 0, 1]])
     assert sp.unflatten(sp.flatten(2)) == 2
+
+
+def test_episode_batch_accessors_match_the_real_reference(golden):
+    """tests/golden/episode_batch_methods.npz (the real ``garage.EpisodeBatch``,
+    ``_dtypes.py:381-390,676-977``): per-episode lists, padded infos and next
+    observations, terminals, ``to_list`` -- including its quirk of slicing the
+    per-step expansion of ``episode_infos`` by the episode index -- and
+    ``from_list`` for paths with T + 1 observations, with ``next_observations``
+    and with neither, with ``dones`` standing in for step types."""
+    g = golden('episode_batch_methods')
+    P = int(g['P'])
+    spec = EnvSpec(Box(-np.inf, np.inf, (3, )), Box(-np.inf, np.inf, (2, )),
+                   max_episode_length=P)
+    st = np.asarray([StepType(int(s)) for s in g['in_step_types']],
+                    dtype=StepType)
+    eps = EpisodeBatch(
+        env_spec=spec,
+        episode_infos={'goal': g['in_ep_goal'], 'task': g['in_ep_task']},
+        observations=g['in_observations'],
+        last_observations=g['in_last_observations'], actions=g['in_actions'],
+        rewards=g['in_rewards'],
+        env_infos={'success': g['in_env_success'], 'pos': g['in_env_pos']},
+        agent_infos={'mean': g['in_agent_mean']}, step_types=st,
+        lengths=g['in_lengths'])
+    assert np.array_equal(eps.terminals, g['terminals'])
+    assert np.array_equal(eps.padded_next_observations,
+                          g['padded_next_observations'])
+    assert np.array_equal(eps.padded_actions, g['padded_actions'])
+    assert np.array_equal(
+        np.asarray([[int(s) for s in row] for row in eps.padded_step_types]),
+        g['padded_step_types'])
+    assert np.array_equal(eps.padded_agent_infos['mean'],
+                          g['padded_agent_mean'])
+    assert np.array_equal(eps.padded_env_infos['pos'], g['padded_env_pos'])
+    assert np.array_equal(eps.padded_env_infos['success'],
+                          g['padded_env_success'])
+    assert np.array_equal(eps.next_observations, g['next_observations'])
+    assert np.array_equal(eps.episode_infos['goal'], g['episode_infos_goal'])
+    n = len(eps.lengths)
+    for i, (o, a) in enumerate(zip(eps.observations_list, eps.actions_list)):
+        assert np.array_equal(o, g['list%d_obs' % i])
+        assert np.array_equal(a, g['list%d_act' % i])
+    dicts = eps.to_list()
+    assert len(dicts) == n
+    for i, d in enumerate(dicts):
+        for k in ('observations', 'next_observations', 'actions', 'rewards'):
+            assert np.array_equal(d[k], g['tolist%d_%s' % (i, k)]), (i, k)
+        assert np.array_equal([int(s) for s in d['step_types']],
+                              g['tolist%d_step_types' % i])
+        assert np.array_equal(d['episode_infos']['goal'],
+                              g['tolist%d_ep_goal' % i])
+        assert np.array_equal(d['env_infos']['pos'], g['tolist%d_env_pos' % i])
+        assert np.array_equal(d['agent_infos']['mean'],
+                              g['tolist%d_agent_mean' % i])
+    paths = []
+    for i, d in enumerate(dicts):
+        paths.append(dict(
+            episode_infos={'goal': g['in_ep_goal'][i]},
+            observations=np.concatenate([d['observations'],
+                                         d['next_observations'][-1:]]),
+            actions=d['actions'], rewards=d['rewards'],
+            env_infos=d['env_infos'], agent_infos=d['agent_infos'],
+            dones=np.asarray([int(s) == 2 for s in d['step_types']])))
+
+    def same(batch, prefix):
+        for k in ('observations', 'last_observations', 'actions', 'rewards',
+                  'lengths'):
+            assert np.array_equal(getattr(batch, k), g[prefix + k]), k
+        assert np.array_equal([int(s) for s in batch.step_types],
+                              g[prefix + 'step_types'])
+        assert str(batch.lengths.dtype) == str(g[prefix + 'lengths_dtype'])
+
+    back = EpisodeBatch.from_list(spec, paths)
+    same(back, 'tp1_')
+    assert np.array_equal(back.episode_infos_by_episode['goal'],
+                          g['tp1_ep_goal'])
+    paths2 = [dict(p, observations=p['observations'][:-1],
+                   next_observations=d['next_observations'])
+              for p, d in zip(paths, dicts)]
+    same(EpisodeBatch.from_list(spec, paths2), 'nxt_')
+    paths3 = [dict(p, observations=p['observations'][:-1]) for p in paths]
+    assert np.array_equal(
+        EpisodeBatch.from_list(spec, paths3).last_observations,
+        g['bare_last_observations'])

@@ -72,3 +72,90 @@ def test_normalised_rollout_runs_through_the_sampler():
                            atol=1e-7)
         raw.advance()
         env.advance()
+
+
+ACTION_CASES = ('symmetric', 'wide_expected_scale', 'scale_only',
+                'upper_unbounded', 'unbounded')
+
+
+@pytest.mark.parametrize('tag', ACTION_CASES)
+def test_action_rescale_and_reward_normalisation_match_real_normalized_env(
+        golden, tag):
+    """tests/golden/normalized_env_actions.npz: the real ``garage.envs.normalize``
+    (``envs/normalized_env.py:90-132,153-164``) around an env that remembers what
+    it was stepped with -- finite bounds with two ``expected_action_scale``s,
+    ``scale_reward`` with and without ``normalize_reward``, the half-open Box
+    the reference's bound test lets through (inf / NaN actions included), and
+    an unbounded Box (no rescale).  Here: the same env objects behind
+    ``HostVecEnv`` inside ``NormalizedVecEnv``."""
+    from garage_amd._dtypes import Box, EnvSpec
+    from garage_amd.envs import HostVecEnv, NormalizedVecEnv
+    from oracle.envs import ActionEchoEnv
+    g = golden('normalized_env_actions')
+    P = int(g['P'])
+    cfg = g[tag + '_cfg']
+    low, high = cfg[0:2].astype(np.float32), cfg[2:4].astype(np.float32)
+    scale, norm_r, scale_r = float(cfg[4]), bool(cfg[5]), float(cfg[6])
+    spec = EnvSpec(Box(-np.inf, np.inf, (3, )), Box(low, high),
+                   max_episode_length=P)
+    members = [ActionEchoEnv(1, 2, P), ActionEchoEnv(1, 2, P)]
+    env = NormalizedVecEnv(HostVecEnv(members, spec=spec),
+                           scale_reward=scale_r, normalize_reward=norm_r,
+                           expected_action_scale=scale)
+    dev = env.device
+    env.reset_all()
+    rewards, means, variances = [], [], []
+    for t, a in enumerate(g['actions']):
+        if t == P:
+            env.reset_all()
+        act = torch.zeros(2, 4, device=dev)
+        act[:, :2] = torch.from_numpy(a).to(dev)
+        env.step_all(act)
+        env.advance()
+        rewards.append(env.reward.cpu().numpy().copy())
+        means.append(env._reward_mean.cpu().numpy().copy())
+        variances.append(env._reward_var.cpu().numpy().copy())
+    for m in members:  # what the wrapped env was stepped with: bit for bit
+        got = np.asarray(m.received)
+        assert np.array_equal(got, g[tag + '_received'], equal_nan=True)
+    rewards = np.asarray(rewards)
+    for i in (0, 1):
+        assert np.allclose(rewards[:, i], g[tag + '_rewards'], rtol=2e-6,
+                           atol=1e-7, equal_nan=True)
+    if norm_r:
+        assert np.allclose(np.asarray(means)[:, 0], g[tag + '_reward_mean'],
+                           rtol=1e-6, atol=1e-9)
+        assert np.allclose(np.asarray(variances)[:, 0], g[tag + '_reward_var'],
+                           rtol=1e-6, atol=1e-9)
+
+
+def test_native_rollout_rescales_actions_like_the_stepwise_path():
+    """``ga_rollout_synth_steps`` with a bounded action space (rescale launch
+    between the policy step and the env step) against the same rollout driven
+    step by step from Python: same bits; and the batch keeps the policy's own
+    actions, not the rescaled ones (``normalized_env.py:109``)."""
+    from garage_amd.envs import NormalizedVecEnv, SyntheticVecEnv
+    from garage_amd.policies import GaussianMLPPolicy
+    from garage_amd.sampler import GpuVecSampler, GpuVecWorker
+    n, O, A, P = 64, 5, 3, 12
+    out = []
+    for fused in (True, False):
+        torch.manual_seed(2)
+        env = NormalizedVecEnv(
+            SyntheticVecEnv(n, O, A, P, min_len=3, seed=6,
+                            action_bounds=(-0.3, 0.2)),
+            normalize_obs=True, normalize_reward=True,
+            expected_action_scale=1.5)
+        pol = GaussianMLPPolicy(env.spec, hidden_sizes=(32, 32))
+        sampler = GpuVecSampler(pol, env, max_episode_length=P, n_workers=1,
+                                worker_class=GpuVecWorker, seed=4,
+                                worker_args=dict(n_envs=n,
+                                                 fused_policy_step=fused))
+        eps = sampler.obtain_samples(0, n * P, None)
+        out.append((eps.obs_dev.clone(), eps.actions_dev.clone(),
+                    eps.rewards_dev.clone(), np.asarray(eps.lengths)))
+    assert np.array_equal(out[0][3], out[1][3])
+    for a, b in zip(out[0][:3], out[1][:3]):
+        assert torch.equal(a, b)
+    acts = out[0][1][:, :A]
+    assert float(acts.abs().max()) > 0.5  # unclipped policy actions are stored
