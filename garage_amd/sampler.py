@@ -304,6 +304,9 @@ class GpuVecWorker:
             self.env.reset_where(progress)
             self.env.advance()
             self._ep_t.zero_()
+        pop = getattr(self.env, 'pop_finished_episode_infos', None)
+        if pop is not None:
+            pop()  # episodes dropped by the reset are not part of any batch
         self._needs_agent_reset = False
         self._needs_env_reset = False
 

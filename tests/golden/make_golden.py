@@ -814,6 +814,176 @@ def gen_multitask():
     save('multitask', **out)
 
 
+def _default_repr(v):
+    import inspect
+    if v is inspect.Parameter.empty:
+        return '<required>'
+    if v is None or isinstance(v, (bool, int, float, str)):
+        return v
+    if isinstance(v, (tuple, list)):
+        return [_default_repr(x) for x in v]
+    if callable(v):
+        return '<callable {}>'.format(getattr(v, '__name__', type(v).__name__))
+    return '<{}>'.format(type(v).__name__)
+
+
+def gen_signatures():
+    """Constructor / function signatures of the reference's plugin surface
+    (SURVEY.md section 8b), written as ``signatures.json``: parameter names,
+    kinds and defaults, for the CPU test that ``garage_amd`` accepts the same
+    keywords."""
+    import inspect
+    import json
+
+    from garage.envs import normalize
+    from garage.sampler import Sampler, Worker
+    from garage.sampler.env_update import (EnvUpdate, ExistingEnvUpdate,
+                                           NewEnvUpdate, SetTaskUpdate)
+    from garage.torch.algos import TRPO
+    from garage.torch.optimizers import ConjugateGradientOptimizer
+    from garage.torch import filter_valids
+    targets = {
+        'LocalSampler': LocalSampler.__init__,
+        'LocalSampler.from_worker_factory': LocalSampler.from_worker_factory,
+        'LocalSampler.obtain_samples': LocalSampler.obtain_samples,
+        'LocalSampler.obtain_exact_episodes':
+        LocalSampler.obtain_exact_episodes,
+        'WorkerFactory': WorkerFactory.__init__,
+        'VecWorker': VecWorker.__init__,
+        'FragmentWorker': FragmentWorker.__init__,
+        'DefaultWorker': DefaultWorker.__init__,
+        'VPG': VPG.__init__,
+        'PPO': PPO.__init__,
+        'TRPO': TRPO.__init__,
+        'GaussianMLPPolicy': GaussianMLPPolicy.__init__,
+        'GaussianMLPValueFunction': GaussianMLPValueFunction.__init__,
+        'OptimizerWrapper': OptimizerWrapper.__init__,
+        'ConjugateGradientOptimizer': ConjugateGradientOptimizer.__init__,
+        'NormalizedEnv': normalize.__init__,
+        'EpisodeBatch': EpisodeBatch.__init__,
+        'EnvSpec': EnvSpec.__init__,
+        'NewEnvUpdate': NewEnvUpdate.__init__,
+        'SetTaskUpdate': SetTaskUpdate.__init__,
+        'ExistingEnvUpdate': ExistingEnvUpdate.__init__,
+        'discount_cumsum': discount_cumsum,
+        'pad_batch_array': pad_batch_array,
+        'compute_advantages': compute_advantages,
+        'filter_valids': filter_valids,
+        'log_performance': gfun.log_performance,
+        'log_multitask_performance': gfun.log_multitask_performance,
+    }
+    out = {}
+    for name, fn in targets.items():
+        params = []
+        for p in inspect.signature(fn).parameters.values():
+            if p.name in ('self', 'cls'):
+                continue
+            params.append(dict(name=p.name, kind=p.kind.name,
+                               default=_default_repr(p.default)))
+        out[name] = params
+    path = os.path.join(HERE, 'signatures.json')
+    with open(path, 'w') as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print('wrote', path, len(out), 'signatures')
+
+
+def gen_trainer_trace():
+    """What the real ``garage.Trainer`` (``trainer.py:137-229,263-341,361-537``)
+    does to an algorithm and its sampler: the calls it makes, with which
+    arguments, and its bookkeeping (``step_itr``, ``total_env_steps``, what goes
+    into a snapshot) -- for a fresh run of 2 epochs and a restore + resume up to
+    epoch 4.  Driven with the real ``VPG`` (2 iterations per epoch), the real
+    ``LocalSampler(VecWorker)`` over fixed-length counting envs and a recording
+    snapshotter; written as JSON (``trainer_trace.json``)."""
+    import json
+    from collections import namedtuple
+
+    import garage.trainer as trainer_mod
+    from garage.trainer import Trainer
+    # experiment.json is a log of the launcher's arguments; its writer uses
+    # np.bool8 (gone in numpy 2) and is not on the path
+    trainer_mod.dump_json = lambda *a, **k: None
+    P, n, batch = 5, 4, 40
+    spec = EnvSpec(akro.Box(-np.inf, np.inf, (3, )),
+                   akro.Box(-np.inf, np.inf, (2, )), max_episode_length=P)
+    torch.manual_seed(0)
+    policy = GaussianMLPPolicy(spec, hidden_sizes=(8, 8))
+    vf = GaussianMLPValueFunction(spec, hidden_sizes=(8, 8))
+    envs = [RefEnv(oenvs.CountingEnv(i, [P], P), 3, 2, P) for i in range(n)]
+    wf = WorkerFactory(seed=1, n_workers=1, worker_class=VecWorker,
+                       worker_args=dict(n_envs=n), max_episode_length=P)
+    sampler = LocalSampler.from_worker_factory(wf, policy, [envs])
+    algo = VPG(env_spec=spec, policy=policy, value_function=vf, sampler=sampler,
+               num_train_per_epoch=2)
+    vpg_mod.tabular = ref.TabularRecorder()
+    gfun.tabular = ref.TabularRecorder()
+    events = []
+
+    real_obtain, real_shutdown = sampler.obtain_samples, sampler.shutdown_worker
+
+    def obtain_samples(itr, num_samples, agent_update, env_update=None):
+        same = all(torch.equal(v, policy.state_dict()[k])
+                   for k, v in agent_update.items())
+        events.append(['obtain_samples', int(itr), int(num_samples),
+                       sorted(agent_update.keys()), bool(same),
+                       env_update is None])
+        return real_obtain(itr, num_samples, agent_update, env_update)
+
+    def shutdown_worker():
+        events.append(['shutdown_worker'])
+        return real_shutdown()
+
+    sampler.obtain_samples = obtain_samples
+    sampler.shutdown_worker = shutdown_worker
+
+    class RecordingSnapshotter:
+        snapshot_dir = '/tmp/garage_amd_trainer_trace'
+        snapshot_mode = 'last'
+
+        def __init__(self):
+            self.saved = {}
+
+        def save_itr_params(self, itr, params):
+            st = params['stats']
+            events.append(['save', int(itr), sorted(params.keys()),
+                           int(st.total_itr), int(st.total_env_steps),
+                           int(st.total_epoch), st.last_episode is None,
+                           params['algo'] is algo,
+                           int(params['train_args'].n_epochs),
+                           int(params['train_args'].batch_size),
+                           int(params['train_args'].start_epoch)])
+            self.saved[itr] = params
+
+        def load(self, from_dir, from_epoch='last'):
+            events.append(['load', from_epoch])
+            return self.saved[max(self.saved)]
+
+    Cfg = namedtuple('SnapshotConfig',
+                     ['snapshot_dir', 'snapshot_mode', 'snapshot_gap'])
+    trainer = Trainer(Cfg('/tmp/garage_amd_trainer_trace', 'none', 1))
+    trainer._snapshotter = RecordingSnapshotter()
+    trainer.setup(algo, envs[0])
+    events.append(['setup', trainer._sampler is sampler])
+    ret = trainer.train(n_epochs=2, batch_size=batch)
+    events.append(['train_returned', type(ret).__name__,
+                   int(trainer.total_env_steps), int(trainer.step_itr)])
+    # restore + resume (trainer.py:295-341,457-497)
+    snap = trainer._snapshotter
+    resumed = Trainer(Cfg('/tmp/garage_amd_trainer_trace', 'none', 1))
+    resumed._snapshotter = snap
+    args = resumed.restore('/tmp/garage_amd_trainer_trace')
+    events.append(['restored', int(args.start_epoch), int(args.n_epochs),
+                   int(resumed.total_env_steps)])
+    ret = resumed.resume(n_epochs=4)
+    events.append(['resume_returned', type(ret).__name__,
+                   int(resumed.total_env_steps), int(resumed.step_itr)])
+    path = os.path.join(HERE, 'trainer_trace.json')
+    with open(path, 'w') as f:
+        json.dump(dict(P=P, n_envs=n, batch_size=batch, hidden=[8, 8],
+                       num_train_per_epoch=2, events=events), f, indent=1)
+    print('wrote', path, len(events), 'events')
+
+
 if __name__ == '__main__':
     print('reference:', garage.__file__)
     if len(sys.argv) > 1:  # regenerate selected fixtures only, e.g. `trpo`
@@ -834,3 +1004,5 @@ if __name__ == '__main__':
     gen_normalized_env_actions()
     gen_log_performance()
     gen_multitask()
+    gen_trainer_trace()
+    gen_signatures()
