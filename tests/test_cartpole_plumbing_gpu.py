@@ -126,6 +126,8 @@ def test_episode_infos_of_cpu_envs_reach_the_batch():
                    max_episode_length=P)
     torch.manual_seed(0)
     pol = GaussianMLPPolicy(spec, hidden_sizes=(8, 8))
+    for e in envs:
+        e.spec = spec
     sampler = GpuVecSampler(pol, [envs], max_episode_length=P, n_workers=1,
                             worker_class=GpuVecWorker, seed=1,
                             worker_args=dict(n_envs=n))

@@ -139,7 +139,7 @@ def test_native_rollout_rescales_actions_like_the_stepwise_path():
     from garage_amd.sampler import GpuVecSampler, GpuVecWorker
     n, O, A, P = 64, 5, 3, 12
     out = []
-    for fused in (True, False):
+    for native in (True, False):
         torch.manual_seed(2)
         env = NormalizedVecEnv(
             SyntheticVecEnv(n, O, A, P, min_len=3, seed=6,
@@ -149,8 +149,10 @@ def test_native_rollout_rescales_actions_like_the_stepwise_path():
         pol = GaussianMLPPolicy(env.spec, hidden_sizes=(32, 32))
         sampler = GpuVecSampler(pol, env, max_episode_length=P, n_workers=1,
                                 worker_class=GpuVecWorker, seed=4,
-                                worker_args=dict(n_envs=n,
-                                                 fused_policy_step=fused))
+                                worker_args=dict(n_envs=n))
+        if not native:  # same kernels, driven one step at a time from Python
+            for w in sampler._workers:
+                w._native_steps = lambda *args: False
         eps = sampler.obtain_samples(0, n * P, None)
         out.append((eps.obs_dev.clone(), eps.actions_dev.clone(),
                     eps.rewards_dev.clone(), np.asarray(eps.lengths)))
