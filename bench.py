@@ -125,6 +125,14 @@ CONFIGS = {
                    n_envs=64, T=256, hidden=(256, 256), min_len=None,
                    minibatches=256),
 }
+# BASELINE.json's second metric ("GAE-scan HBM GB/s") at the footprint of the C4
+# batch (8 x 4096 envs x T = 256 = 134 MB of r, V, A, G): one step = one scan
+SCAN_CONFIGS = {
+    'c4scan': dict(name='GAE(lambda) + discounted-return scan, C4 batch '
+                   'footprint', n_rows=32768, T=256),
+    'c3scan': dict(name='GAE(lambda) + discounted-return scan, C3 batch '
+                   'footprint', n_rows=4096, T=256),
+}
 HYPER = dict(discount=0.99, gae_lambda=0.97, lr_clip_range=0.2, lr=2.5e-4,
              epochs=10, minibatches_per_epoch=32)
 
@@ -326,12 +334,73 @@ def cpu_baseline(cfg, n_envs, seed=1):
                     os.cpu_count()))
 
 
+def scan_bench(args):
+    """``--config c4scan`` / ``c3scan``: the scan kernel alone.  Every launch is
+    timed with HIP events attached to its dispatch (prof.cpp); between launches
+    the inputs are rewritten, so they come from the caches the way the value
+    forward leaves the baselines in the real iteration."""
+    from garage_amd import _lib
+    from garage_amd.engine import gae_scan
+    cfg = SCAN_CONFIGS[args.config]
+    n, T = cfg['n_rows'], cfg['T']
+    dev = torch.device('cuda', 0)
+    torch.cuda.set_device(0)
+    g = torch.Generator(device='cpu').manual_seed(0)
+    r = torch.randn(n, T, generator=g).to(dev)
+    v = torch.randn(n, T, generator=g).to(dev)
+    adv, ret = torch.empty_like(r), torch.empty_like(r)
+    lib = _lib.load()
+
+    def run():
+        gae_scan(r, v, discount=HYPER['discount'],
+                 gae_lambda=HYPER['gae_lambda'], max_episode_length=T, adv=adv,
+                 ret=ret)
+
+    for _ in range(max(1, args.warmup)):
+        run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    lib.ga_prof_enable(1)
+    for _ in range(args.steps):
+        run()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    lib.ga_prof_enable(0)
+    out = (C.c_double * (3 * len(KIND_NAMES)))()
+    lib.ga_prof_collect(out, len(KIND_NAMES))
+    ms, work, cnt = out[18], out[19], out[20]
+    gbs = work / (ms * 1e-3) / 1e9
+    print(json.dumps({
+        'metric': 'GAE-scan HBM GB/s', 'value': gbs, 'unit': 'GB/s',
+        'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
+        'data': 'synthetic',
+        'config': {'workload': '{}: {} rows x {} steps, gamma {} lambda {}, '
+                   '16 B per step (r, V in; A, G out)'.format(
+                       cfg['name'], n, T, HYPER['discount'],
+                       HYPER['gae_lambda']),
+                   'config_id': args.config, 'parallelism': 'dp1'},
+        'roofline': {'kernel': 'gae_scan_rows_kernel<1>', 'bound': 'hbm',
+                     'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                     'frac': gbs / PEAK_HBM_GBS, 'traffic': None,
+                     'frac_of_measured_copy_6290': gbs / 6290.0,
+                     'avg_launch_us': ms * 1e3 / max(1.0, cnt),
+                     'bytes_per_launch': work / max(1.0, cnt),
+                     'measured': 'HIP events attached to each of the {} '
+                                 'launches; ms_per_step is the host wall clock '
+                                 'per launch incl. the Python call'.format(
+                                     int(cnt))},
+    }))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--config', default='c3', choices=sorted(CONFIGS))
+    ap.add_argument('--config', default='c3',
+                    choices=sorted(CONFIGS) + sorted(SCAN_CONFIGS))
     ap.add_argument('--cpu-envs', type=int, default=1024,
                     help='envs of the bounded CPU-baseline sample (0: skip)')
     ap.add_argument('--no-roofline', action='store_true')
@@ -359,6 +428,8 @@ def main():
                     'the other on one stream (isolated per-kernel timings)')
     args = ap.parse_args()
 
+    if args.config in SCAN_CONFIGS:
+        return scan_bench(args)
     from garage_amd.distributed import gradient_exchange, init_from_env
     comm = init_from_env()
     world = comm.world_size if comm is not None else 1
@@ -509,6 +580,7 @@ def main():
                 'kernel': scan['kernel'], 'bound': 'hbm', 'achieved': gbs,
                 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                 'frac': gbs / PEAK_HBM_GBS, 'traffic': None,
+                'frac_of_measured_copy_6290': gbs / 6290.0,
                 'avg_launch_us': scan['total_ms'] * 1e3 / scan['launches'],
                 'bytes_per_launch': scan['work'] / scan['launches'],
             }

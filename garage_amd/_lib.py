@@ -91,6 +91,7 @@ SIGNATURES = {
                                 c_i64, c_int, c_int, c_f64, c_f64, c_f32,
                                 c_f32, ptr, ptr, ptr]),
     'ga_set_gae_fixed_fast_path': (c_int, [c_int]),
+    'ga_set_gae_rows_steps_per_lane': (c_int, [c_int]),
     'ga_mlp_forward_f32': (c_int, [C.POINTER(MlpDesc), ptr, ptr, c_i64, ptr,
                                    c_i64, ptr, ptr, c_i64, ptr]),
     'ga_mlp_forward_fused_f32': (c_int, [C.POINTER(MlpDesc), ptr, ptr, c_i64,

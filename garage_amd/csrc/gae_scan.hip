@@ -260,7 +260,11 @@ struct RowsScanParams {
   float* ret;
 };
 
+// NQ = quads (4 steps) per lane: 1 (up to 256 steps per 64-lane row group) or 2
+// (8 steps per lane: half the lanes, waves and shuffle steps per row)
+template <int NQ>
 __global__ __launch_bounds__(256) void gae_scan_rows_kernel(RowsScanParams p) {
+  constexpr int NS = 4 * NQ;
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lpr = p.lpr;
@@ -278,18 +282,29 @@ __global__ __launch_bounds__(256) void gae_scan_rows_kernel(RowsScanParams p) {
       len = (int)p.T;
     }
   }
-  const int i0 = 4 * sub;
-  const int nv = max(0, min(4, len - i0));  // valid steps of this lane
-  float rf[4] = {0.f, 0.f, 0.f, 0.f}, vf[4] = {0.f, 0.f, 0.f, 0.f};
-  const bool vec = nv == 4 && ((start + i0) & 3) == 0;
+  const int i0 = NS * sub;
+  const int nv = max(0, min(NS, len - i0));  // valid steps of this lane
+  float rf[NS], vf[NS];
+#pragma unroll
+  for (int j = 0; j < NS; ++j) { rf[j] = 0.f; vf[j] = 0.f; }
+  const bool vec = nv == NS && ((start + i0) & 3) == 0;
   if (vec) {
-    const float4 r4 = *reinterpret_cast<const float4*>(p.rew + start + i0);
-    const float4 v4 = *reinterpret_cast<const float4*>(p.val + start + i0);
-    rf[0] = r4.x; rf[1] = r4.y; rf[2] = r4.z; rf[3] = r4.w;
-    vf[0] = v4.x; vf[1] = v4.y; vf[2] = v4.z; vf[3] = v4.w;
+    float4 r4[NQ], v4[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      r4[q] = *reinterpret_cast<const float4*>(p.rew + start + i0 + 4 * q);
+      v4[q] = *reinterpret_cast<const float4*>(p.val + start + i0 + 4 * q);
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      rf[4 * q + 0] = r4[q].x; rf[4 * q + 1] = r4[q].y;
+      rf[4 * q + 2] = r4[q].z; rf[4 * q + 3] = r4[q].w;
+      vf[4 * q + 0] = v4[q].x; vf[4 * q + 1] = v4[q].y;
+      vf[4 * q + 2] = v4[q].z; vf[4 * q + 3] = v4[q].w;
+    }
   } else {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NS; ++j) {
       if (j < nv) {
         rf[j] = p.rew[start + i0 + j];
         vf[j] = p.val[start + i0 + j];
@@ -316,21 +331,22 @@ __global__ __launch_bounds__(256) void gae_scan_rows_kernel(RowsScanParams p) {
       end_add = p.gamma * p.v0 + p.c * c0;
     }
   }
-  double r[4], xa[4];
+  double r[NS], xa[NS];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < NS; ++j) {
     r[j] = (double)rf[j];
     const bool valid = j < nv;
     const bool last = has_end && j == nv - 1;
-    const double vn = last ? 0.0 : (double)(j == 3 ? vr : vf[j < 3 ? j + 1 : 3]);
+    const double vn =
+        last ? 0.0 : (double)(j == NS - 1 ? vr : vf[j < NS - 1 ? j + 1 : NS - 1]);
     xa[j] = valid ? (r[j] + p.bonus_const) + p.gamma * vn - (double)vf[j] +
                         (last ? end_add : 0.0)
                   : 0.0;
     if (!valid) r[j] = 0.0;
   }
-  double ax = xa[3], gx = r[3];
+  double ax = xa[NS - 1], gx = r[NS - 1];
 #pragma unroll
-  for (int j = 2; j >= 0; --j) {
+  for (int j = NS - 2; j >= 0; --j) {
     ax = xa[j] + p.c * ax;
     gx = r[j] + p.gamma_ret * gx;
   }
@@ -349,22 +365,25 @@ __global__ __launch_bounds__(256) void gae_scan_rows_kernel(RowsScanParams p) {
     ya = 0.0;
     yg = 0.0;
   }
-  float oa[4], og[4];
+  float oa[NS], og[NS];
 #pragma unroll
-  for (int j = 3; j >= 0; --j) {
+  for (int j = NS - 1; j >= 0; --j) {
     ya = xa[j] + p.c * ya;
     yg = r[j] + p.gamma_ret * yg;
     oa[j] = (float)ya;
     og[j] = (float)yg;
   }
   if (vec) {
-    *reinterpret_cast<float4*>(p.adv + start + i0) =
-        make_float4(oa[0], oa[1], oa[2], oa[3]);
-    *reinterpret_cast<float4*>(p.ret + start + i0) =
-        make_float4(og[0], og[1], og[2], og[3]);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      *reinterpret_cast<float4*>(p.adv + start + i0 + 4 * q) =
+          make_float4(oa[4 * q], oa[4 * q + 1], oa[4 * q + 2], oa[4 * q + 3]);
+      *reinterpret_cast<float4*>(p.ret + start + i0 + 4 * q) =
+          make_float4(og[4 * q], og[4 * q + 1], og[4 * q + 2], og[4 * q + 3]);
+    }
   } else {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NS; ++j) {
       if (j < nv) {
         p.adv[start + i0 + j] = oa[j];
         p.ret[start + i0 + j] = og[j];
@@ -376,6 +395,12 @@ __global__ __launch_bounds__(256) void gae_scan_rows_kernel(RowsScanParams p) {
 }  // namespace
 
 static int g_fixed_fast_path = 1;
+// steps per lane of the whole-episode fast path: 4 or 8 (A/B runs)
+static int g_rows_steps_per_lane = 4;
+extern "C" int ga_set_gae_rows_steps_per_lane(int steps) {
+  g_rows_steps_per_lane = steps == 8 ? 8 : 4;
+  return 0;
+}
 extern "C" int ga_set_gae_fixed_fast_path(int on) {
   g_fixed_fast_path = on != 0;
   return 0;
@@ -428,24 +453,38 @@ extern "C" int ga_gae_scan_f32(const float* rewards, const float* values,
   GA_REQUIRE(blocks < (1ll << 31), "ga_gae_scan_f32: grid too large");
   // whole-episode rows of at most 256 steps: the constant-decay kernel
   if (g_fixed_fast_path && mode == 1 && !bonus && max_len <= 256) {
+    const int nq = (g_rows_steps_per_lane == 8 && max_len > 4) ? 2 : 1;
+    int flpr = 1;
+    while (flpr < 64 && (int64_t)flpr * 4 * nq < max_len) flpr <<= 1;
     RowsScanParams f;
     f.rew = rewards; f.val = values; f.offsets = offsets; f.n_rows = n_rows; f.T = T;
-    f.ld = ld; f.lpr = lpr; f.P = max_episode_length; f.gamma = p.gamma; f.c = p.c;
+    f.ld = ld; f.lpr = flpr; f.P = max_episode_length; f.gamma = p.gamma; f.c = p.c;
     f.gamma_ret = p.gamma_ret; f.bonus_const = p.bonus_const; f.v0 = p.v0;
     f.adv = adv; f.ret = ret;
-    double cd = ((p.c * p.c) * p.c) * p.c, gd = ((discount * discount) * discount) * discount;
+    // decay over one lane's steps, then squared per scan step
+    double cd = 1.0, gd = 1.0;
+    for (int k = 0; k < 4 * nq; ++k) {
+      cd *= p.c;
+      gd *= discount;
+    }
     for (int k = 0; k < 6; ++k) {
       f.cpow[k] = cd;
       f.gpow[k] = gd;
       cd *= cd;
       gd *= gd;
     }
+    const int64_t fwaves = ga_ceil_div(n_rows, 64 / flpr);
+    const int64_t fblocks = ga_ceil_div(fwaves, 4);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     ga_prof_events(GA_PROF_GAE_SCAN,
                    16.0 * (offsets ? (double)prof_steps : (double)n_rows * (double)T),
                    &e0, &e1);
-    hipExtLaunchKernelGGL(gae_scan_rows_kernel, dim3((unsigned)blocks), dim3(256), 0,
-                          stream, e0, e1, 0, f);
+    if (nq == 2)
+      hipExtLaunchKernelGGL(gae_scan_rows_kernel<2>, dim3((unsigned)fblocks), dim3(256),
+                            0, stream, e0, e1, 0, f);
+    else
+      hipExtLaunchKernelGGL(gae_scan_rows_kernel<1>, dim3((unsigned)fblocks), dim3(256),
+                            0, stream, e0, e1, 0, f);
     GA_CHECK_LAUNCH("ga_gae_scan_f32");
     return GA_OK;
   }

@@ -58,6 +58,10 @@ int ga_gae_scan_f32(const float* rewards, const float* values, const float* bonu
  * max_episode_length steps; otherwise the ragged variant); 0 forces the general
  * kernel (A/B runs, tests). */
 int ga_set_gae_fixed_fast_path(int on);
+/* Steps per lane of those fast paths: 4 (one 16-B access per array and lane) or 8
+ * (two; half the lanes, waves and shuffle steps per row).  Same recurrences in
+ * another association order: results agree to fp64 rounding. */
+int ga_set_gae_rows_steps_per_lane(int steps);
 
 /* ---- MLP forward / backward (fp32 MFMA GEMMs) -------------------------------
  * Replaces MLPModule / MultiHeadedMLPModule.forward
