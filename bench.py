@@ -336,9 +336,11 @@ def cpu_baseline(cfg, n_envs, seed=1):
 
 def scan_bench(args):
     """``--config c4scan`` / ``c3scan``: the scan kernel alone.  Every launch is
-    timed with HIP events attached to its dispatch (prof.cpp); between launches
-    the inputs are rewritten, so they come from the caches the way the value
-    forward leaves the baselines in the real iteration."""
+    timed with HIP events attached to its dispatch (prof.cpp).  The launches run
+    back to back on the same buffers, so below 256 MiB the inputs are Infinity-
+    Cache resident -- as the baselines (just written by the value forward) and
+    the rewards (gathered right before the scan) are in the real iteration; the
+    in-iteration figure is `roofline_gae_scan` of the PPO configs."""
     from garage_amd import _lib
     from garage_amd.engine import gae_scan
     cfg = SCAN_CONFIGS[args.config]
