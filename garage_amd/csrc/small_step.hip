@@ -707,7 +707,12 @@ __global__ __launch_bounds__(SS_THREADS) void small_step_kernel(SmallStepParams 
     const int lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      const int cj = (32 * (cg + 4 * t) < H) ? cg + 4 * t : cg;
+      // waves whose column tile lies beyond the layer (H < 32 * (cg + 4 t) + 32) load
+      // the layer's last tile instead: the values are not used, but the address
+      // must stay inside the parameter buffer (a wave of a 32-wide net would
+      // otherwise read up to 96 floats past its row -- past the end of a small
+      // value network's buffer for the last rows)
+      const int cj = min(cg + 4 * t, H / 32 - 1);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int row = (i & 3) + 8 * (i >> 2) + 4 * kh;

@@ -13,6 +13,8 @@
 // 32768-row minibatch is a single wave of 512 workgroups).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/garage_amd.h"
@@ -59,6 +61,26 @@ extern "C" int ga_set_fused_train(int on) {
   g_fused_train = on != 0;
   return 0;
 }
+
+// GARAGE_AMD_TRACE=1: every launch of the epoch loop is announced on stderr and
+// waited for (a faulting kernel is then the last one named)
+static int trace_on() {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("GARAGE_AMD_TRACE");
+    on = (e && e[0] == '1') ? 1 : 0;
+  }
+  return on;
+}
+#define GA_TRACE(stream, ...)                                   \
+  do {                                                          \
+    if (trace_on()) {                                           \
+      (void)hipStreamSynchronize((hipStream_t)(stream));        \
+      fprintf(stderr, "[ga_trace] " __VA_ARGS__);               \
+      fprintf(stderr, "\n");                                    \
+      fflush(stderr);                                           \
+    }                                                           \
+  } while (0)
 
 namespace {
 struct FusedPlan {
@@ -330,6 +352,8 @@ int run_minibatch(const ga_update_args* a, int64_t k, ga_stream_t stream,
     s.bar = reinterpret_cast<unsigned*>(tail);
     s.fault = reinterpret_cast<int*>(tail + 1);
     s.loss_out = loss_slot;
+    GA_TRACE(stream, "small_step k=%lld M=%lld H=%d in=%d out=%d kind=%d", (long long)k,
+             (long long)M, s.H, s.in_w, s.out_w, s.kind);
     return ga_small_step(&s, stream);
   }
   if (g_fused_train && !g_fuse_head && a->partials && a->kind >= 0 && a->kind <= 2 &&
@@ -343,9 +367,12 @@ int run_minibatch(const ga_update_args* a, int64_t k, ga_stream_t stream,
   const int hid_w = L >= 2 ? a->desc->dims[L - 1] : 0;
   const bool fuse_head = g_fuse_head && L >= 2 && (a->kind == 0 || a->kind == 1) &&
                          ga_head_loss_supported(hid_w, out_w);
+  GA_TRACE(stream, "forward k=%lld M=%lld start=%lld kind=%d", (long long)k, (long long)M,
+           (long long)start, a->kind);
   int rc = ga_mlp_forward_f32(a->desc, a->params, a->X, a->ldx, idx, M, a->acts,
                               fuse_head ? nullptr : a->out, a->ldo, stream);
   if (rc) return rc;
+  GA_TRACE(stream, "loss");
   const float* H = fuse_head ? a->acts + a->desc->act_off[L - 2] : nullptr;
   const int64_t ldh = (hid_w + 3) & ~3;
   const float* Wh = a->params + a->desc->w_off[L - 1];
@@ -379,10 +406,12 @@ int run_minibatch(const ga_update_args* a, int64_t k, ga_stream_t stream,
                                   a->workspace, stream);
   }
   if (rc) return rc;
+  GA_TRACE(stream, "backward splits=%lld", (long long)splits);
   rc = ga_mlp_backward_f32(a->desc, a->params, a->X, a->ldx, idx, M, a->acts,
                            a->dout, a->ldo, a->dacts, a->slabs, a->n_flat, splits,
                            stream);
   if (rc) return rc;
+  GA_TRACE(stream, "reduce + adam");
   if (!a->comm && a->phase != 1) {
     // single process: slab sum and Adam in one launch
     return ga_reduce_adam_f32(a->slabs, splits, a->n_flat, a->params, a->grads,
