@@ -565,12 +565,7 @@ class DeviceEpisodeBatch(EpisodeBatch):
         self.obs_dev = obs_dev
         self.last_obs_dev = last_obs_dev
         self.actions_dev = actions_dev
-        # a tensor, or a zero-argument callable that produces it on first use:
-        # the sampler leaves the rewards in its rollout buffer and the (S,)
-        # gather runs right before the first consumer -- in PPO the GAE scan,
-        # after the full-batch baseline forward has swept the caches -- so that
-        # the scan finds them in the Infinity Cache rather than in HBM
-        self._rewards_dev = rewards_dev
+        self.rewards_dev = rewards_dev
         self.step_types_dev = step_types_dev
         self.ep_off_dev = ep_off_dev
         self.head_dev = head_dev
@@ -579,17 +574,6 @@ class DeviceEpisodeBatch(EpisodeBatch):
         self._discrete = discrete
         self.extras = extras or {}
         self._cache = {}
-
-    @property
-    def rewards_dev(self):
-        if callable(self._rewards_dev):
-            self._rewards_dev = self._rewards_dev()
-        return self._rewards_dev
-
-    def __getstate__(self):
-        state = self.__dict__.copy()
-        state['_rewards_dev'] = self.rewards_dev  # closures do not pickle
-        return state
 
     @property
     def n_samples(self):

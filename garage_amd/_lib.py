@@ -98,7 +98,6 @@ SIGNATURES = {
                                          ptr, c_i64, ptr, ptr, c_i64, ptr]),
     'ga_set_fused_forward': (c_int, [c_int]),
     'ga_set_skinny_kernels': (c_int, [c_int]),
-    'ga_set_first_layer_mfma': (c_int, [c_int]),
     'ga_set_fused_head_dgrad': (c_int, [c_int]),
     'ga_set_fused_head_forward': (c_int, [c_int]),
     'ga_set_small_m_gemm': (c_int, [c_int]),

@@ -388,145 +388,6 @@ void launch_fwd(const SkinnyFwdParams& p, bool w_kc, int epi, dim3 grid,
 
 // Y = act(X W^T + b): W[n][ldw] k-contiguous.  epi 0.
 // Y = (X W) * (1 - H^2): W[k][ldw] n-contiguous.  epi 1.
-// ---------------------------------------------------------------------------
-// First-layer forward on the matrix cores: H[m, n] = tanh(sum_k X[row(m), k] W[n, k]
-// + b[n]),  K <= 32, N a multiple of 32 * NT.
-//
-// The streaming kernel above spends ~100 vector instructions per 16 stored bytes
-// (20 FMAs per output on the VALU); here a wave owns a strip of 32 rows x 32 NT
-// columns and the products run as v_mfma_f32_32x32x2_f32: A = X (i = batch row),
-// B = W^T (j = output column), so for every accumulator register the 32 lanes of a
-// half-wave hold 32 consecutive columns of one row -- bias, tanh and a 4-B store
-// per lane that covers a whole 128-B line per half-wave; no LDS, no staging.  The
-// operand fragments come straight from global memory (a lane reads its own row of
-// X / W as 16-B loads and keeps every other float: k = 2 s + lane / 32).
-// (The transposed orientation, which gives each lane 4 adjacent columns and
-// 16-B stores, was measured first: its store instructions scatter 32-B pieces over
-// 32 rows and the kernel took 45 us against 19.5 us for the streaming kernel.)
-// ---------------------------------------------------------------------------
-struct L1FwdParams {
-  const float* X; int64_t ldx; const int32_t* idx;
-  const float* W; int64_t ldw; const float* bias;
-  float* H; int64_t ldh;
-  int M, N, K;
-  int col_groups;  // N / (32 NT)
-};
-
-typedef float l1_f32x16 __attribute__((ext_vector_type(16)));
-
-// KQ = quads of the padded reduction dimension (ceil(K / 4)); NT = column tiles
-template <int KQ, int NT>
-__global__ __launch_bounds__(256) void l1_fwd_mfma_kernel(L1FwdParams p) {
-  const int lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
-  const int64_t task = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int64_t strip = task / p.col_groups;
-  const int cg = (int)(task % p.col_groups);
-  const int m0 = (int)(strip * 32);
-  if (m0 >= p.M) return;
-  const int n0 = cg * 32 * NT;
-  // this lane's batch row (A operand)
-  const int m = m0 + l31;
-  const int mc = min(m, p.M - 1);
-  const int64_t src = p.idx ? (int64_t)p.idx[mc] : (int64_t)mc;
-  float4 xq[KQ];
-#pragma unroll
-  for (int q = 0; q < KQ; ++q)
-    xq[q] = *reinterpret_cast<const float4*>(p.X + src * p.ldx + 4 * q);
-  // k = 2 s + half for s = 0 .. 2 KQ - 1: floats (half, 2 + half) of every quad
-  float xb[2 * KQ];
-#pragma unroll
-  for (int q = 0; q < KQ; ++q) {
-    xb[2 * q + 0] = half ? xq[q].y : xq[q].x;
-    xb[2 * q + 1] = half ? xq[q].w : xq[q].z;
-    // columns >= K of an observation row may hold anything (0 * NaN poisons)
-    if (4 * q + 0 + half >= p.K) xb[2 * q + 0] = 0.f;
-    if (4 * q + 2 + half >= p.K) xb[2 * q + 1] = 0.f;
-  }
-  l1_f32x16 acc[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    // B operand: row n0 + 32 t + l31 of W (rows are padded with zeros to 4 KQ)
-    float4 wq[KQ];
-#pragma unroll
-    for (int q = 0; q < KQ; ++q)
-      wq[q] = *reinterpret_cast<const float4*>(
-          p.W + (int64_t)(n0 + 32 * t + l31) * p.ldw + 4 * q);
-#pragma unroll
-    for (int q = 0; q < KQ; ++q) {
-      float w0 = half ? wq[q].y : wq[q].x;
-      float w1 = half ? wq[q].w : wq[q].z;
-      if (4 * q + 0 + half >= p.K) w0 = 0.f;
-      if (4 * q + 2 + half >= p.K) w1 = 0.f;
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xb[2 * q + 0], w0, acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xb[2 * q + 1], w1, acc[t], 0, 0, 0);
-    }
-  }
-  // D(i = row, j = column): lane holds column n0 + 32 t + l31 and, in register r,
-  // row m0 + (r & 3) + 8 (r >> 2) + 4 half
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const int n = n0 + 32 * t + l31;
-    const float b = p.bias[n];
-    float* out = p.H + (int64_t)(m0 + 4 * half) * p.ldh + n;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2);
-      if (m0 + 4 * half + row < p.M)
-        out[(int64_t)row * p.ldh] = tanh_fast(acc[t][r] + b);
-    }
-  }
-  (void)m;
-}
-
-static int g_l1_mfma = 1;
-extern "C" int ga_set_first_layer_mfma(int on) {
-  g_l1_mfma = on != 0;
-  return 0;
-}
-
-template <int KQ>
-static void launch_l1(const L1FwdParams& p, int nt, dim3 grid, hipStream_t stream,
-                      hipEvent_t e0, hipEvent_t e1) {
-  if (nt == 4)
-    hipExtLaunchKernelGGL((l1_fwd_mfma_kernel<KQ, 4>), grid, dim3(256), 0, stream, e0, e1,
-                          0, p);
-  else
-    hipExtLaunchKernelGGL((l1_fwd_mfma_kernel<KQ, 2>), grid, dim3(256), 0, stream, e0, e1,
-                          0, p);
-}
-
-// Returns 1 when the shape is not taken.
-static int l1_forward_mfma(const float* X, int64_t ldx, const int32_t* idx,
-                           const float* W, int64_t ldw, const float* bias, float* Y,
-                           int64_t ldy, int M, int N, int K, hipStream_t stream) {
-  if (!g_l1_mfma || !bias || K < 1 || K > 32 || N < 64 || N % 64 != 0 || M < 1 ||
-      ldw < ((K + 3) & ~3))
-    return 1;
-  L1FwdParams p;
-  p.X = X; p.ldx = ldx; p.idx = idx; p.W = W; p.ldw = ldw; p.bias = bias;
-  p.H = Y; p.ldh = ldy; p.M = M; p.N = N; p.K = K;
-  const int nt = (N % 128 == 0) ? 4 : 2;
-  p.col_groups = N / (32 * nt);
-  const int64_t tasks = ga_ceil_div(M, 32) * p.col_groups;
-  const dim3 grid((unsigned)ga_ceil_div(tasks, 4));
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  ga_prof_events(GA_PROF_SKINNY_FWD, 4.0 * M * ((double)N + K), &e0, &e1);
-  switch ((K + 3) / 4) {
-    case 1: launch_l1<1>(p, nt, grid, stream, e0, e1); break;
-    case 2: launch_l1<2>(p, nt, grid, stream, e0, e1); break;
-    case 3: launch_l1<3>(p, nt, grid, stream, e0, e1); break;
-    case 4: launch_l1<4>(p, nt, grid, stream, e0, e1); break;
-    case 5: launch_l1<5>(p, nt, grid, stream, e0, e1); break;
-    case 6: launch_l1<6>(p, nt, grid, stream, e0, e1); break;
-    case 7: launch_l1<7>(p, nt, grid, stream, e0, e1); break;
-    default: launch_l1<8>(p, nt, grid, stream, e0, e1); break;
-  }
-  GA_CHECK_LAUNCH("l1_fwd_mfma");
-  return GA_OK;
-}
-
 int ga_skinny_forward(const float* X, int64_t ldx, const int32_t* idx, const float* W,
                       int64_t ldw, bool w_kc, const float* bias, int act,
                       const float* H, int64_t ldh, float* Y, int64_t ldy, int M, int N,
@@ -537,10 +398,6 @@ int ga_skinny_forward(const float* X, int64_t ldx, const int32_t* idx, const flo
       (bias && !ga_aligned16(bias)) || (H && !ga_aligned16(H)) || ldx < ((K + 3) & ~3))
     return 1;
   if (w_kc != (H == nullptr)) return 1;  // only the two layer products above
-  if (w_kc && act == 1) {  // first-layer forward: matrix cores when the shape fits
-    const int rc = l1_forward_mfma(X, ldx, idx, W, ldw, bias, Y, ldy, M, N, K, stream);
-    if (rc != 1) return rc;
-  }
   SkinnyFwdParams p;
   p.X = X; p.ldx = ldx; p.idx = idx; p.W = W; p.ldw = ldw; p.bias = bias; p.H = H;
   p.ldh = ldh; p.Y = Y; p.ldy = ldy; p.M = M; p.N = N; p.K = K; p.act = act;

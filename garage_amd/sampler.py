@@ -484,14 +484,8 @@ class GpuVecWorker:
         act = rows(b['act'], src, S)
         head = rows(b['head'], src, S) if b['head'] is not None else None
         last = rows(b['lastobs'], ep_cell, n_eps)
-        rew_buf = b['rew']
-
-        def rew():  # gathered on first use (see DeviceEpisodeBatch.rewards_dev)
-            out = torch.empty(S, dtype=torch.float32, device=dev)
-            call('ga_gather_f32', dptr(rew_buf), dptr(src), S, dptr(out),
-                 stream_ptr())
-            return out
-
+        rew = torch.empty(S, dtype=torch.float32, device=dev)
+        call('ga_gather_f32', dptr(b['rew']), dptr(src), S, dptr(rew), s)
         st = torch.empty(S, dtype=torch.uint8, device=dev)
         call('ga_gather_u8', dptr(b['st']), dptr(src), S, dptr(st), s)
         pol = self.agent

@@ -95,11 +95,6 @@ int ga_set_fused_forward(int on);
  * gradient, first-layer / head weight gradients) run as HBM-streaming kernels
  * instead of MFMA tiles (default on; 0 = MFMA tiles everywhere, for A/B runs). */
 int ga_set_skinny_kernels(int on);
-/* The first-layer forward (K = obs_dim <= 32, width a multiple of 64) on the matrix
- * cores with the transposed operand orientation: no LDS, a 16-B store per
- * accumulator group (default on; 0 = the streaming VALU kernel).  Same k order per
- * output as an fmaf chain: results agree with it to the last bit or two of tanh. */
-int ga_set_first_layer_mfma(int on);
 /* The head layer's weight-gradient streaming kernel also writes the data gradient
  * of the layer below (same pass over the hidden activations) when the head is
  * <= 16 wide (default on; 0 = separate data-gradient launch, for A/B runs). */
