@@ -16,6 +16,7 @@
 // narrow operand is staged in LDS and read back as same-address broadcasts, and
 // the arithmetic is a sequential fp32 FMA chain on the vector ALU.
 #include "common.h"
+#include <stdlib.h>
 #include <hip/hip_ext.h>
 
 #include "prof.h"
@@ -46,6 +47,8 @@ struct SkinnyFwdParams {
   int qpr;               // column quads per row handled by one workgroup (<= 64)
   int rows_per_thread;   // multiple of SK_UNROLL
 };
+
+typedef float sk_v2f __attribute__((ext_vector_type(2)));
 
 constexpr int SK_THREADS = 256;
 constexpr int SK_UNROLL = 4;
@@ -118,7 +121,10 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_fwd_kernel(SkinnyFwdParams 
     for (int u = 0; u < SK_UNROLL; ++u) {
       const int rl = (it + u) * n_rg + rg;
       const int m = row0 + rl;
-      float4 a = (EPI == 0) ? bias : make_float4(0.f, 0.f, 0.f, 0.f);
+      // two packed FMAs (v_pk_fma_f32) per k instead of four scalar ones: the same
+      // fmaf chain per output, half the vector-issue slots
+      const float4 a0 = (EPI == 0) ? bias : make_float4(0.f, 0.f, 0.f, 0.f);
+      sk_v2f alo = {a0.x, a0.y}, ahi = {a0.z, a0.w};
 #pragma unroll
       for (int v = 0; v < KV; ++v) {
         const float4 xv = *reinterpret_cast<const float4*>(xs + (rl * KV + v) * 4);
@@ -126,12 +132,13 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_fwd_kernel(SkinnyFwdParams 
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const float4 w = wk[4 * v + j];
-          a.x = fmaf(xk[j], w.x, a.x);
-          a.y = fmaf(xk[j], w.y, a.y);
-          a.z = fmaf(xk[j], w.z, a.z);
-          a.w = fmaf(xk[j], w.w, a.w);
+          const sk_v2f xx = {xk[j], xk[j]};
+          const sk_v2f wlo = {w.x, w.y}, whi = {w.z, w.w};
+          alo = __builtin_elementwise_fma(xx, wlo, alo);
+          ahi = __builtin_elementwise_fma(xx, whi, ahi);
         }
       }
+      float4 a = make_float4(alo.x, alo.y, ahi.x, ahi.y);
       if (EPI == 0) {
         if (p.act == 1) {
           a.x = tanh_fast(a.x); a.y = tanh_fast(a.y);
@@ -403,13 +410,20 @@ int ga_skinny_forward(const float* X, int64_t ldx, const int32_t* idx, const flo
   p.ldh = ldh; p.Y = Y; p.ldy = ldy; p.M = M; p.N = N; p.K = K; p.act = act;
   p.qpr = qpr;
   const int n_rg = SK_THREADS / qpr;
-  // ~128 rows per workgroup, never fewer than one unroll per thread: every
-  // workgroup first loads its W quads into registers (20 KB from L2 at the C3
-  // first layer), so fewer, longer-lived workgroups win while the other update
-  // chain shares the chip (32 / 128 / 256 rows: 146.2 / 143.3 / 152.9 ms per C3
-  // iteration)
+  // 32 rows per workgroup (never fewer than one unroll per thread): two generations
+  // of workgroups per CU, so one's prologue (gathered X rows, 20 KB of W quads from
+  // L2) runs under the other's stores.  Round 1 preferred 128 rows while the other
+  // update chain's streaming kernels shared the chip (146.2 / 143.3 / 152.9 ms per
+  // C3 iteration at 32 / 128 / 256); with those kernels folded into the GEMMs it
+  // is 131.5 / 133.0 / 132.7 ms at 32 / 64 / 128 (18.5 / 18.9 / 20.2 us a launch).
+  // Packed FMAs changed nothing: the kernel is bound by its store stream.
   // (... but at least one workgroup per CU)
-  int rows_wg = 128;
+  static int rows_wg_env = -1;  // A/B runs: GARAGE_AMD_SKINNY_ROWS
+  if (rows_wg_env < 0) {
+    const char* e = getenv("GARAGE_AMD_SKINNY_ROWS");
+    rows_wg_env = e ? atoi(e) : 0;
+  }
+  int rows_wg = rows_wg_env > 0 ? rows_wg_env : 32;
   while (rows_wg > 32 && (int64_t)M < 256 * (int64_t)rows_wg) rows_wg >>= 1;
   p.rows_per_thread = ((rows_wg / n_rg + SK_UNROLL - 1) / SK_UNROLL) * SK_UNROLL;
   if (p.rows_per_thread < SK_UNROLL) p.rows_per_thread = SK_UNROLL;
