@@ -28,3 +28,17 @@ clean:
 	rm -rf $(OUT)/*.o $(OUT)/*.so
 
 .PHONY: all clean
+
+# Host-side epoch / rollout loops under AddressSanitizer + UBSan on the CPU, with
+# every kernel entry point replaced by a recording fake (tests/host/).
+asan-host: $(OUT)/host_asan_test
+	$(OUT)/host_asan_test
+
+$(OUT)/host_asan_test: tests/host/update_loop_harness.cpp $(CSRC)/update.cpp $(CSRC)/rollout_loop.cpp $(CSRC)/small_step.h $(CSRC)/fused_train.h include/garage_amd.h
+	@mkdir -p $(OUT)
+	g++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer \
+	  -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Wall -Wno-unused-function \
+	  tests/host/update_loop_harness.cpp $(CSRC)/update.cpp $(CSRC)/rollout_loop.cpp \
+	  -o $@
+
+.PHONY: asan-host

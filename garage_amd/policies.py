@@ -150,6 +150,75 @@ class _GaussianMLP:
     def set_param_values(self, state_dict):
         self.load_state_dict(state_dict)
 
+    # The rest of the ``nn.Module`` surface launchers and garage's own code touch
+    # (``torch/policies/policy.py:9-79``, ``trainer.py``, ``set_gpu_mode`` helpers):
+    # there are no sub-modules, no autograd graph and no train / eval distinction
+    # (no dropout, no batch norm), so these are bookkeeping only.
+    training = True
+
+    def train(self, mode=True):
+        self.training = bool(mode)
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def to(self, device=None, *args, **kwargs):
+        """Parameters live in HBM from construction; moving to another HIP device
+        copies the flat buffers, a CPU target is refused (no CPU fallback)."""
+        if device is None or isinstance(device, torch.dtype):
+            return self
+        device = torch.device(device)
+        if device.type != 'cuda':
+            raise RuntimeError(
+                'garage_amd modules live on the GPU; there is no CPU fallback')
+        if device.index is not None and device != self.device:
+            net = FlatMLP(self.net.in_dim, self.net.out_dim,
+                          self.net.hidden_sizes, device)
+            for k in ('params', 'grads', 'exp_avg', 'exp_avg_sq'):
+                getattr(net, k).copy_(getattr(self.net, k))
+            net.adam_steps = self.net.adam_steps
+            self.net, self.device = net, device
+        return self
+
+    def cuda(self, device=None):
+        return self.to(torch.device('cuda', torch.cuda.current_device()
+                                    if device is None else device))
+
+    def zero_grad(self, set_to_none=False):
+        del set_to_none
+        self.net.grads.zero_()
+
+    def modules(self):
+        return iter([self])
+
+    def children(self):
+        return iter([])
+
+    def named_modules(self, memo=None, prefix=''):
+        del memo
+        return iter([(prefix, self)])
+
+    def buffers(self):
+        """``min_std_param`` / ``max_std_param`` are buffers in the reference
+        (``gaussian_mlp_module.py:131-152``)."""
+        out = []
+        for v in (self._min_log_std, self._max_log_std):
+            if v is not None:
+                out.append(torch.tensor([v], device=self.device))
+        return out
+
+    def apply(self, fn):
+        fn(self)
+        return self
+
+    def requires_grad_(self, requires_grad=True):
+        del requires_grad  # gradients exist only inside the update kernels
+        return self
+
+    def __call__(self, *args, **kwargs):
+        return self.forward(*args, **kwargs)
+
     def copy_params_from(self, other):
         """Device-to-device parameter copy (``_old_policy`` sync)."""
         self.net.params.copy_(other.net.params)

@@ -1,0 +1,431 @@
+// Host-logic harness for the C++ epoch loops (garage_amd/csrc/update.cpp,
+// rollout_loop.cpp), built with -fsanitize=address,undefined on the CPU
+// (`make asan-host`; SURVEY.md section 5 "sanitizers": GPU sanitizers are not
+// available, the host loops are plain C++).  Every kernel entry point the loops
+// call -- and the handful of HIP runtime calls they make -- is replaced by a fake
+// that records the call, so the checks are about the loops' own arithmetic: which
+// rows form which minibatch, how many steps a pass takes (single process and data
+// parallel), the order in which two passes interleave, what is skipped in which
+// phase, and that argument errors are refused before anything is launched.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/garage_amd.h"
+#include "../../garage_amd/csrc/fused_train.h"
+#include "../../garage_amd/csrc/small_step.h"
+
+static std::vector<std::string> g_log;
+static std::string g_error;
+
+static void logf(const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_log.push_back(buf);
+}
+
+void ga_set_error(const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_error = buf;
+}
+
+// ---- HIP runtime fakes -------------------------------------------------------
+extern "C" {
+hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned) {
+  logf("wait stream=%p event=%p", (void*)s, (void*)e);
+  return hipSuccess;
+}
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) {
+  logf("record stream=%p event=%p", (void*)s, (void*)e);
+  return hipSuccess;
+}
+hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) {
+  static char slots[8];
+  static int next = 0;
+  *e = (hipEvent_t)&slots[next++ % 8];
+  return hipSuccess;
+}
+hipError_t hipMemsetAsync(void*, int, size_t bytes, hipStream_t) {
+  logf("memset %zu", bytes);
+  return hipSuccess;
+}
+hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+
+// ---- kernel entry point fakes --------------------------------------------------
+int ga_mlp_forward_f32(const ga_mlp_desc* d, const float*, const float*, int64_t,
+                       const int32_t* idx, int64_t M, float*, float* out, int64_t,
+                       ga_stream_t s) {
+  logf("fwd M=%lld idx0=%d layers=%d out=%d stream=%p", (long long)M, idx ? idx[0] : -1,
+       d->n_layers, out != nullptr, s);
+  if (idx) {  // touch every id of the minibatch: out-of-range slices trip ASAN
+    long long sum = 0;
+    for (int64_t i = 0; i < M; ++i) sum += idx[i];
+    logf("idxsum %lld", sum);
+  }
+  return 0;
+}
+int ga_ppo_gaussian_loss_f32(const float*, int64_t, const float*, int64_t, const float*,
+                             const float*, const int32_t*, const float*, int, float, int,
+                             float, int64_t M, int A, int algo, float, float, int, float*,
+                             float*, float* loss_out, float*, int64_t, int64_t splits,
+                             double*, ga_stream_t) {
+  logf("ppo_loss M=%lld A=%d algo=%d splits=%lld", (long long)M, A, algo, (long long)splits);
+  if (loss_out) *loss_out = (float)M;
+  return 0;
+}
+int ga_ppo_categorical_loss_f32(const float*, int64_t, const float*, int64_t, const float*,
+                                const float*, const int32_t*, int64_t M, int, int, int,
+                                float, float, int, float*, float*, float*, float*, double*,
+                                float*, int64_t, int64_t, double*, ga_stream_t) {
+  logf("cat_loss M=%lld", (long long)M);
+  return 0;
+}
+int ga_gaussian_nll_loss_f32(const float*, int64_t, const float*, const int32_t*,
+                             const float*, int64_t M, float*, float*, float*, int64_t,
+                             int64_t, double*, ga_stream_t) {
+  logf("nll_loss M=%lld", (long long)M);
+  return 0;
+}
+int ga_head_loss_supported(int, int) { return 0; }
+int ga_head_ppo_gaussian_loss_f32(const float*, int64_t, const float*, int64_t,
+                                  const float*, int, float*, int64_t, const float*, int64_t,
+                                  const float*, const float*, const int32_t*, const float*,
+                                  int, float, int, float, int64_t, int, int, float, float,
+                                  int, float*, int64_t, float*, float*, float*, int64_t,
+                                  int64_t, double*, ga_stream_t) {
+  return 0;
+}
+int ga_head_gaussian_nll_loss_f32(const float*, int64_t, const float*, const float*, int,
+                                  float*, int64_t, const float*, const int32_t*,
+                                  const float*, int64_t, float*, int64_t, float*, float*,
+                                  int64_t, int64_t, double*, ga_stream_t) {
+  return 0;
+}
+int64_t ga_mlp_backward_splits(const ga_mlp_desc*, int64_t M) { return (M + 255) / 256; }
+int ga_mlp_backward_f32(const ga_mlp_desc*, const float*, const float*, int64_t,
+                        const int32_t*, int64_t M, const float*, const float*, int64_t,
+                        float*, float*, int64_t, int64_t splits, ga_stream_t) {
+  logf("bwd M=%lld splits=%lld", (long long)M, (long long)splits);
+  return 0;
+}
+int ga_mlp_backward_range_f32(const ga_mlp_desc*, const float*, const float*, int64_t,
+                              const int32_t*, int64_t M, const float*, const float*,
+                              int64_t, float*, float*, int64_t, int64_t, int l_start,
+                              int fused_first, ga_stream_t) {
+  logf("bwd_range M=%lld l_start=%d fused_first=%d", (long long)M, l_start, fused_first);
+  return 0;
+}
+int ga_reduce_adam_f32(const float*, int64_t splits, int64_t, float*, float*, float*,
+                       float*, int64_t, int64_t step, double, double, double, double,
+                       int zero0, ga_stream_t) {
+  logf("reduce_adam splits=%lld step=%lld zero0=%d", (long long)splits, (long long)step,
+       zero0);
+  return 0;
+}
+int ga_reduce_slabs_f32(const float*, int64_t splits, int64_t, int64_t, float scale,
+                        float*, ga_stream_t) {
+  logf("reduce_slabs splits=%lld scale=%.4f", (long long)splits, scale);
+  return 0;
+}
+int ga_adam_step_f32(float*, const float*, float*, float*, int64_t, int64_t step, double,
+                     double, double, double, ga_stream_t) {
+  logf("adam step=%lld", (long long)step);
+  return 0;
+}
+int64_t ga_reduction_partials_doubles(void) { return 1024; }
+int ga_small_step_supported(int n_layers, const int* dims, int64_t M) {
+  return n_layers == 3 && dims[1] == dims[2] && dims[1] % 32 == 0 && dims[1] <= 256 &&
+         dims[0] <= 32 && dims[3] <= 8 && M >= 1 && M <= 64;
+}
+int ga_small_step_resident(int, int) { return 1; }
+int ga_small_step(const ga_small_step_args* a, void*) {
+  logf("small_step M=%d step=%lld", a->M, (long long)a->step);
+  return 0;
+}
+int ga_fused_width_ok(int w) { return w == 64 || w == 128 || w == 256; }
+int64_t ga_fused_tiles(int64_t M) { return (M + 63) / 64; }
+int ga_fused_fwd_head_loss(const float*, int64_t, const int32_t* a_idx, const float*,
+                           int64_t, const float*, int64_t M, int width, int K,
+                           const float*, int64_t, const float*,
+                           const ga_fused_loss_args* loss, float*, int64_t, float* hpart,
+                           double* lpart, hipStream_t) {
+  logf("fused_fwd M=%lld width=%d K=%d a_idx=%d A=%d", (long long)M, width, K,
+       a_idx != nullptr, loss->A);
+  // the partial-sum scratch must hold what the plan says
+  const int64_t tiles = ga_fused_tiles(M);
+  for (int64_t t = 0; t < tiles; ++t) {
+    lpart[2 * t] = 0.0;
+    lpart[2 * t + 1] = 0.0;
+    memset(hpart + t * (8 * (int64_t)width + 8), 0, sizeof(float) * (8 * width + 8));
+  }
+  return 0;
+}
+int ga_fused_dgrad_wgrad0(const float*, int64_t, const float*, int64_t, int64_t M,
+                          int width, int K, const float*, int64_t, const float*, int64_t,
+                          const int32_t*, int in_w, float* wpart, hipStream_t) {
+  logf("fused_dgrad M=%lld width=%d K=%d in=%d", (long long)M, width, K, in_w);
+  const int64_t ld0 = (in_w + 3) & ~3;
+  const int64_t tiles = ga_fused_tiles(M);
+  for (int64_t t = 0; t < tiles; ++t)
+    memset(wpart + t * (width * ld0 + width), 0, sizeof(float) * (width * ld0 + width));
+  return 0;
+}
+int ga_reduce_regions_adam(const ga_fused_region* r, int n, float*, float*, float*, float*,
+                           int64_t step, double, double, double, double, float scale,
+                           int do_adam, int zero0, const double*, int n_lpart, int64_t M,
+                           const ga_fused_loss_args*, float* loss_out, hipStream_t) {
+  logf("reduce_regions n=%d step=%lld scale=%.4f adam=%d zero0=%d lparts=%d M=%lld", n,
+       (long long)step, scale, do_adam, zero0, n_lpart, (long long)M);
+  for (int k = 0; k < n; ++k)
+    logf("  region beg=%lld n=%lld parts=%d stride=%lld", (long long)r[k].beg,
+         (long long)r[k].n, r[k].n_part, (long long)r[k].stride);
+  if (loss_out) *loss_out = 1.f;
+  return 0;
+}
+int ga_policy_step_fused_supported(const ga_mlp_desc*) { return 1; }
+int ga_policy_step_fused_f32(const ga_mlp_desc*, const float*, const ga_head_args* h,
+                             ga_stream_t) {
+  logf("policy_step col=%lld step=%u obs=%p", (long long)h->col, h->step, (void*)h->obs);
+  return 0;
+}
+int ga_synth_env_step_record_norm(const ga_synth_env*, const ga_record_args* r,
+                                  const ga_norm_args* nm, const float* act, int64_t,
+                                  const float* obs, ga_stream_t) {
+  logf("env_step col=%lld obs=%p next=%p act=%p norm=%d", (long long)r->col, (void*)obs,
+       (void*)r->next_obs, (void*)act, nm != nullptr);
+  return 0;
+}
+int ga_action_rescale_f32(int64_t n, int A, const float*, int64_t, const float*,
+                          const float*, float s, float*, int64_t, ga_stream_t) {
+  logf("rescale n=%lld A=%d s=%.2f", (long long)n, A, s);
+  return 0;
+}
+}  // extern "C"
+
+// ---- checks ------------------------------------------------------------------
+static int g_failed = 0;
+#define CHECK(cond)                                                       \
+  do {                                                                    \
+    if (!(cond)) {                                                        \
+      fprintf(stderr, "FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond);   \
+      ++g_failed;                                                         \
+    }                                                                     \
+  } while (0)
+
+static int count(const char* prefix) {
+  int n = 0;
+  for (auto& l : g_log) n += l.rfind(prefix, 0) == 0;
+  return n;
+}
+static std::vector<long long> ms_of(const char* prefix) {
+  std::vector<long long> out;
+  for (auto& l : g_log)
+    if (l.rfind(prefix, 0) == 0) {
+      long long m = -1;
+      sscanf(l.c_str() + strlen(prefix), " M=%lld", &m);
+      out.push_back(m);
+    }
+  return out;
+}
+
+struct Net {
+  ga_mlp_desc d;
+  std::vector<float> params, acts, slabs, scratch;
+  explicit Net(int in, int h1, int h2, int out) {
+    memset(&d, 0, sizeof(d));
+    d.n_layers = 3;
+    d.dims[0] = in; d.dims[1] = h1; d.dims[2] = h2; d.dims[3] = out;
+    int64_t off = 4;
+    const int w[4] = {in, h1, h2, out};
+    for (int l = 0; l < 3; ++l) {
+      d.w_off[l] = off; off += (int64_t)w[l + 1] * ((w[l] + 3) & ~3);
+      d.b_off[l] = off; off += (w[l + 1] + 3) & ~3;
+    }
+    d.act_off[0] = 0; d.act_off[1] = 1 << 16;
+    params.assign(off, 0.f);
+    acts.assign(1 << 18, 0.f);
+    slabs.assign(off * 8, 0.f);
+    scratch.assign(16, 0.f);
+  }
+  ga_update_args args(int64_t S, int64_t mb, const int32_t* perm, int kind) {
+    ga_update_args a;
+    memset(&a, 0, sizeof(a));
+    a.desc = &d; a.params = a.grads = a.exp_avg = a.exp_avg_sq = params.data();
+    a.n_flat = (int64_t)params.size();
+    a.acts = a.dacts = acts.data(); a.out = a.dout = acts.data(); a.ldo = 8;
+    a.slabs = slabs.data(); a.max_splits = 8;
+    a.lr = 1e-3; a.beta1 = 0.9; a.beta2 = 0.999; a.eps = 1e-8; a.learn_std = 1;
+    a.X = params.data(); a.ldx = (d.dims[0] + 3) & ~3; a.S = S; a.perm = perm; a.mb = mb;
+    a.kind = kind; a.actions = params.data(); a.lda = 4; a.old_ll = a.adv = a.returns =
+        params.data();
+    a.loss_scratch = scratch.data();
+    static std::vector<double> ws(2048, 0.0);
+    a.workspace = ws.data();
+    return a;
+  }
+};
+
+extern "C" int ga_set_small_step(int on);
+extern "C" int ga_set_fused_train(int on);
+extern "C" int64_t ga_update_partials_floats(const ga_mlp_desc* d, int64_t M);
+extern "C" void ga_set_allreduce_hook(ga_allreduce_fn fn);
+static int fake_allreduce(void*, float*, int64_t n, void*) {
+  logf("allreduce n=%lld", (long long)n);
+  return 0;
+}
+
+int main() {
+  std::vector<int32_t> perm(23);
+  for (int i = 0; i < 23; ++i) perm[i] = 22 - i;
+  Net net(17, 48, 48, 6);  // 48-wide: neither the small step nor the fused step
+  // 1. BatchDataset minibatches: ceil(S / mb) of mb ids, the last one partial
+  {
+    g_log.clear();
+    ga_update_args a = net.args(23, 5, perm.data(), 0);
+    CHECK(ga_update_epoch(&a, nullptr) == 0);
+    CHECK((ms_of("fwd") == std::vector<long long>{5, 5, 5, 5, 3}));
+    CHECK(count("reduce_adam") == 5 && count("adam step") == 0);
+    CHECK(g_log[0].find("idx0=22") != std::string::npos);
+  }
+  // 2. the even split of a data-parallel rank: exactly n_mb steps, per-step scales,
+  //    one all-reduce each, Adam after it
+  {
+    g_log.clear();
+    ga_set_allreduce_hook(fake_allreduce);
+    const float scales[4] = {0.25f, 0.5f, 0.75f, 1.0f};
+    ga_update_args a = net.args(23, 0, perm.data(), 1);
+    a.n_mb = 4; a.grad_scales_host = scales; a.comm = (void*)1; a.world = 2;
+    a.step0 = 10;
+    CHECK(ga_update_epoch(&a, nullptr) == 0);
+    CHECK((ms_of("fwd") == std::vector<long long>{5, 6, 6, 6}));
+    CHECK(count("allreduce") == 4 && count("reduce_adam") == 0);
+    CHECK(count("reduce_slabs splits=1 scale=0.2500") == 1);
+    CHECK(count("reduce_slabs splits=1 scale=1.0000") == 1);
+    CHECK(count("adam step=11") == 1 && count("adam step=14") == 1);
+  }
+  // 3. phase 1 stops at the scaled gradient: no exchange, no optimizer
+  {
+    g_log.clear();
+    ga_update_args a = net.args(23, 23, perm.data(), 0);
+    a.phase = 1; a.grad_scale = 0.5f;
+    CHECK(ga_update_epoch(&a, nullptr) == 0);
+    CHECK(count("reduce_slabs splits=1 scale=0.5000") == 1);
+    CHECK(count("adam") == 0 && count("allreduce") == 0 && count("reduce_adam") == 0);
+  }
+  // 4. two passes interleave minibatch by minibatch on their streams
+  {
+    g_log.clear();
+    Net other(17, 48, 48, 1);
+    ga_update_args a = net.args(23, 8, perm.data(), 0);
+    ga_update_args b = other.args(23, 8, perm.data(), 1);
+    std::vector<double> ws2(2048, 0.0);
+    b.workspace = ws2.data();
+    CHECK(ga_update_epoch_pair(&a, (void*)0x10, &b, (void*)0x20) == 0);
+    std::vector<std::string> order;
+    for (auto& l : g_log)
+      if (l.rfind("fwd", 0) == 0)
+        order.push_back(l.find("stream=0x10") != std::string::npos ? "a" : "b");
+    CHECK((order == std::vector<std::string>{"a", "b", "a", "b", "a", "b"}));
+    // sharing buffers is refused
+    CHECK(ga_update_epoch_pair(&a, (void*)0x10, &a, (void*)0x20) != 0);
+  }
+  // 5. argument errors never launch
+  {
+    g_log.clear();
+    ga_update_args a = net.args(0, 5, perm.data(), 0);
+    CHECK(ga_update_epoch(&a, nullptr) != 0 && g_log.empty());
+    a = net.args(23, 0, perm.data(), 0);
+    CHECK(ga_update_epoch(&a, nullptr) != 0 && g_log.empty());
+    a = net.args(23, 5, perm.data(), 0);
+    a.n_mb = 24;  // more minibatches than samples
+    CHECK(ga_update_epoch(&a, nullptr) != 0 && g_log.empty());
+    CHECK(ga_update_epoch(nullptr, nullptr) != 0);
+    a = net.args(4000, 4000, nullptr, 0);
+    a.max_splits = 2;  // slab workspace too small for 16 splits
+    CHECK(ga_update_epoch(&a, nullptr) != 0);
+    CHECK(g_error.find("slab workspace") != std::string::npos);
+  }
+  // 6. the small step takes minibatches of <= 64 rows of a 2 x H net
+  {
+    g_log.clear();
+    Net small(17, 64, 64, 6);
+    std::vector<int32_t> p2(200);
+    for (int i = 0; i < 200; ++i) p2[i] = i;
+    ga_update_args a = small.args(200, 64, p2.data(), 0);
+    ga_set_fused_train(0);
+    CHECK(ga_update_epoch(&a, nullptr) == 0);
+    CHECK(count("small_step") == 4 && count("fwd") == 0);  // 64, 64, 64, 8
+    ga_set_small_step(0);
+    g_log.clear();
+    CHECK(ga_update_epoch(&a, nullptr) == 0);
+    CHECK(count("small_step") == 0 && count("fwd") == 4);
+    ga_set_small_step(1);
+    ga_set_fused_train(1);
+  }
+  // 7. the fused step: plan, scratch layout, regions
+  {
+    g_log.clear();
+    Net wide(17, 256, 256, 6);
+    const int64_t M = 1000;
+    const int64_t need = ga_update_partials_floats(&wide.d, M);
+    const int64_t tiles = (M + 63) / 64;
+    CHECK(need == 4 * tiles + tiles * (8 * 256 + 8) + tiles * (256 * 20 + 256));
+    CHECK(ga_update_partials_floats(&net.d, M) == 0);  // 48-wide: per-layer path
+    std::vector<float> partials((size_t)need, 1.f);  // exactly what was asked for
+    std::vector<int32_t> p3(M);
+    for (int i = 0; i < M; ++i) p3[i] = i;
+    ga_update_args a = wide.args(M, M, p3.data(), 0);
+    a.partials = partials.data(); a.partials_floats = need;
+    CHECK(ga_update_epoch(&a, nullptr) == 0);
+    CHECK(count("fused_fwd M=1000 width=256 K=256 a_idx=0 A=6") == 1);
+    CHECK(count("bwd_range M=1000 l_start=1 fused_first=1") == 1);
+    CHECK(count("fused_dgrad M=1000 width=256 K=256 in=17") == 1);
+    CHECK(count("reduce_regions n=6 step=1 scale=1.0000 adam=1 zero0=0 lparts=16") == 1);
+    CHECK(count("fwd M=1000") == 1);  // the hidden layers below the last one
+    // a scratch one float short falls back to the per-layer kernels
+    g_log.clear();
+    a.partials_floats = need - 1;
+    CHECK(ga_update_epoch(&a, nullptr) == 0);
+    CHECK(count("fused_fwd") == 0 && count("reduce_adam") == 1);
+  }
+  // 8. the native rollout loop ping-pongs the observation buffers
+  {
+    g_log.clear();
+    ga_head_args h;
+    memset(&h, 0, sizeof(h));
+    h.col = 3; h.Tcap = 16; h.step = 100;
+    ga_synth_env env;
+    memset(&env, 0, sizeof(env));
+    env.n = 4; env.act_dim = 2;
+    ga_record_args rec;
+    memset(&rec, 0, sizeof(rec));
+    float A[4], B[4];
+    Net pol(17, 64, 64, 6);
+    CHECK(ga_rollout_synth_steps(&pol.d, pol.params.data(), &h, &env, &rec, A, B, nullptr,
+                                 nullptr, nullptr, 3, nullptr) == 0);
+    CHECK(count("policy_step") == 3 && count("env_step") == 3);
+    char want[128];
+    snprintf(want, sizeof(want), "env_step col=4 obs=%p next=%p", (void*)B, (void*)A);
+    CHECK(count(want) == 1);
+    CHECK(ga_rollout_synth_steps(&pol.d, pol.params.data(), &h, &env, &rec, A, B, nullptr,
+                                 nullptr, nullptr, 14, nullptr) != 0);  // past Tcap
+  }
+  if (g_failed) {
+    fprintf(stderr, "%d check(s) failed\n", g_failed);
+    return 1;
+  }
+  printf("host loops ok\n");
+  return 0;
+}

@@ -43,3 +43,19 @@ def test_product_never_imports_the_oracle():
                 if re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M):
                     bad.append(f)
     assert not bad, bad
+
+
+def test_host_loops_under_address_sanitizer():
+    """``make asan-host``: the C++ epoch and rollout loops (update.cpp,
+    rollout_loop.cpp) compiled with ``-fsanitize=address,undefined`` for the CPU
+    and run against recording fakes of every kernel entry point
+    (tests/host/update_loop_harness.cpp): minibatch ranges, the data-parallel even
+    split and per-step scales, phase 1, the interleaving of two passes, argument
+    errors, the fused step's scratch layout and regions, the rollout loop's buffer
+    ping-pong.  GPU sanitizers are not available on this pool."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run(['make', '-C', root, 'asan-host'], capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert 'host loops ok' in out.stdout

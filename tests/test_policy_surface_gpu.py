@@ -88,3 +88,38 @@ def test_policy_and_value_function_surface_matches_real_classes(golden, tag):
     loss = vf.compute_loss(torch.from_numpy(obs), torch.from_numpy(ret))
     assert np.isclose(float(loss), float(g[tag + '_vf_loss']), rtol=1e-5,
                       atol=1e-6)
+
+
+def test_nn_module_surface():
+    """The ``nn.Module`` methods garage's own code and launchers call on a policy
+    / value function (``torch/policies/policy.py:9-79``: ``parameters``,
+    ``state_dict`` ...; ``.to()``, ``.train()`` / ``.eval()``, ``.zero_grad()``,
+    ``.modules()``, calling the module): bookkeeping on the flat HBM buffers."""
+    from garage_amd._dtypes import Box, EnvSpec
+    from garage_amd.policies import GaussianMLPPolicy, GaussianMLPValueFunction
+    spec = EnvSpec(Box(-np.inf, np.inf, (5, )), Box(-np.inf, np.inf, (2, )),
+                   max_episode_length=10)
+    torch.manual_seed(0)
+    pol = GaussianMLPPolicy(spec, hidden_sizes=(8, 8))
+    vf = GaussianMLPValueFunction(spec, hidden_sizes=(8, 8))
+    for m in (pol, vf):
+        assert m.train() is m and m.training is True
+        assert m.eval() is m and m.training is False
+        assert m.to('cuda') is m and m.to(torch.float32) is m and m.cuda() is m
+        with pytest.raises(RuntimeError, match='no CPU fallback'):
+            m.to('cpu')
+        assert list(m.modules()) == [m] and list(m.children()) == []
+        assert [n for n, _ in m.named_modules()] == ['']
+        m.net.grads.fill_(1.0)
+        m.zero_grad()
+        assert float(m.net.grads.abs().sum()) == 0.0
+        assert m.requires_grad_(False) is m and m.apply(lambda x: None) is m
+        names = [n for n, _ in m.named_parameters()]
+        assert names[0] == '_module._init_std'
+        assert len(list(m.parameters())) == len(names)
+    assert len(pol.buffers()) == 1 and len(vf.buffers()) == 0  # min_std_param
+    obs = torch.randn(4, 5)
+    dist, info = pol(obs)  # __call__ == forward
+    dist2, _ = pol.forward(obs)
+    assert torch.equal(dist.mean, dist2.mean) and 'mean' in info
+    assert torch.equal(vf(obs), vf.forward(obs))
