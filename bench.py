@@ -153,8 +153,9 @@ KIND_NAMES = [
     'skinny_wgrad_kernel (first-layer / head weight grad; work = bytes)',
     'fwd_head_loss_kernel<256,1,8> (last hidden layer + head + loss + seed)',
     'dgrad_wgrad0_kernel<256,1,8> (data grad + first-layer weight grad)',
+    'narrow_train_kernel<64> (forward + loss + backward of a 2 x 64 net)',
 ]
-GEMM_KINDS = (0, 1, 2, 3, 4, 5, 9, 10)  # MFMA kernels: work = flops
+GEMM_KINDS = (0, 1, 2, 3, 4, 5, 9, 10, 11)  # MFMA kernels: work = flops
 
 
 TRAFFIC_FILE = 'profiles/r01_traffic.json'

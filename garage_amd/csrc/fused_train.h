@@ -40,6 +40,14 @@ int ga_fused_dgrad_wgrad0(const float* dZ2, int64_t lddz, const float* W2, int64
                           int64_t M, int width, int K, const float* H1, int64_t ldh,
                           const float* X, int64_t ldx, const int32_t* idx, int in_w,
                           float* wpart, hipStream_t stream);
+// narrow_step.hip: forward + loss + backward of a 2 x H network (H = 32 or 64) in one
+// launch; part: [tiles][ga_narrow_step_stride] floats, lpart: [tiles][2] doubles
+int ga_narrow_step_supported(int n_layers, const int* dims);
+int64_t ga_narrow_step_stride(int in_w, int H);
+int ga_narrow_train_step(const float* params, const int64_t* w_off, const int64_t* b_off,
+                         int in_w, int H, int out_w, const float* X, int64_t ldx,
+                         int64_t M, const ga_fused_loss_args* loss, float* part,
+                         double* lpart, hipStream_t stream);
 int ga_reduce_regions_adam(const ga_fused_region* regions, int n_regions, float* params,
                            float* grads, float* exp_avg, float* exp_avg_sq, int64_t step,
                            double lr, double beta1, double beta2, double eps, float scale,

@@ -82,9 +82,18 @@ static int trace_on() {
     }                                                           \
   } while (0)
 
+// 2 x H networks with H = 32 or 64: forward + loss + backward in ONE launch
+// (narrow_step.hip); 0 = the fused GEMM-epilogue kernels / per-layer kernels
+static int g_narrow_step = 1;
+extern "C" int ga_set_narrow_step(int on) {
+  g_narrow_step = on != 0;
+  return 0;
+}
+
 namespace {
 struct FusedPlan {
   bool ok = false;
+  bool narrow = false;    // the whole step in one launch (narrow_step.hip)
   bool first = false;     // data gradient into layer 0 + its weight gradient fused too
   int64_t tiles = 0;
   int64_t lpart_off = 0, hpart_off = 0, wpart_off = 0, floats = 0;
@@ -97,6 +106,16 @@ FusedPlan fused_plan(const ga_mlp_desc* d, int64_t M) {
   FusedPlan f;
   const int L = d->n_layers;
   if (L < 2 || L > 8 || M < 1) return f;
+  if (g_narrow_step && ga_narrow_step_supported(L, d->dims)) {
+    f.ok = f.narrow = true;
+    f.tiles = ga_fused_tiles(M);
+    f.hstride = ga_narrow_step_stride(d->dims[0], d->dims[1]);
+    f.lpart_off = 0;
+    f.hpart_off = 4 * f.tiles;
+    f.wpart_off = f.hpart_off + f.tiles * f.hstride;
+    f.floats = f.wpart_off;
+    return f;
+  }
   if (!ga_fused_width_ok(d->dims[L - 1]) || d->dims[L] > 8) return f;
   f.ok = true;
   f.tiles = ga_fused_tiles(M);
@@ -242,6 +261,47 @@ int run_minibatch_fused(const ga_update_args* a, const FusedPlan& f, int64_t k,
   }
   auto r4 = [](int v) { return (int64_t)((v + 3) & ~3); };
   int rc;
+  if (f.narrow) {
+    ga_fused_loss_args la;
+    memset(&la, 0, sizeof(la));
+    la.kind = a->kind; la.actions = a->actions; la.lda = a->lda; la.old_ll = a->old_ll;
+    la.adv = a->adv; la.returns = a->returns; la.idx = idx; la.log_std = a->params;
+    la.has_min = a->has_min; la.has_max = a->has_max; la.min_log_std = a->min_log_std;
+    la.max_log_std = a->max_log_std; la.A = out_w; la.algo = a->algo; la.clip = a->clip;
+    la.ent_coeff = a->ent_coeff; la.ent_flags = a->ent_flags;
+    la.double_softmax = a->double_softmax;
+    double* lpart = reinterpret_cast<double*>(a->partials + f.lpart_off);
+    float* part = a->partials + f.hpart_off;
+    const int H = d->dims[1];
+    rc = ga_narrow_train_step(a->params, d->w_off, d->b_off, d->dims[0], H, out_w, a->X,
+                              a->ldx, M, &la, part, lpart, stream);
+    if (rc) return rc;
+    const int64_t ld0 = r4(d->dims[0]);
+    const int64_t off[6] = {0, (int64_t)H * ld0, (int64_t)H * ld0 + H,
+                            (int64_t)H * ld0 + H + (int64_t)H * H,
+                            (int64_t)H * ld0 + 2 * H + (int64_t)H * H,
+                            (int64_t)H * ld0 + 2 * H + (int64_t)H * H + 8 * (int64_t)H};
+    ga_fused_region reg[6];
+    for (int l = 0; l < 3; ++l) {
+      reg[2 * l].beg = d->w_off[l];
+      reg[2 * l].n = (int64_t)d->dims[l + 1] * r4(d->dims[l]);
+      reg[2 * l + 1].beg = d->b_off[l];
+      reg[2 * l + 1].n = d->dims[l + 1];
+    }
+    for (int k = 0; k < 6; ++k) {
+      reg[k].src = part + off[k];
+      reg[k].stride = f.hstride;
+      reg[k].n_part = (int)f.tiles;
+    }
+    const bool exchange = a->comm && a->phase != 1;
+    const bool do_adam = !exchange && a->phase != 1;
+    rc = ga_reduce_regions_adam(reg, 6, a->params, a->grads, a->exp_avg, a->exp_avg_sq,
+                                a->step0 + k + 1, a->lr, a->beta1, a->beta2, a->eps,
+                                step_scale(a, k), do_adam ? 1 : 0, !a->learn_std, lpart,
+                                (int)f.tiles, M, &la, loss_slot, stream);
+    if (rc || !exchange) return rc;
+    return allreduce_and_adam(a, k, stream_, order);
+  }
   if (L >= 3) {
     ga_mlp_desc below = *d;  // layers 0 .. L-3: the hidden layers under the last one
     below.n_layers = L - 1;

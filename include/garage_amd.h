@@ -495,6 +495,11 @@ int64_t ga_update_partials_floats(const ga_mlp_desc* desc, int64_t M);
  * that also finishes the loss.  Same formulas, other summation orders than the
  * per-layer kernels (0 selects those): results agree to rounding. */
 int ga_set_fused_train(int on);
+/* 1 (default): networks of two equal tanh hidden layers of 32 or 64 units (<= 32
+ * inputs, <= 8 outputs) take forward + loss + backward of a minibatch in ONE launch
+ * (every weight in LDS, 64 rows per workgroup) followed by the same reduction +
+ * Adam launch; 0: the kernels above.  Needs `partials` like them. */
+int ga_set_narrow_step(int on);
 /* The policy pass and the value-function pass of one epoch, minibatch by
  * minibatch alternately on two streams.  The reference runs them back to back
  * (vpg.py:244-248); they share no written state, so the results are identical

@@ -194,6 +194,26 @@ int ga_reduce_regions_adam(const ga_fused_region* r, int n, float*, float*, floa
   if (loss_out) *loss_out = 1.f;
   return 0;
 }
+int ga_narrow_step_supported(int n_layers, const int* dims) {
+  return n_layers == 3 && dims[1] == dims[2] && (dims[1] == 32 || dims[1] == 64) &&
+         dims[0] <= 32 && dims[3] <= 8;
+}
+int64_t ga_narrow_step_stride(int in_w, int H) {
+  const int64_t ld0 = (in_w + 3) & ~3;
+  return (int64_t)H * ld0 + H + (int64_t)H * H + H + 8 * (int64_t)H + 8;
+}
+int ga_narrow_train_step(const float*, const int64_t*, const int64_t*, int in_w, int H,
+                         int out_w, const float*, int64_t, int64_t M,
+                         const ga_fused_loss_args*, float* part, double* lpart,
+                         hipStream_t) {
+  logf("narrow M=%lld in=%d H=%d out=%d", (long long)M, in_w, H, out_w);
+  const int64_t tiles = ga_fused_tiles(M), stride = ga_narrow_step_stride(in_w, H);
+  for (int64_t t = 0; t < tiles; ++t) {
+    lpart[2 * t] = lpart[2 * t + 1] = 0.0;
+    memset(part + t * stride, 0, sizeof(float) * stride);
+  }
+  return 0;
+}
 int ga_policy_step_fused_supported(const ga_mlp_desc*) { return 1; }
 int ga_policy_step_fused_f32(const ga_mlp_desc*, const float*, const ga_head_args* h,
                              ga_stream_t) {
@@ -399,6 +419,23 @@ int main() {
     a.partials_floats = need - 1;
     CHECK(ga_update_epoch(&a, nullptr) == 0);
     CHECK(count("fused_fwd") == 0 && count("reduce_adam") == 1);
+  }
+  // 7b. 2 x 64 networks: the whole step in one launch + the reduction
+  {
+    g_log.clear();
+    Net narrow(4, 64, 64, 2);
+    const int64_t M = 200, tiles = 4;
+    const int64_t need = ga_update_partials_floats(&narrow.d, M);
+    CHECK(need == 4 * tiles + tiles * ga_narrow_step_stride(4, 64));
+    std::vector<float> partials((size_t)need, 1.f);
+    std::vector<int32_t> p4(M);
+    for (int i = 0; i < M; ++i) p4[i] = i;
+    ga_update_args a = narrow.args(M, 100, p4.data(), 2);
+    a.partials = partials.data(); a.partials_floats = need;
+    CHECK(ga_update_epoch(&a, nullptr) == 0);
+    CHECK(count("narrow M=100 in=4 H=64 out=2") == 2 && count("fwd") == 0);
+    CHECK(count("reduce_regions n=6 step=1") == 1 && count("reduce_regions n=6 step=2") == 1);
+    CHECK(count("  region beg=4 n=256 parts=2") == 2);  // W1, both steps
   }
   // 8. the native rollout loop ping-pongs the observation buffers
   {

@@ -37,6 +37,13 @@ CASES = {
                                  'policy_ent_coeff': 0.01, 'center_adv': False,
                                  'stop_entropy_gradient': True}),
     'full_batch': (8, 2, (64, 64), None, False, {}),
+    # 2 x 32 / 2 x 64 networks: the whole step in one launch (narrow_step.hip)
+    'narrow_32': (4, 2, (32, 32), 200, True, {}),
+    'narrow_32_gaussian_wide_input': (32, 8, (32, 32), 333, False, {}),
+    'narrow_64_ragged': (13, 5, (64, 64), 1000, False, {}),
+    'narrow_64_entropy': (6, 3, (64, 64), 450, False,
+                          {'entropy_method': 'regularized',
+                           'policy_ent_coeff': 0.03}),
 }
 
 
@@ -107,6 +114,7 @@ def test_fused_step_gradients_match_per_layer_path(case):
     try:
         for on in (1, 0):
             lib.ga_set_fused_train(on)
+            lib.ga_set_small_step(on)  # reference path: per-layer kernels only
             algo, pol, vf = _algo(
                 case, spec, (torch.optim.Adam, dict(lr=lr, betas=(0.0, 0.0),
                                                     eps=1.0)))
@@ -117,6 +125,7 @@ def test_fused_step_gradients_match_per_layer_path(case):
                        dict(algo.last_tabular))
     finally:
         lib.ga_set_fused_train(1)
+        lib.ga_set_small_step(1)
     for i in (0, 1):
         scale = float(out[0][i].abs().max())
         assert scale > 1e-3  # the pass did move the parameters
@@ -128,7 +137,7 @@ def test_fused_step_gradients_match_per_layer_path(case):
 
 
 @pytest.mark.parametrize('case', ['c3_shape', 'c2_shape_categorical',
-                                  'three_hidden'])
+                                  'three_hidden', 'narrow_32'])
 def test_fused_step_python_loop_and_native_loop_are_the_same_bits(case):
     """A subclass that hooks ``_train_policy`` forces the Python minibatch loop,
     which drives the same entry point one minibatch at a time: same bits as the
@@ -177,3 +186,32 @@ def test_fused_step_is_reproducible_and_actually_taken():
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
     assert not torch.equal(res[0][0], res[2][0])
     assert float((res[0][0] - res[2][0]).abs().max()) < 5e-4
+
+
+def test_narrow_step_is_taken_and_matches_the_gemm_epilogue_kernels():
+    """2 x 64 networks are eligible for both fused paths: the one-launch narrow
+    step is the default; switching it off falls back to the GEMM-epilogue kernels;
+    all three (with the per-layer kernels) agree to rounding."""
+    from garage_amd import _lib
+    lib = _lib.load()
+    spec, batch = _problem('c2_shape_categorical')
+    opt = (torch.optim.Adam, dict(lr=1e-3, betas=(0.0, 0.0), eps=1.0))
+    res = []
+    try:
+        for narrow, fused in ((1, 1), (0, 1), (0, 0)):
+            lib.ga_set_narrow_step(narrow)
+            lib.ga_set_fused_train(fused)
+            algo, pol, vf = _algo('c2_shape_categorical', spec, opt)
+            p0, v0 = pol.net.params.clone(), vf.net.params.clone()
+            np.random.seed(11)
+            algo._train_once(0, batch)
+            res.append(((pol.net.params - p0) / 1e-3, (vf.net.params - v0) / 1e-3))
+    finally:
+        lib.ga_set_narrow_step(1)
+        lib.ga_set_fused_train(1)
+    assert not torch.equal(res[0][0], res[1][0])  # different kernels ran
+    for other in res[1:]:
+        for i in (0, 1):
+            scale = float(res[2][i].abs().max())
+            d = float((res[0][i] - other[i]).abs().max())
+            assert d < 1e-4 * scale + 4e-5, (i, d, scale)
