@@ -469,7 +469,7 @@ struct FtRegion {
   const float* src;   // partial 0 of element 0
   int64_t stride;     // floats between consecutive partials
   int n_part;
-  int ways;           // lane groups of a wave that share the partials (1, 2, 4, 8)
+  int ways;           // lane groups of a wave that share the partials (1 .. 64)
   int64_t vbeg;       // first virtual thread (a multiple of 64)
 };
 struct ReduceRegionsParams {
@@ -551,14 +551,12 @@ __global__ __launch_bounds__(256) void reduce_regions_adam_kernel(ReduceRegionsP
       acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
     }
   }
-  // the ways' sums, added in way order (every lane of the wave takes part)
-  float g[4] = {0.f, 0.f, 0.f, 0.f};
-  const int peer = lane % Q;
-  for (int w = 0; w < ways; ++w) {
-    g[0] += __shfl(acc.x, peer + w * Q, 64);
-    g[1] += __shfl(acc.y, peer + w * Q, 64);
-    g[2] += __shfl(acc.z, peer + w * Q, 64);
-    g[3] += __shfl(acc.w, peer + w * Q, 64);
+  // the ways' sums meet in a butterfly over the lane groups (lanes Q, 2 Q, 4 Q ...
+  // apart): a fixed tree, the same bits on every run
+  float g[4] = {acc.x, acc.y, acc.z, acc.w};
+  for (int off = Q; off < 64; off <<= 1) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) g[j] += __shfl_xor(g[j], off, 64);
   }
   if (!on || way != 0) return;
   const int64_t i = R.beg + 4 * e4;
@@ -579,9 +577,11 @@ __global__ __launch_bounds__(256) void reduce_regions_adam_kernel(ReduceRegionsP
   }
 }
 
+// lane groups per wave that split an element's partials: at most ~8 partials per
+// lane (one or two batches of independent 16-B loads), up to the whole wave
 int ways_for(int n_part) {
   int w = 1;
-  while (w < 8 && n_part > 32 * w) w *= 2;
+  while (w < 64 && n_part > 8 * w) w *= 2;
   return w;
 }
 

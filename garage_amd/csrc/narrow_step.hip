@@ -31,7 +31,6 @@ namespace {
 
 constexpr int NS_ROWS = 64;
 constexpr int NS_THREADS = 256;
-constexpr int NS_LDX = 36;  // staged observation / first-layer weight rows (32 + 4)
 constexpr int NS_HN = 8;
 
 typedef float ns_f32x16 __attribute__((ext_vector_type(16)));
@@ -92,22 +91,33 @@ __device__ __forceinline__ ns_f32x16 ns_tile(const float* A, int lda, const floa
   return acc0;
 }
 
-template <int H>
+// NS_LDX = floats per staged observation / first-layer weight row: round8(in_w) + 4
+// (12, 20 or 36).  At 12 and 20 the workgroup stays under 80 KB of LDS, so a
+// workgroup of the policy pass and one of the value-function pass (two streams)
+// share a CU.
+template <int H, int NS_LDX>
 __global__ __launch_bounds__(NS_THREADS) void narrow_train_kernel(NarrowParams p) {
   constexpr int LDH = H + 4;
   constexpr int CT = H / 32;        // column tiles of a hidden layer
   constexpr int QW = H / 4;         // hidden columns per wave in the VALU phases
+  // dz2 is written in P5; until then its memory holds the first-layer weights (read
+  // in P1 only) and the four planes of the head's partial sums (P3)
+  constexpr int DZ2_FLOATS = NS_ROWS * LDH;
+  constexpr int W1_FLOATS = H * NS_LDX, PLANES_FLOATS = 4 * NS_ROWS * NS_HN;
+  constexpr int SCRATCH = DZ2_FLOATS > W1_FLOATS + PLANES_FLOATS
+                              ? DZ2_FLOATS : W1_FLOATS + PLANES_FLOATS;
   __shared__ __attribute__((aligned(16))) float xs[NS_ROWS * NS_LDX];
-  __shared__ __attribute__((aligned(16))) float w1s[H * NS_LDX];
   __shared__ __attribute__((aligned(16))) float w2s[H * LDH];
   __shared__ __attribute__((aligned(16))) float whs[NS_HN * H];
   __shared__ __attribute__((aligned(16))) float h1[NS_ROWS * LDH];
   __shared__ __attribute__((aligned(16))) float h2[NS_ROWS * LDH];   // later dZ1
-  __shared__ __attribute__((aligned(16))) float dz2[NS_ROWS * LDH];
+  __shared__ __attribute__((aligned(16))) float scratch[SCRATCH];
   __shared__ __attribute__((aligned(16))) float outl[NS_ROWS * NS_HN];
   __shared__ __attribute__((aligned(16))) float doutl[NS_ROWS * NS_HN];
-  __shared__ __attribute__((aligned(16))) float planes[4 * NS_ROWS * NS_HN];
   __shared__ float b1s[H], b2s[H], bhs[NS_HN];
+  float* dz2 = scratch;
+  float* w1s = scratch;
+  float* planes = scratch + W1_FLOATS;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, l31 = lane & 31, half = lane >> 5;
@@ -447,12 +457,20 @@ extern "C" int ga_narrow_train_step(const float* params, const int64_t* w_off,
       6.0 * (double)M * ((double)in_w * H + (double)H * H + (double)H * out_w);
   hipEvent_t e0 = nullptr, e1 = nullptr;
   ga_prof_events(GA_PROF_NARROW_STEP, flops, &e0, &e1);
-  if (H == 64)
-    hipExtLaunchKernelGGL((narrow_train_kernel<64>), grid, dim3(NS_THREADS), 0, stream, e0,
-                          e1, 0, p);
-  else
-    hipExtLaunchKernelGGL((narrow_train_kernel<32>), grid, dim3(NS_THREADS), 0, stream, e0,
-                          e1, 0, p);
+#define GA_NARROW_LAUNCH(HH, LL)                                                      \
+  hipExtLaunchKernelGGL((narrow_train_kernel<HH, LL>), grid, dim3(NS_THREADS), 0, stream, \
+                        e0, e1, 0, p)
+  const int ldx_s = in_w <= 8 ? 12 : (in_w <= 16 ? 20 : 36);
+  if (H == 64) {
+    if (ldx_s == 12) GA_NARROW_LAUNCH(64, 12);
+    else if (ldx_s == 20) GA_NARROW_LAUNCH(64, 20);
+    else GA_NARROW_LAUNCH(64, 36);
+  } else {
+    if (ldx_s == 12) GA_NARROW_LAUNCH(32, 12);
+    else if (ldx_s == 20) GA_NARROW_LAUNCH(32, 20);
+    else GA_NARROW_LAUNCH(32, 36);
+  }
+#undef GA_NARROW_LAUNCH
   GA_CHECK_LAUNCH("narrow_train");
   return GA_OK;
 }
