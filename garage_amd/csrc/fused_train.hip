@@ -25,8 +25,8 @@
 //
 //   reduce_regions_adam_kernel   the optimizer step over per-region partial sums
 //       (split-K slabs of the weight-gradient GEMMs, per-workgroup partials of
-//       the two kernels above), each element summed in a fixed order by `ways`
-//       lane groups; one extra block finishes the loss (batch sums -> loss
+//       the two kernels above), each element summed in a fixed tree by 16 shares
+//       of a workgroup; one extra block finishes the loss (batch sums -> loss
 //       value, log-std gradient) and steps the log-std slot.
 //       torch.optim.Adam arithmetic as in losses.hip.
 //
@@ -469,13 +469,13 @@ struct FtRegion {
   const float* src;   // partial 0 of element 0
   int64_t stride;     // floats between consecutive partials
   int n_part;
-  int ways;           // lane groups of a wave that share the partials (1 .. 64)
-  int64_t vbeg;       // first virtual thread (a multiple of 64)
+  int quads;          // quads per workgroup: 64 or 16
+  int64_t vbeg;       // first workgroup of the region
 };
 struct ReduceRegionsParams {
   FtRegion r[FT_MAX_REGIONS];
   int n_regions;
-  int64_t n_virtual;
+  int64_t n_virtual;  // workgroups over all regions
   FtAdam a;
   float* grads;       // the reduced (scaled) gradient is also written here
   float scale;
@@ -513,24 +513,29 @@ __global__ __launch_bounds__(256) void reduce_regions_adam_kernel(ReduceRegionsP
     }
     return;
   }
-  // A virtual thread = (4 adjacent elements, one of `ways` shares of the partials);
-  // a wave belongs to one region (vbeg are multiples of 64) and covers 64 / ways
-  // quads: lanes [way * Q, (way + 1) * Q) walk the same 16 Q contiguous bytes of
-  // their partials, so every load instruction moves whole 16-B-per-lane segments.
-  const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  // A workgroup = Q adjacent quads of one region x 4 (64 / Q) shares of the partials:
+  // lane l holds quad l % Q and lane-share l / Q, wave w the wave-share w; a share
+  // sums a contiguous run of partials with four independent 16-B loads in flight.
+  // Q = 64 (whole 1-KB rows per load instruction, 4 shares) for regions of up to 128
+  // partials -- the split-K slabs --, Q = 16 (256-B segments, 16 shares) for the
+  // small regions with one partial per 64-row tile.  The lane-shares meet in a
+  // butterfly, the wave-shares in LDS, both fixed trees.
+  __shared__ float4 wsum[4][64];
+  const int64_t b = blockIdx.x;
   int ri = 0;
 #pragma unroll 1
   for (int k = 1; k < p.n_regions; ++k)
-    if (v >= p.r[k].vbeg) ri = k;
+    if (b >= p.r[k].vbeg) ri = k;
   const FtRegion& R = p.r[ri];
-  const int ways = R.ways;
-  const int lane = threadIdx.x & 63;
-  const int Q = 64 / ways;
-  const int way = lane / Q;
-  const int64_t wave0 = (v - lane - R.vbeg) / ways;  // first quad of this wave
-  const int64_t e4 = wave0 + (lane % Q);             // this lane's quad
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int Q = R.quads;  // 64 or 16
+  const int lwc = 64 / Q;
+  const int q = lane % Q, lw = lane / Q;
+  const int way = lwc * wv + lw;
+  const int64_t e4 = (b - R.vbeg) * Q + q;  // this lane's quad
   const bool on = 4 * e4 < R.n;
-  const int chunk = (R.n_part + ways - 1) / ways;
+  const int shares = 4 * lwc;
+  const int chunk = (R.n_part + shares - 1) / shares;
   const int p0 = way * chunk, p1 = min(R.n_part, p0 + chunk);
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   if (on) {
@@ -551,14 +556,21 @@ __global__ __launch_bounds__(256) void reduce_regions_adam_kernel(ReduceRegionsP
       acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
     }
   }
-  // the ways' sums meet in a butterfly over the lane groups (lanes Q, 2 Q, 4 Q ...
-  // apart): a fixed tree, the same bits on every run
   float g[4] = {acc.x, acc.y, acc.z, acc.w};
   for (int off = Q; off < 64; off <<= 1) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) g[j] += __shfl_xor(g[j], off, 64);
   }
-  if (!on || way != 0) return;
+  if (lw == 0) wsum[wv][q] = make_float4(g[0], g[1], g[2], g[3]);
+  __syncthreads();
+  if ((int)threadIdx.x >= Q || !on) return;
+  {
+    const float4 a0 = wsum[0][q], a1 = wsum[1][q], a2 = wsum[2][q], a3 = wsum[3][q];
+    g[0] = (a0.x + a1.x) + (a2.x + a3.x);
+    g[1] = (a0.y + a1.y) + (a2.y + a3.y);
+    g[2] = (a0.z + a1.z) + (a2.z + a3.z);
+    g[3] = (a0.w + a1.w) + (a2.w + a3.w);
+  }
   const int64_t i = R.beg + 4 * e4;
 #pragma unroll
   for (int j = 0; j < 4; ++j) g[j] *= p.scale;
@@ -575,14 +587,6 @@ __global__ __launch_bounds__(256) void reduce_regions_adam_kernel(ReduceRegionsP
     *reinterpret_cast<float4*>(p.a.m + i) = make_float4(mm[0], mm[1], mm[2], mm[3]);
     *reinterpret_cast<float4*>(p.a.v + i) = make_float4(vv[0], vv[1], vv[2], vv[3]);
   }
-}
-
-// lane groups per wave that split an element's partials: at most ~8 partials per
-// lane (one or two batches of independent 16-B loads), up to the whole wave
-int ways_for(int n_part) {
-  int w = 1;
-  while (w < 64 && n_part > 8 * w) w *= 2;
-  return w;
 }
 
 LossRowArgs loss_args(const ga_fused_loss_args* l, int64_t M) {
@@ -719,9 +723,9 @@ extern "C" int ga_reduce_regions_adam(const ga_fused_region* regions, int n_regi
     p.r[k].beg = regions[k].beg; p.r[k].n = (regions[k].n + 3) & ~(int64_t)3;
     p.r[k].src = regions[k].src;
     p.r[k].stride = regions[k].stride; p.r[k].n_part = regions[k].n_part;
-    p.r[k].ways = ways_for(regions[k].n_part);
+    p.r[k].quads = regions[k].n_part <= 128 ? 64 : 16;
     p.r[k].vbeg = v;
-    v += ga_ceil_div(p.r[k].n / 4 * p.r[k].ways, 64) * 64;
+    v += ga_ceil_div(p.r[k].n / 4, p.r[k].quads);  // workgroups of this region
   }
   p.n_regions = n_regions;
   p.n_virtual = v;
@@ -738,7 +742,7 @@ extern "C" int ga_reduce_regions_adam(const ga_fused_region* regions, int n_regi
   p.lpart = lpart; p.n_lpart = n_lpart; p.M = M;
   p.loss = loss_args(loss, M);
   p.loss_out = loss_out;
-  const unsigned blocks = (unsigned)ga_ceil_div(v, 256) + 1;  // + the loss block
+  const unsigned blocks = (unsigned)v + 1;  // + the loss block
   hipLaunchKernelGGL(reduce_regions_adam_kernel, dim3(blocks), dim3(256), 0, stream, p);
   GA_CHECK_LAUNCH("reduce_regions_adam");
   return GA_OK;
