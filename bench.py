@@ -158,7 +158,7 @@ KIND_NAMES = [
 GEMM_KINDS = (0, 1, 2, 3, 4, 5, 9, 10, 11)  # MFMA kernels: work = flops
 
 
-TRAFFIC_FILE = 'profiles/r01_traffic.json'
+TRAFFIC_FILE = 'profiles/r02_traffic.json'
 
 
 def load_traffic():
@@ -587,7 +587,8 @@ def main():
                 'avg_launch_us': scan['total_ms'] * 1e3 / scan['launches'],
                 'bytes_per_launch': scan['work'] / scan['launches'],
             }
-            for name in ('gae_scan_rows_kernel', 'gae_scan_kernel<true>'):
+            for name in ('gae_scan_rows_kernel<1>', 'gae_scan_rows_kernel',
+                         'gae_scan_kernel<true>'):
                 if args.config == 'c3' and name in traffic:
                     line['roofline_gae_scan']['traffic'] = \
                         traffic[name]['hbm_bytes']
