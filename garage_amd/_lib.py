@@ -197,6 +197,7 @@ SIGNATURES = {
     'ga_update_partials_floats': (c_i64, [C.POINTER(MlpDesc), c_i64]),
     'ga_set_fused_train': (c_int, [c_int]),
     'ga_set_narrow_step': (c_int, [c_int]),
+    'ga_set_fused_first_layer': (c_int, [c_int]),
     'ga_update_epoch_pair': (c_int, [C.POINTER(UpdateArgs), ptr,
                                      C.POINTER(UpdateArgs), ptr]),
     'ga_set_allreduce_hook': (None, [ptr]),

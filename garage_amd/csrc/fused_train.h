@@ -26,14 +26,29 @@ struct ga_fused_region {
 extern "C" {
 int ga_fused_width_ok(int width);       // 64, 128 or 256 units
 int64_t ga_fused_tiles(int64_t M);      // workgroups (= partial sets) for M rows
+// The layer under the last hidden one when that is the network's FIRST layer and
+// the kernel is to produce its outputs itself (H = tanh(X W^T + b), X gathered
+// through loss->idx) instead of reading them: in_w <= 32, K * round4(in_w) <=
+// ga_fused_first_layer_ok's bound.  H is written too (the backward pass reads it).
+typedef struct ga_fused_first_layer {
+  const float* X;
+  int64_t ldx;
+  const float* W;  // [K][round4(in_w)]
+  const float* b;  // [K]
+  int in_w;
+  float* H;        // [M][ldh]
+  int64_t ldh;
+} ga_fused_first_layer;
+int ga_fused_first_layer_ok(int in_w, int K);
 // last hidden layer + head + loss + gradient seed + head weight-gradient shares;
-// hpart: [tiles][8 * width + 8] floats, lpart: [tiles][2] doubles
+// hpart: [tiles][8 * width + 8] floats, lpart: [tiles][2] doubles.  first != null:
+// A / lda / a_idx are ignored, the operand comes from `first`
 int ga_fused_fwd_head_loss(const float* A, int64_t lda, const int32_t* a_idx,
                            const float* W, int64_t ldw, const float* bias, int64_t M,
                            int width, int K, const float* head_W, int64_t head_ldw,
                            const float* head_bias, const ga_fused_loss_args* loss,
                            float* dZ, int64_t lddz, float* hpart, double* lpart,
-                           hipStream_t stream);
+                           const ga_fused_first_layer* first, hipStream_t stream);
 // data gradient into the first hidden layer + first-layer weight / bias gradient
 // shares; wpart: [tiles][width * round4(in_w) + width] floats
 int ga_fused_dgrad_wgrad0(const float* dZ2, int64_t lddz, const float* W2, int64_t ldw,

@@ -56,13 +56,62 @@ struct FwdLossParams {
   int64_t lddz;
   float* hpart;          // [gx][8 * BN + 8]: dW_head (j major), then db_head
   double* lpart;         // [gx][2]
+  // L1 instantiation: the layer below is the FIRST layer (<= 32 inputs) and its
+  // output -- this GEMM's A operand -- is produced by the kernel itself:
+  // H1 = tanh(X W1^T + b1) chunk by chunk; g.A / g.lda are unused
+  const float* l1_X;     // observations [*][l1_ldx], gathered through loss.idx
+  int64_t l1_ldx;
+  const float* l1_W;     // [K][round4(l1_in)]
+  const float* l1_b;     // [K]
+  int l1_in;
+  float* l1_H;           // [M][l1_ldh]: H1 is written once, for the backward pass
+  int64_t l1_ldh;
 };
 
 typedef const __attribute__((address_space(4))) float* ft_uniform_ptr;
+typedef float ft_f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int FT_W1_FLOATS = 5120;  // LDS floats for the first layer's weights
+
+// MFMAs of one 32-deep k-step on k-contiguous LDS tiles (gemm_core.h: the
+// A_KC = B_KC = true case of gemm_mainloop's body)
+template <int TM, int TN>
+__device__ __forceinline__ void ft_kstep(const float* As, const float* Bs,
+                                         f32x16 (&acc)[TM][TN], int wm0, int wn0,
+                                         int lane) {
+  constexpr int LDK = BK + PAD;
+  const int half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+  for (int g = 0; g < BK / 8; ++g) {
+    float a[TM][4], b[TN][4];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const float4 v = *reinterpret_cast<const float4*>(As + (wm0 + 32 * i + l31) * LDK +
+                                                        8 * g + 4 * half);
+      a[i][0] = v.x; a[i][1] = v.y; a[i][2] = v.z; a[i][3] = v.w;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const float4 v = *reinterpret_cast<const float4*>(Bs + (wn0 + 32 * j + l31) * LDK +
+                                                        8 * g + 4 * half);
+      b[j][0] = v.x; b[j][1] = v.y; b[j][2] = v.z; b[j][3] = v.w;
+    }
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] =
+              __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[j][q], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  }
+}
 
 // (two 512-thread workgroups per CU need <= 128 registers: the second bound is waves
 // per SIMD)
-template <int BN, int WAVES_M, int WAVES_N>
+template <int BN, int WAVES_M, int WAVES_N, bool L1 = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N,
                              WAVES_M * WAVES_N == 8 ? 4 : 2) void fwd_head_loss_kernel(
     FwdLossParams p) {
@@ -80,11 +129,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N,
   constexpr int AUX_FLOATS = PL * 64 * HN > HN * BN ? PL * 64 * HN : HN * BN;
   static_assert(SEGS <= 2 * PL, "two reduction steps");
   static_assert((FT_ROWS * (BN / 4)) % NT == 0, "whole quads per thread");
-  __shared__ __attribute__((aligned(16))) float lds[TILE_FLOATS + AUX_FLOATS];
+  // L1: the first layer's weights sit behind the operand tiles for the k-loop -- in
+  // the part of the epilogue stage the tiles leave free (all 20 KB of it at
+  // BN = 256), plus EXTRA floats where that is not enough
+  constexpr int SLACK = TILE_FLOATS - (A_FLOATS + B_FLOATS);
+  constexpr int EXTRA = (L1 && FT_W1_FLOATS > SLACK) ? FT_W1_FLOATS - SLACK : 0;
+  __shared__ __attribute__((aligned(16))) float lds[TILE_FLOATS + EXTRA + AUX_FLOATS];
   __shared__ __attribute__((aligned(16))) float outl[FT_ROWS * HN];
   __shared__ __attribute__((aligned(16))) float doutl[FT_ROWS * HN];
   float* stage = lds;
-  float* aux = lds + TILE_FLOATS;  // head partial planes, later W_head [8][BN]
+  float* aux = lds + TILE_FLOATS + EXTRA;  // head partial planes, later W_head [8][BN]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -95,8 +149,120 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N,
   const int M = p.g.M;
   const LossRowArgs& L = p.loss;
 
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  if constexpr (L1) {
+    // ---- k-loop with the A operand produced in place:
+    //   As(chunk c) = tanh(X_tile W1[32 c .. 32 c + 31]^T + b1) as 8 sub-tiles of
+    //   16 x 16 on v_mfma_f32_16x16x4_f32 (lane l: A[l % 16][k = l / 16],
+    //   B[k = l / 16][l % 16], D[row 4 (l / 16) + reg][col l % 16]); the wave's
+    //   observation values stay in registers for the whole kernel, W1 / b1 in LDS.
+    constexpr int NSUB = 8 / (NT / 64);  // sub-tiles per wave: 1 (8 waves) or 2
+    const int K = p.g.K, in_w = p.l1_in;
+    const int ld0 = (in_w + 3) & ~3, KS = ld0 / 4;
+    float* As = lds;
+    float* Bs = lds + A_FLOATS;
+    float* w1s = lds + A_FLOATS + B_FLOATS;
+    float* b1s = aux;
+    const int r16 = lane & 15, g4 = lane >> 4;
+    const int rt = wave & 3;  // row sub-tile (the same for both sub-tiles of a wave)
+    // prologue: the gathered row number first (the observation loads depend on it),
+    // W1 / b1 / the first B tile in flight behind it
+    const int xm = m0 + 16 * rt + r16;
+    const int xmc = min(xm, M - 1);
+    const int64_t xsrc = L.idx ? (int64_t)L.idx[xmc] : (int64_t)xmc;
+    TileLoader<BN, true, NT, BK, true> lb;
+    lb.init(nullptr, 0, BN, 0, K);
+    lb.load(p.g.B, p.g.ldb, 0, 0, K, false);
+    float xa[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int k = 4 * s + g4;
+      xa[s] = p.l1_X[xsrc * p.l1_ldx + min(k, in_w - 1)];
+      xa[s] = (k < in_w && xm < M) ? xa[s] : 0.f;
+    }
+    for (int e = tid; e < K * KS; e += NT)
+      reinterpret_cast<float4*>(w1s)[e] = reinterpret_cast<const float4*>(p.l1_W)[e];
+    for (int e = tid; e < K; e += NT) b1s[e] = p.l1_b[e];
+    ft_f32x4 a4[NSUB];
+    // the 16 x 16 sub-tiles of chunk c: MFMAs (two accumulation chains per sub-tile) ...
+    auto produce = [&](int c) {
+#pragma unroll
+      for (int u = 0; u < NSUB; ++u) {
+        const int ct = (wave + (NT / 64) * u) >> 2;
+        const float* wrow = w1s + (32 * c + 16 * ct + r16) * ld0 + g4;
+        ft_f32x4 e4 = {0.f, 0.f, 0.f, 0.f}, o4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 8; s += 2) {
+          if (s < KS)
+            e4 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s], wrow[4 * s], e4, 0, 0, 0);
+          if (s + 1 < KS)
+            o4 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s + 1], wrow[4 * s + 4], o4, 0,
+                                                      0, 0);
+        }
+        a4[u] = e4 + o4;
+      }
+    };
+    // ... and bias + tanh into the operand tile
+    auto write = [&](int c) {
+#pragma unroll
+      for (int u = 0; u < NSUB; ++u) {
+        const int ct = (wave + (NT / 64) * u) >> 2;
+        const float b = b1s[32 * c + 16 * ct + r16];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          As[(16 * rt + 4 * g4 + r) * LDK + 16 * ct + r16] = tanh_fast(a4[u][r] + b);
+      }
+    };
+    // H1 goes to memory from the finished operand tile: 16-B pieces, 128 B per row
+    auto spill = [&](int c) {
+#pragma unroll
+      for (int q = 0; q < FT_ROWS * (BK / 4) / NT; ++q) {
+        const int e = tid + NT * q;
+        const int row = e / (BK / 4), c4 = e % (BK / 4);
+        const float4 v = *reinterpret_cast<const float4*>(As + row * LDK + 4 * c4);
+        if (m0 + row < M)
+          *reinterpret_cast<float4*>(p.l1_H + (int64_t)(m0 + row) * p.l1_ldh + 32 * c +
+                                     4 * c4) = v;
+      }
+    };
+    const int nk = K / BK;
+    __syncthreads();  // W1 / b1 staged
+    produce(0);
+    write(0);
+    lb.store(Bs, 0, BN, 0, K, false);
+    __syncthreads();
+    for (int s = 0; s < nk; ++s) {
+      const bool more = s + 1 < nk;
+      if (more) lb.load(p.g.B, p.g.ldb, 0, (s + 1) * BK, K, false);
+      spill(s);
+      if (more) produce(s + 1);
+      ft_kstep<TM, TN>(As, Bs, acc, wm0, wn0, lane);
+      __syncthreads();
+      if (more) {
+        lb.store(Bs, 0, BN, (s + 1) * BK, K, false);
+        write(s + 1);
+        __syncthreads();
+      }
+    }
+  } else {
+    float csum = 0.f;
+    const bool full = m0 + FT_ROWS <= M;
+    if (full)
+      gemm_mainloop<FT_ROWS, BN, WAVES_M, WAVES_N, true, true, BK, true>(
+          p.g, lds, acc, csum, false, m0, 0, 0, p.g.K, wm0, wn0);
+    else
+      gemm_mainloop<FT_ROWS, BN, WAVES_M, WAVES_N, true, true, BK, false>(
+          p.g, lds, acc, csum, false, m0, 0, 0, p.g.K, wm0, wn0);
+  }
+
   // the sample of this lane's row (wave 0 computes the loss rows): loads issued
-  // now, consumed after the k-loop
+  // here, consumed three barriers later
   float act[8];
   float adv = 0.f, old_ll = 0.f, ret = 0.f;
 #pragma unroll
@@ -125,21 +291,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N,
     }
   }
 
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  float csum = 0.f;
-  const bool full = m0 + FT_ROWS <= M;
-  if (full)
-    gemm_mainloop<FT_ROWS, BN, WAVES_M, WAVES_N, true, true, BK, true>(
-        p.g, lds, acc, csum, false, m0, 0, 0, p.g.K, wm0, wn0);
-  else
-    gemm_mainloop<FT_ROWS, BN, WAVES_M, WAVES_N, true, true, BK, false>(
-        p.g, lds, acc, csum, false, m0, 0, 0, p.g.K, wm0, wn0);
 
   // ---- E1: accumulators -> staged rows [64][BN + 4]
 #pragma unroll
@@ -611,15 +762,32 @@ extern "C" int ga_fused_width_ok(int width) {
 
 extern "C" int64_t ga_fused_tiles(int64_t M) { return ga_ceil_div(M, FT_ROWS); }
 
+extern "C" int ga_fused_first_layer_ok(int in_w, int K) {
+  return in_w >= 1 && in_w <= 32 && K >= 32 && K % 32 == 0 &&
+         (int64_t)K * ((in_w + 3) & ~3) <= FT_W1_FLOATS;
+}
+
 extern "C" int ga_fused_fwd_head_loss(const float* A, int64_t lda, const int32_t* a_idx,
                                       const float* W, int64_t ldw, const float* bias,
                                       int64_t M, int width, int K, const float* head_W,
                                       int64_t head_ldw, const float* head_bias,
                                       const ga_fused_loss_args* loss, float* dZ,
                                       int64_t lddz, float* hpart, double* lpart,
+                                      const ga_fused_first_layer* first,
                                       hipStream_t stream) {
-  GA_REQUIRE(A && W && bias && head_W && head_bias && loss && dZ && hpart && lpart,
+  GA_REQUIRE((A || first) && W && bias && head_W && head_bias && loss && dZ && hpart &&
+                 lpart,
              "ga_fused_fwd_head_loss: null pointer");
+  if (first) {
+    GA_REQUIRE(first->X && first->W && first->b && first->H &&
+                   ga_fused_first_layer_ok(first->in_w, K) && K <= 256 &&
+                   first->ldx >= first->in_w && first->ldh % 4 == 0 && first->ldh >= K &&
+                   ga_aligned16(first->W),
+               "ga_fused_fwd_head_loss: unsupported first layer");
+    A = first->H;  // (only for the checks below; never read)
+    lda = first->ldh;
+    a_idx = nullptr;
+  }
   GA_REQUIRE(ga_fused_width_ok(width) && M >= 1 && M < (1ll << 31) && K >= 1 &&
                  loss->A >= 1 && loss->A <= 8,
              "ga_fused_fwd_head_loss: unsupported shape");
@@ -644,11 +812,25 @@ extern "C" int ga_fused_fwd_head_loss(const float* A, int64_t lda, const int32_t
   p.loss = loss_args(loss, M);
   p.dZ = dZ; p.lddz = lddz; p.hpart = hpart; p.lpart = lpart;
   const dim3 grid((unsigned)ga_fused_tiles(M));
-  // algorithmic flops of both layers
-  const double flops = 2.0 * (double)M * width * ((double)K + loss->A);
+  // algorithmic flops of the layers computed
+  double flops = 2.0 * (double)M * width * ((double)K + loss->A);
+  if (first) {
+    p.l1_X = first->X; p.l1_ldx = first->ldx; p.l1_W = first->W; p.l1_b = first->b;
+    p.l1_in = first->in_w; p.l1_H = first->H; p.l1_ldh = first->ldh;
+    flops += 2.0 * (double)M * K * first->in_w;
+  }
   hipEvent_t e0 = nullptr, e1 = nullptr;
   ga_prof_events(GA_PROF_FUSED_FWD, flops, &e0, &e1);
-  if (width == 64)
+  if (first && width == 64)
+    hipExtLaunchKernelGGL((fwd_head_loss_kernel<64, 2, 2, true>), grid, dim3(256), 0,
+                          stream, e0, e1, 0, p);
+  else if (first && width == 128)
+    hipExtLaunchKernelGGL((fwd_head_loss_kernel<128, 1, 4, true>), grid, dim3(256), 0,
+                          stream, e0, e1, 0, p);
+  else if (first)
+    hipExtLaunchKernelGGL((fwd_head_loss_kernel<256, 1, 8, true>), grid, dim3(512), 0,
+                          stream, e0, e1, 0, p);
+  else if (width == 64)
     hipExtLaunchKernelGGL((fwd_head_loss_kernel<64, 2, 2>), grid, dim3(256), 0, stream,
                           e0, e1, 0, p);
   else if (width == 128)

@@ -90,6 +90,23 @@ extern "C" int ga_set_narrow_step(int on) {
   return 0;
 }
 
+// The first layer's forward inside the fused last-hidden-layer kernel (3-layer
+// networks with <= 32 inputs); 0 = its own streaming launch (A/B runs, tests)
+// (GARAGE_AMD_FUSED_FIRST_LAYER=0 in the environment: the same, for A/B runs of
+// programs that do not call the setter)
+static int g_fused_first_layer = -1;
+extern "C" int ga_set_fused_first_layer(int on) {
+  g_fused_first_layer = on != 0;
+  return 0;
+}
+static int fused_first_layer_on() {
+  if (g_fused_first_layer < 0) {
+    const char* e = getenv("GARAGE_AMD_FUSED_FIRST_LAYER");
+    g_fused_first_layer = (e && e[0] == '0') ? 0 : 1;
+  }
+  return g_fused_first_layer;
+}
+
 namespace {
 struct FusedPlan {
   bool ok = false;
@@ -302,7 +319,9 @@ int run_minibatch_fused(const ga_update_args* a, const FusedPlan& f, int64_t k,
     if (rc || !exchange) return rc;
     return allreduce_and_adam(a, k, stream_, order);
   }
-  if (L >= 3) {
+  const bool first_in_kernel =
+      fused_first_layer_on() && L == 3 && ga_fused_first_layer_ok(d->dims[0], d->dims[1]);
+  if (L >= 3 && !first_in_kernel) {
     ga_mlp_desc below = *d;  // layers 0 .. L-3: the hidden layers under the last one
     below.n_layers = L - 1;
     rc = ga_mlp_forward_f32(&below, a->params, a->X, a->ldx, idx, M, a->acts, nullptr,
@@ -322,12 +341,19 @@ int run_minibatch_fused(const ga_update_args* a, const FusedPlan& f, int64_t k,
   float* wpart = a->partials + f.wpart_off;
   const int wl = d->dims[L - 1];  // last hidden width
   const float* Ain = L >= 3 ? a->acts + d->act_off[L - 3] : a->X;
+  ga_fused_first_layer fl;
+  if (first_in_kernel) {
+    fl.X = a->X; fl.ldx = a->ldx; fl.W = a->params + d->w_off[0];
+    fl.b = a->params + d->b_off[0]; fl.in_w = d->dims[0];
+    fl.H = a->acts + d->act_off[0]; fl.ldh = r4(d->dims[1]);
+  }
   rc = ga_fused_fwd_head_loss(Ain, L >= 3 ? r4(d->dims[L - 2]) : a->ldx,
                               L >= 3 ? nullptr : idx, a->params + d->w_off[L - 2],
                               r4(d->dims[L - 2]), a->params + d->b_off[L - 2], M, wl,
                               d->dims[L - 2], a->params + d->w_off[L - 1], r4(wl),
                               a->params + d->b_off[L - 1], &la,
-                              a->dacts + d->act_off[L - 2], r4(wl), hpart, lpart, stream);
+                              a->dacts + d->act_off[L - 2], r4(wl), hpart, lpart,
+                              first_in_kernel ? &fl : nullptr, stream);
   if (rc) return rc;
   rc = ga_mlp_backward_range_f32(d, a->params, a->X, a->ldx, idx, M, a->acts, nullptr,
                                  a->ldo, a->dacts, a->slabs, a->n_flat, splits, L - 2,

@@ -500,6 +500,12 @@ int ga_set_fused_train(int on);
  * (every weight in LDS, 64 rows per workgroup) followed by the same reduction +
  * Adam launch; 0: the kernels above.  Needs `partials` like them. */
 int ga_set_narrow_step(int on);
+/* 1 (default): with two hidden layers and <= 32 inputs (first-layer weights of at
+ * most 5120 padded floats) the fused last-hidden-layer kernel computes the first
+ * layer's outputs itself, k-chunk by k-chunk, instead of reading them back from a
+ * separate launch (they are still written once for the backward pass); 0: the
+ * first layer runs as its own launch. */
+int ga_set_fused_first_layer(int on);
 /* The policy pass and the value-function pass of one epoch, minibatch by
  * minibatch alternately on two streams.  The reference runs them back to back
  * (vpg.py:244-248); they share no written state, so the results are identical

@@ -155,14 +155,18 @@ int ga_small_step(const ga_small_step_args* a, void*) {
   return 0;
 }
 int ga_fused_width_ok(int w) { return w == 64 || w == 128 || w == 256; }
+int ga_fused_first_layer_ok(int in_w, int K) {
+  return in_w >= 1 && in_w <= 32 && K % 32 == 0 && K * ((in_w + 3) & ~3) <= 5120;
+}
 int64_t ga_fused_tiles(int64_t M) { return (M + 63) / 64; }
 int ga_fused_fwd_head_loss(const float*, int64_t, const int32_t* a_idx, const float*,
                            int64_t, const float*, int64_t M, int width, int K,
                            const float*, int64_t, const float*,
                            const ga_fused_loss_args* loss, float*, int64_t, float* hpart,
-                           double* lpart, hipStream_t) {
-  logf("fused_fwd M=%lld width=%d K=%d a_idx=%d A=%d", (long long)M, width, K,
-       a_idx != nullptr, loss->A);
+                           double* lpart, const ga_fused_first_layer* first,
+                           hipStream_t) {
+  logf("fused_fwd M=%lld width=%d K=%d a_idx=%d A=%d first=%d", (long long)M, width, K,
+       a_idx != nullptr, loss->A, first != nullptr);
   // the partial-sum scratch must hold what the plan says
   const int64_t tiles = ga_fused_tiles(M);
   for (int64_t t = 0; t < tiles; ++t) {
@@ -409,11 +413,18 @@ int main() {
     ga_update_args a = wide.args(M, M, p3.data(), 0);
     a.partials = partials.data(); a.partials_floats = need;
     CHECK(ga_update_epoch(&a, nullptr) == 0);
-    CHECK(count("fused_fwd M=1000 width=256 K=256 a_idx=0 A=6") == 1);
+    // (the first layer is computed inside the fused kernel: no forward launch)
+    CHECK(count("fused_fwd M=1000 width=256 K=256 a_idx=0 A=6 first=1") == 1);
     CHECK(count("bwd_range M=1000 l_start=1 fused_first=1") == 1);
     CHECK(count("fused_dgrad M=1000 width=256 K=256 in=17") == 1);
     CHECK(count("reduce_regions n=6 step=1 scale=1.0000 adam=1 zero0=0 lparts=16") == 1);
-    CHECK(count("fwd M=1000") == 1);  // the hidden layers below the last one
+    CHECK(count("fwd M=1000") == 0);
+    ga_set_fused_first_layer(0);
+    g_log.clear();
+    CHECK(ga_update_epoch(&a, nullptr) == 0);
+    CHECK(count("fused_fwd M=1000 width=256 K=256 a_idx=0 A=6 first=0") == 1);
+    CHECK(count("fwd M=1000") == 1);  // the hidden layer below the last one
+    ga_set_fused_first_layer(1);
     // a scratch one float short falls back to the per-layer kernels
     g_log.clear();
     a.partials_floats = need - 1;

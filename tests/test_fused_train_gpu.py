@@ -215,3 +215,38 @@ def test_narrow_step_is_taken_and_matches_the_gemm_epilogue_kernels():
             scale = float(res[2][i].abs().max())
             d = float((res[0][i] - other[i]).abs().max())
             assert d < 1e-4 * scale + 4e-5, (i, d, scale)
+
+
+@pytest.mark.parametrize('case', ['c3_shape', 'ragged_tiles_128',
+                                  'wide_first_narrow_last',
+                                  'categorical_max_entropy'])
+def test_first_layer_inside_the_fused_kernel_is_taken_and_matches(case):
+    """Two hidden layers and <= 32 inputs: the last-hidden-layer kernel produces the
+    first layer's outputs itself (v_mfma_f32_16x16x4_f32 sub-tiles per k-chunk);
+    ``ga_set_fused_first_layer(0)`` restores the separate streaming launch.  Other
+    summation order in the first layer, same gradients to rounding."""
+    from garage_amd import _lib
+    lib = _lib.load()
+    spec, batch = _problem(case)
+    lr = 1e-3
+    opt = (torch.optim.Adam, dict(lr=lr, betas=(0.0, 0.0), eps=1.0))
+    res = []
+    try:
+        for on in (1, 0):
+            lib.ga_set_fused_first_layer(on)
+            algo, pol, vf = _algo(case, spec, opt)
+            p0, v0 = pol.net.params.clone(), vf.net.params.clone()
+            np.random.seed(11)
+            algo._train_once(0, batch)
+            res.append(((pol.net.params - p0) / lr, (vf.net.params - v0) / lr,
+                        dict(algo.last_tabular)))
+    finally:
+        lib.ga_set_fused_first_layer(1)
+    assert not torch.equal(res[0][0], res[1][0])  # different kernels ran
+    for i in (0, 1):
+        scale = float(res[1][i].abs().max())
+        d = float((res[0][i] - res[1][i]).abs().max())
+        assert d < 1e-4 * scale + 4e-5, (i, d, scale)
+    for k, v in res[1][2].items():
+        assert np.isclose(res[0][2][k], v, rtol=2e-5, atol=2e-6), (k, v,
+                                                                  res[0][2][k])
