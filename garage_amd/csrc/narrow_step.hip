@@ -49,7 +49,11 @@ struct NarrowParams {
   float* part;      // [tiles][stride]: dW1 [H][ld0], db1 [H], dW2 [H][H], db2 [H],
   int64_t stride;   //                  dW_head [8][H], db_head [8]
   double* lpart;    // [tiles][2]
+  long long* dbg;   // developer hook: phase timestamps of workgroup 0
 };
+
+#define NS_STAMP(i) \
+  if (p.dbg && blockIdx.x == 0 && threadIdx.x == 0) p.dbg[i] = wall_clock64()
 
 // One 32 x 32 output tile on the matrix cores: acc += sum_k A(i, k) B(k, j), K a
 // multiple of 8.  Lane l feeds A(l % 32, k) and B(k, l % 32) with k = 8 g + 4 (l / 32)
@@ -131,6 +135,7 @@ __global__ __launch_bounds__(NS_THREADS) void narrow_train_kernel(NarrowParams p
   const float* W2 = p.params + p.w_off[1];
   const float* Wh = p.params + p.w_off[2];
 
+  NS_STAMP(0);
   // ---- the sample of this lane's row (wave 0 computes the loss rows)
   float act[8];
   float adv = 0.f, old_ll = 0.f, ret = 0.f;
@@ -196,6 +201,7 @@ __global__ __launch_bounds__(NS_THREADS) void narrow_train_kernel(NarrowParams p
   }
   if (tid < NS_HN) bhs[tid] = tid < A ? p.params[p.b_off[2] + tid] : 0.f;
   __syncthreads();
+  NS_STAMP(1);
 
   // tile of this wave in the 2 x CT tilings below (H = 32: waves 2, 3 idle there)
   const int tri = wave & 1, tcj = wave >> 1;
@@ -214,6 +220,7 @@ __global__ __launch_bounds__(NS_THREADS) void narrow_train_kernel(NarrowParams p
     }
   }
   __syncthreads();
+  NS_STAMP(2);
   // ---- P2: H2 = tanh(H1 W2^T + b2)
   if (tile_on) {
     const ns_f32x16 acc = ns_tile<true, true>(h1 + 32 * tri * LDH, LDH,
@@ -227,6 +234,7 @@ __global__ __launch_bounds__(NS_THREADS) void narrow_train_kernel(NarrowParams p
     }
   }
   __syncthreads();
+  NS_STAMP(3);
   // ---- P3: head outputs (lane = row, wave = a quarter of the hidden columns)
   {
     float a[NS_HN];
@@ -254,6 +262,7 @@ __global__ __launch_bounds__(NS_THREADS) void narrow_train_kernel(NarrowParams p
     outl[o] = s;
   }
   __syncthreads();
+  NS_STAMP(4);
   // ---- P4: loss rows (wave 0)
   if (wave == 0) {
     float s = 0.f, inv_var = 1.f;
@@ -289,6 +298,7 @@ __global__ __launch_bounds__(NS_THREADS) void narrow_train_kernel(NarrowParams p
     }
   }
   __syncthreads();
+  NS_STAMP(5);
   float* part = p.part + (int64_t)blockIdx.x * p.stride;
   float* pW1 = part;
   float* pb1 = pW1 + (int64_t)H * ld0;
@@ -338,6 +348,7 @@ __global__ __launch_bounds__(NS_THREADS) void narrow_train_kernel(NarrowParams p
     }
   }
   __syncthreads();  // dz2 complete; every read of h2 done
+  NS_STAMP(6);
   // ---- P7: dW2[n][k] = sum_r dZ2[r][n] H1[r][k]   (CT x CT tiles)
   for (int t = wave; t < CT * CT; t += 4) {
     const int tn = t / CT, tk = t % CT;
@@ -370,6 +381,7 @@ __global__ __launch_bounds__(NS_THREADS) void narrow_train_kernel(NarrowParams p
     pb2[n] = b;
   }
   __syncthreads();
+  NS_STAMP(7);
   // ---- P9: dW1[n][k] = sum_r dZ1[r][n] X[r][k], db1
   {
     constexpr int GROUPS = NS_THREADS / H;
@@ -391,9 +403,25 @@ __global__ __launch_bounds__(NS_THREADS) void narrow_train_kernel(NarrowParams p
       pb1[nn] = b;
     }
   }
+  __syncthreads();
+  NS_STAMP(8);
 }
 
 }  // namespace
+
+static long long* g_ns_dbg = nullptr;
+// developer hook: phase timestamps (100 MHz wall clock) of workgroup 0 of the most
+// recent launch -- first call arms it, second call reads 16 values back
+extern "C" int ga_narrow_step_debug(long long* host_out16) {
+  if (!g_ns_dbg) {
+    if (hipMalloc(&g_ns_dbg, 16 * sizeof(long long)) != hipSuccess) return -1;
+    (void)hipMemset(g_ns_dbg, 0, 16 * sizeof(long long));
+    return 1;
+  }
+  (void)hipDeviceSynchronize();
+  return hipMemcpy(host_out16, g_ns_dbg, 16 * sizeof(long long), hipMemcpyDeviceToHost) ==
+                 hipSuccess ? 0 : -1;
+}
 
 // LossRowArgs from the epoch loop's arguments (fused_train.hip holds the same
 // conversion for its kernels)
@@ -451,6 +479,7 @@ extern "C" int ga_narrow_train_step(const float* params, const int64_t* w_off,
   p.in_w = in_w; p.out_w = out_w; p.M = (int)M; p.X = X; p.ldx = ldx;
   p.loss = narrow_loss_args(loss, M);
   p.part = part; p.stride = ga_narrow_step_stride(in_w, H); p.lpart = lpart;
+  p.dbg = g_ns_dbg;
   const dim3 grid((unsigned)ga_fused_tiles(M));
   // algorithmic flops: forward + both backward products of every layer
   const double flops =

@@ -138,6 +138,8 @@ int64_t ga_small_step_launches(void); /* launches so far (tests, diagnostics) */
  * clock of workgroup 0 at the phase boundaries of the most recent launch) to the
  * HOST array and return 0. */
 int ga_small_step_debug(long long* host_out16);
+/* the same for the one-launch step of 2 x 32 / 2 x 64 networks (narrow_step.hip) */
+int ga_narrow_step_debug(long long* host_out16);
 /* Forward-mode tangent of the MLP (torch/optimizers/conjugate_gradient_optimizer.py
  * :18-66 takes the same product by double backward): with dtheta = tangent (flat
  * parameter layout) and acts = the hidden activations of a forward at the same
