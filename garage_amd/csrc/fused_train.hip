@@ -66,7 +66,15 @@ struct FwdLossParams {
   int l1_in;
   float* l1_H;           // [M][l1_ldh]: H1 is written once, for the backward pass
   int64_t l1_ldh;
+  long long* dbg;        // developer hook: phase timestamps of one workgroup
 };
+
+// FT_STAMP: timestamp i of workgroup 8; FT_MARK: slot (0 start, 1 end of the k-loop,
+// 2 end) of EVERY workgroup, behind the 16 values of workgroup 8: the skew of a launch
+#define FT_STAMP(i) \
+  if (p.dbg && blockIdx.x == 8 && threadIdx.x == 0) p.dbg[i] = wall_clock64()
+#define FT_MARK(slot) \
+  if (p.dbg && threadIdx.x == 0) p.dbg[16 + 3 * blockIdx.x + (slot)] = wall_clock64()
 
 typedef const __attribute__((address_space(4))) float* ft_uniform_ptr;
 typedef float ft_f32x4 __attribute__((ext_vector_type(4)));
@@ -149,6 +157,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N,
   const int M = p.g.M;
   const LossRowArgs& L = p.loss;
 
+  FT_STAMP(0);
+  FT_MARK(0);
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -237,6 +247,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N,
     write(0);
     lb.store(Bs, 0, BN, 0, K, false);
     __syncthreads();
+    FT_STAMP(1);
     for (int s = 0; s < nk; ++s) {
       const bool more = s + 1 < nk;
       if (more) lb.load(p.g.B, p.g.ldb, 0, (s + 1) * BK, K, false);
@@ -261,6 +272,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N,
           p.g, lds, acc, csum, false, m0, 0, 0, p.g.K, wm0, wn0);
   }
 
+  FT_STAMP(2);
+  FT_MARK(1);
   // the sample of this lane's row (wave 0 computes the loss rows): loads issued
   // here, consumed three barriers later
   float act[8];
@@ -303,6 +316,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N,
         stage[rr * LDC + wn0 + 32 * j + (lane & 31)] = acc[i][j][r];
       }
   __syncthreads();
+  FT_STAMP(3);
   // ---- E2: H = tanh(. + bias), kept in the stage only
 #pragma unroll
   for (int q = 0; q < FT_ROWS * (BN / 4) / NT; ++q) {
@@ -315,6 +329,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N,
     *reinterpret_cast<float4*>(stage + rr * LDC + 4 * c4) = v;
   }
   __syncthreads();
+  FT_STAMP(4);
   // ---- E3: head outputs of the 64 rows (lane = row, wave = a column segment whose
   //      weights are wave-uniform: scalar loads, v_fmac with an SGPR operand)
   {
@@ -370,6 +385,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N,
     }
   }
   __syncthreads();
+  FT_STAMP(5);
   // ---- E4: wave 0: the loss rows (d(loss)/d(head output) -> doutl, batch-sum
   //      shares -> lpart); the other waves stage W_head [8][BN] over the planes
   if (wave == 0) {
@@ -414,6 +430,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N,
     }
   }
   __syncthreads();
+  FT_STAMP(6);
   // ---- E5: dZ = (dout W_head) (1 - H^2) -> global (the only [M x BN] store)
 #pragma unroll
   for (int q = 0; q < FT_ROWS * (BN / 4) / NT; ++q) {
@@ -437,6 +454,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N,
     if (m0 + rr < M)
       *reinterpret_cast<float4*>(p.dZ + (int64_t)(m0 + rr) * p.lddz + 4 * c4) = z;
   }
+  FT_STAMP(7);
   // ---- E6: this workgroup's share of dW_head[j][c] = sum_r dout[r][j] H[r][c]
   //      (rows beyond M carry dout = 0) and of db_head
   {
@@ -459,6 +477,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N,
       hp[HN * BN + tid] = b;
     }
   }
+  FT_STAMP(8);
+  FT_MARK(2);
 }
 
 // ---------------------------------------------------------------------------
@@ -762,6 +782,28 @@ extern "C" int ga_fused_width_ok(int width) {
 
 extern "C" int64_t ga_fused_tiles(int64_t M) { return ga_ceil_div(M, FT_ROWS); }
 
+static long long* g_ft_dbg = nullptr;
+constexpr int FT_DBG_BLOCKS = 4096, FT_DBG_WORDS = 16 + 3 * FT_DBG_BLOCKS;
+// developer hook: phase timestamps (100 MHz wall clock) of workgroup 8 of the most
+// recent fwd_head_loss launch -- first call arms it, second call reads 16 values back
+extern "C" int ga_fused_fwd_debug(long long* host_out16) {
+  if (!g_ft_dbg) {
+    if (hipMalloc(&g_ft_dbg, FT_DBG_WORDS * sizeof(long long)) != hipSuccess) return -1;
+    (void)hipMemset(g_ft_dbg, 0, FT_DBG_WORDS * sizeof(long long));
+    return 1;
+  }
+  (void)hipDeviceSynchronize();
+  return hipMemcpy(host_out16, g_ft_dbg, 16 * sizeof(long long), hipMemcpyDeviceToHost) ==
+                 hipSuccess ? 0 : -1;
+}
+// (start, end of k-loop, end) of the first n workgroups of that launch, n <= 4096
+extern "C" int ga_fused_fwd_debug_skew(long long* host_out, int n) {
+  if (!g_ft_dbg || n < 1 || n > FT_DBG_BLOCKS) return -1;
+  (void)hipDeviceSynchronize();
+  return hipMemcpy(host_out, g_ft_dbg + 16, 3 * (size_t)n * sizeof(long long),
+                   hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+
 extern "C" int ga_fused_first_layer_ok(int in_w, int K) {
   return in_w >= 1 && in_w <= 32 && K >= 32 && K % 32 == 0 &&
          (int64_t)K * ((in_w + 3) & ~3) <= FT_W1_FLOATS;
@@ -811,6 +853,7 @@ extern "C" int ga_fused_fwd_head_loss(const float* A, int64_t lda, const int32_t
   p.head_W = head_W; p.head_ldw = head_ldw; p.head_bias = head_bias;
   p.loss = loss_args(loss, M);
   p.dZ = dZ; p.lddz = lddz; p.hpart = hpart; p.lpart = lpart;
+  p.dbg = ga_fused_tiles(M) <= FT_DBG_BLOCKS ? g_ft_dbg : nullptr;
   const dim3 grid((unsigned)ga_fused_tiles(M));
   // algorithmic flops of the layers computed
   double flops = 2.0 * (double)M * width * ((double)K + loss->A);

@@ -140,6 +140,10 @@ int64_t ga_small_step_launches(void); /* launches so far (tests, diagnostics) */
 int ga_small_step_debug(long long* host_out16);
 /* the same for the one-launch step of 2 x 32 / 2 x 64 networks (narrow_step.hip) */
 int ga_narrow_step_debug(long long* host_out16);
+/* ... and for the fused last-hidden-layer + head + loss kernel (fused_train.hip) */
+int ga_fused_fwd_debug(long long* host_out16);
+/* (start, end of the k-loop, end) of the first n <= 4096 workgroups of that launch */
+int ga_fused_fwd_debug_skew(long long* host_out, int n);
 /* Forward-mode tangent of the MLP (torch/optimizers/conjugate_gradient_optimizer.py
  * :18-66 takes the same product by double backward): with dtheta = tangent (flat
  * parameter layout) and acts = the hidden activations of a forward at the same
