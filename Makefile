@@ -9,7 +9,7 @@ OUT   := garage_amd/_C
 HIPS  := gae_scan gemm skinny losses rollout policy_fused small_step fused_train narrow_step
 CPPS  := errors prof update comm rollout_loop
 OBJS  := $(patsubst %,$(OUT)/%.o,$(HIPS) $(CPPS))
-FLAGS := --offload-arch=$(ARCH) -O3 -fPIC -std=c++17 -Wall -Wno-unused-function
+FLAGS := --offload-arch=$(ARCH) -O3 -fPIC -std=c++17 -Wall -Wno-unused-function $(EXTRA)
 
 all: $(OUT)/libgarage_amd.so
 

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N,
   // L1: the first layer's weights sit behind the operand tiles for the k-loop -- in
   // the part of the epilogue stage the tiles leave free (all 20 KB of it at
   // BN = 256), plus EXTRA floats where that is not enough
-  constexpr int SLACK = TILE_FLOATS - (A_FLOATS + B_FLOATS);
+  constexpr int SLACK = TILE_FLOATS - 2 * A_FLOATS;
   constexpr int EXTRA = (L1 && FT_W1_FLOATS > SLACK) ? FT_W1_FLOATS - SLACK : 0;
   __shared__ __attribute__((aligned(16))) float lds[TILE_FLOATS + EXTRA + AUX_FLOATS];
   __shared__ __attribute__((aligned(16))) float outl[FT_ROWS * HN];
@@ -175,20 +175,33 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N,
     constexpr int NSUB = 8 / (NT / 64);  // sub-tiles per wave: 1 (8 waves) or 2
     const int K = p.g.K, in_w = p.l1_in;
     const int ld0 = (in_w + 3) & ~3, KS = ld0 / 4;
-    float* As = lds;
-    float* Bs = lds + A_FLOATS;
-    float* w1s = lds + A_FLOATS + B_FLOATS;
+    // two buffers for the produced A chunks; the B fragments never pass through LDS
+    auto As2 = [&](int i) { return lds + (i & 1) * A_FLOATS; };
+    float* w1s = lds + 2 * A_FLOATS;
     float* b1s = aux;
+    static_assert(2 * A_FLOATS + FT_W1_FLOATS <= TILE_FLOATS + EXTRA, "W1 fits");
     const int r16 = lane & 15, g4 = lane >> 4;
+    const int half = lane >> 5, l31 = lane & 31;
     const int rt = wave & 3;  // row sub-tile (the same for both sub-tiles of a wave)
     // prologue: the gathered row number first (the observation loads depend on it),
-    // W1 / b1 / the first B tile in flight behind it
+    // W1 / b1 / the first B fragments in flight behind it
     const int xm = m0 + 16 * rt + r16;
     const int xmc = min(xm, M - 1);
     const int64_t xsrc = L.idx ? (int64_t)L.idx[xmc] : (int64_t)xmc;
-    TileLoader<BN, true, NT, BK, true> lb;
-    lb.init(nullptr, 0, BN, 0, K);
-    lb.load(p.g.B, p.g.ldb, 0, 0, K, false);
+    // B fragments of a 32-deep step: lane (l31, half) feeds B(k, n = wn0 + 32 j + l31),
+    // k = 32 s + 8 g + 4 half + q -- one 16-B load per group, straight from memory
+    // (every workgroup reads all of W: it stays in L2), one step ahead
+    const float* Wb = p.g.B + (int64_t)(wn0 + l31) * p.g.ldb + 4 * half;
+    float4 bn[TN][4];
+    auto fetch_b = [&](int s) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          bn[j][g] = *reinterpret_cast<const float4*>(Wb + (int64_t)(32 * j) * p.g.ldb +
+                                                      32 * s + 8 * g);
+    };
+    fetch_b(0);
     float xa[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
@@ -199,9 +212,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N,
     for (int e = tid; e < K * KS; e += NT)
       reinterpret_cast<float4*>(w1s)[e] = reinterpret_cast<const float4*>(p.l1_W)[e];
     for (int e = tid; e < K; e += NT) b1s[e] = p.l1_b[e];
-    ft_f32x4 a4[NSUB];
-    // the 16 x 16 sub-tiles of chunk c: MFMAs (two accumulation chains per sub-tile) ...
+    // the 16 x 16 sub-tiles of chunk c (two accumulation chains per sub-tile), bias +
+    // tanh, into the operand buffer of the chunk
     auto produce = [&](int c) {
+      float* As = As2(c);
 #pragma unroll
       for (int u = 0; u < NSUB; ++u) {
         const int ct = (wave + (NT / 64) * u) >> 2;
@@ -215,22 +229,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N,
             o4 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s + 1], wrow[4 * s + 4], o4, 0,
                                                       0, 0);
         }
-        a4[u] = e4 + o4;
-      }
-    };
-    // ... and bias + tanh into the operand tile
-    auto write = [&](int c) {
-#pragma unroll
-      for (int u = 0; u < NSUB; ++u) {
-        const int ct = (wave + (NT / 64) * u) >> 2;
         const float b = b1s[32 * c + 16 * ct + r16];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          As[(16 * rt + 4 * g4 + r) * LDK + 16 * ct + r16] = tanh_fast(a4[u][r] + b);
+          As[(16 * rt + 4 * g4 + r) * LDK + 16 * ct + r16] = tanh_fast(e4[r] + o4[r] + b);
       }
     };
-    // H1 goes to memory from the finished operand tile: 16-B pieces, 128 B per row
+    // H1 goes to memory from the finished operand buffer: 16-B pieces, 128 B per row
     auto spill = [&](int c) {
+      const float* As = As2(c);
 #pragma unroll
       for (int q = 0; q < FT_ROWS * (BK / 4) / NT; ++q) {
         const int e = tid + NT * q;
@@ -244,23 +251,69 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N,
     const int nk = K / BK;
     __syncthreads();  // W1 / b1 staged
     produce(0);
-    write(0);
-    lb.store(Bs, 0, BN, 0, K, false);
     __syncthreads();
     FT_STAMP(1);
+#ifdef GA_FT_LOOP_STAMPS
+    // developer build: shader-clock ticks thread 0 of every workgroup spends in the
+    // parts of a k-step, summed over the loop (tools/fused_fwd_phases.py)
+    long long c_mma = 0, c_bar1 = 0, c_store = 0, c_bar2 = 0;
+#define FT_TICK(acc_, t_) { const long long n_ = clock64(); acc_ += n_ - t_; t_ = n_; }
+#else
+#define FT_TICK(acc_, t_)
+#endif
+    // step s: MFMAs on chunk buffer s % 2 with the B fragments fetched during step
+    // s - 1; chunk s + 1 is produced into the other buffer (last read in step s - 1);
+    // ONE barrier per step
     for (int s = 0; s < nk; ++s) {
       const bool more = s + 1 < nk;
-      if (more) lb.load(p.g.B, p.g.ldb, 0, (s + 1) * BK, K, false);
+#ifdef GA_FT_LOOP_STAMPS
+      long long tk = clock64();
+#endif
+      float4 bc[TN][4];
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bc[j][g] = bn[j][g];
+      if (more) fetch_b(s + 1);
       spill(s);
       if (more) produce(s + 1);
-      ft_kstep<TM, TN>(As, Bs, acc, wm0, wn0, lane);
-      __syncthreads();
-      if (more) {
-        lb.store(Bs, 0, BN, (s + 1) * BK, K, false);
-        write(s + 1);
-        __syncthreads();
+      FT_TICK(c_store, tk);
+      const float* As = As2(s);
+#pragma unroll
+      for (int g = 0; g < BK / 8; ++g) {
+        float a[TM][4];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const float4 v = *reinterpret_cast<const float4*>(As + (wm0 + 32 * i + l31) * LDK +
+                                                            8 * g + 4 * half);
+          a[i][0] = v.x; a[i][1] = v.y; a[i][2] = v.z; a[i][3] = v.w;
+        }
+        float b[TN][4];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          b[j][0] = bc[j][g].x; b[j][1] = bc[j][g].y; b[j][2] = bc[j][g].z; b[j][3] = bc[j][g].w;
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[j][q], acc[i][j],
+                                                               0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
       }
+      FT_TICK(c_mma, tk);
+      __syncthreads();
+      FT_TICK(c_bar1, tk);
     }
+#ifdef GA_FT_LOOP_STAMPS
+    if (p.dbg && tid == 0) {
+      long long* o = p.dbg + 16 + 3 * 4096 + 4 * blockIdx.x;
+      o[0] = c_mma; o[1] = c_bar1; o[2] = c_store; o[3] = c_bar2;
+    }
+#endif
   } else {
     float csum = 0.f;
     const bool full = m0 + FT_ROWS <= M;
@@ -783,7 +836,7 @@ extern "C" int ga_fused_width_ok(int width) {
 extern "C" int64_t ga_fused_tiles(int64_t M) { return ga_ceil_div(M, FT_ROWS); }
 
 static long long* g_ft_dbg = nullptr;
-constexpr int FT_DBG_BLOCKS = 4096, FT_DBG_WORDS = 16 + 3 * FT_DBG_BLOCKS;
+constexpr int FT_DBG_BLOCKS = 4096, FT_DBG_WORDS = 16 + 7 * FT_DBG_BLOCKS;
 // developer hook: phase timestamps (100 MHz wall clock) of workgroup 8 of the most
 // recent fwd_head_loss launch -- first call arms it, second call reads 16 values back
 extern "C" int ga_fused_fwd_debug(long long* host_out16) {
@@ -795,6 +848,16 @@ extern "C" int ga_fused_fwd_debug(long long* host_out16) {
   (void)hipDeviceSynchronize();
   return hipMemcpy(host_out16, g_ft_dbg, 16 * sizeof(long long), hipMemcpyDeviceToHost) ==
                  hipSuccess ? 0 : -1;
+}
+// -DGA_FT_LOOP_STAMPS builds only (make EXTRA=-DGA_FT_LOOP_STAMPS): per workgroup,
+// ticks in (fragment reads + MFMAs, first barrier, tile stores, second barrier)
+// summed over the k-loop
+extern "C" int ga_fused_fwd_debug_loop(long long* host_out, int n) {
+  if (!g_ft_dbg || n < 1 || n > FT_DBG_BLOCKS) return -1;
+  (void)hipDeviceSynchronize();
+  return hipMemcpy(host_out, g_ft_dbg + 16 + 3 * FT_DBG_BLOCKS,
+                   4 * (size_t)n * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess
+             ? 0 : -1;
 }
 // (start, end of k-loop, end) of the first n workgroups of that launch, n <= 4096
 extern "C" int ga_fused_fwd_debug_skew(long long* host_out, int n) {

@@ -35,3 +35,19 @@ print('workgroup ends    : min %.2f  median %.2f  max %.2f us' % (
     a[:, 2].min() - t0, np.median(a[:, 2]) - t0, a[:, 2].max() - t0))
 d = a[:, 2] - a[:, 0]
 print('workgroup duration: min %.2f  median %.2f  max %.2f us' % (d.min(), np.median(d), d.max()))
+
+# developer build (make clean; make EXTRA=-DGA_FT_LOOP_STAMPS): where thread 0 of each
+# workgroup spends the k-loop
+import ctypes
+lib.ga_fused_fwd_debug_loop.restype = ctypes.c_int
+lp = (C.c_longlong * (4 * n))()
+if lib.ga_fused_fwd_debug_loop(lp, n) == 0:
+    b = np.array(list(lp), dtype=np.float64).reshape(n, 4)
+    if b.sum() > 0:
+        tot = b.sum(axis=1)
+        order = np.argsort(a[:, 1])  # by end of k-loop
+        for name, sel in (('fastest 64', order[:64]), ('slowest 64', order[-64:]),
+                          ('all', order)):
+            m = b[sel].mean(axis=0)
+            print('%-10s ticks/k-loop: reads+MFMA %8.0f  barrier1 %8.0f  stores %8.0f  '
+                  'barrier2 %8.0f  (sum %8.0f)' % (name, m[0], m[1], m[2], m[3], m.sum()))
