@@ -79,6 +79,13 @@ class OracleCGOptimizer:
         self.hvp_reg_coeff = hvp_reg_coeff
         self.accept_violation = accept_violation
         self.trace = {}
+        # test probes (per-iterate pins against the reference's recorded CG run):
+        # vectors to multiply by the constraint Hessian, and a descent step whose
+        # first `probe_candidates` backtracking candidates are evaluated, both at
+        # the parameters the step starts from
+        self.probe_vectors = None
+        self.probe_descent = None
+        self.probe_candidates = 0
 
     def zero_grad(self):
         for p in self.params:
@@ -99,8 +106,37 @@ class OracleCGOptimizer:
         self.trace = dict(grad=flat_loss_grads.detach().numpy().copy(),
                           step_dir=step_dir.detach().numpy().copy(),
                           descent_step=descent_step.detach().numpy().copy())
+        if self.probe_vectors is not None:
+            self.trace['probe_Ax'] = np.stack([
+                f_Ax(torch.as_tensor(v)).detach().numpy().copy()
+                for v in self.probe_vectors])
+        if self.probe_descent is not None:
+            self.trace['probe_ls'] = self._probe_line_search(
+                params, torch.as_tensor(self.probe_descent), f_loss, f_constraint)
         self._backtracking_line_search(params, descent_step, f_loss,
                                        f_constraint)
+
+    def _probe_line_search(self, params, descent_step, f_loss, f_constraint):
+        """(loss_before, [(loss, constraint) of candidate k]) for a GIVEN descent
+        step; parameters are restored."""
+        prev = [p.detach().clone() for p in params]
+        out = [float(f_loss())]
+        off = 0
+        steps = []
+        for p in params:
+            n = p.numel()
+            steps.append(descent_step[off:off + n].reshape(p.shape))
+            off += n
+        for k in range(self.probe_candidates):
+            ratio = self.backtrack_ratio**k
+            with torch.no_grad():
+                for step, pv, p in zip(steps, prev, params):
+                    p.copy_(pv - ratio * step)
+            out.append((float(f_loss()), float(f_constraint())))
+        with torch.no_grad():
+            for pv, p in zip(prev, params):
+                p.copy_(pv)
+        return out
 
     def _backtracking_line_search(self, params, descent_step, f_loss,
                                   f_constraint):

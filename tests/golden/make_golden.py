@@ -543,15 +543,42 @@ def gen_trpo():
         real_ls = cgo.ConjugateGradientOptimizer._backtracking_line_search
 
         def spy_cg(f_Ax, b, cg_iters, residual_tol=1e-10):
-            x = real_cg(f_Ax, b, cg_iters, residual_tol)
+            # every Hessian-vector product the real loop takes: (p_k, A p_k)
+            calls = []
+
+            def rec_Ax(vec):
+                z = f_Ax(vec)
+                calls.append((vec.detach().numpy().copy(),
+                              z.detach().numpy().copy()))
+                return z
+
+            x = real_cg(rec_Ax, b, cg_iters, residual_tol)
             trace['grad'] = b.detach().numpy().copy()
             trace['step_dir'] = x.detach().numpy().copy()
             trace['Ax'] = f_Ax(x).detach().numpy().copy()
+            trace['iter_p'] = np.stack([c[0] for c in calls])
+            trace['iter_Ap'] = np.stack([c[1] for c in calls])
             return x
 
         def spy_ls(self, params, descent_step, f_loss, f_constraint):
             trace['descent_step'] = descent_step.detach().numpy().copy()
-            return real_ls(self, params, descent_step, f_loss, f_constraint)
+            # loss_before, then (loss, constraint) of every candidate it tries
+            losses, kls = [], []
+
+            def rec_loss():
+                v = f_loss()
+                losses.append(float(v.detach()))
+                return v
+
+            def rec_constraint():
+                v = f_constraint()
+                kls.append(float(v.detach()))
+                return v
+
+            out = real_ls(self, params, descent_step, rec_loss, rec_constraint)
+            trace['ls_loss'] = np.asarray(losses, dtype=np.float64)
+            trace['ls_constraint'] = np.asarray(kls, dtype=np.float64)
+            return out
 
         cgo._conjugate_gradient = spy_cg
         cgo.ConjugateGradientOptimizer._backtracking_line_search = spy_ls

@@ -566,6 +566,53 @@ def test_golden_trpo_train_once(golden, tag):
         assert algo.cg.trace['accepted'] in (-1, 0)
 
 
+@pytest.mark.parametrize('tag', sorted(TRPO_CASES))
+def test_golden_trpo_per_iterate_pins(golden, tag):
+    """The end-to-end comparison above is as loose as ten fp32 CG iterations make
+    it (the reference run is itself one sample of that rounding noise).  Each
+    operation of the step is pinned on its own instead, at the reference's OWN
+    iterates: the Hessian-vector product ``A p_k`` for every direction ``p_k`` the
+    real ``_conjugate_gradient`` visited
+    (``conjugate_gradient_optimizer.py:69-104``), and the (loss, constraint) pair
+    of every backtracking candidate of the real descent step (``:236-277``) -- all
+    at one-operation fp32 accuracy."""
+    from oracle.trpo import OracleTRPO
+    g = golden('trpo_train_once')
+    O, A, P, E, mb = [int(v) for v in g[tag + '_cfg']]
+    algo = OracleTRPO(_params(g, tag + '_pol0:'), _params(g, tag + '_vf0:'),
+                      max_episode_length=P,
+                      max_constraint_value=float(g[tag + '_delta']),
+                      max_backtracks=int(g[tag + '_max_backtracks']),
+                      max_optimization_epochs=E, minibatch_size=mb,
+                      **TRPO_CASES[tag])
+    pre = tag + '_it0_'
+    algo.cg.probe_vectors = g[pre + 'cg:iter_p']
+    algo.cg.probe_descent = g[pre + 'cg:descent_step']
+    algo.cg.probe_candidates = len(g[pre + 'cg:ls_constraint'])
+    lens = g[pre + 'lengths']
+    b = ob.OracleEpisodeBatch(
+        observations=g[pre + 'observations'],
+        last_observations=np.zeros((len(lens), O), np.float32),
+        actions=g[pre + 'actions'], rewards=g[pre + 'rewards'],
+        step_types=g[pre + 'step_types'], lengths=lens, max_episode_length=P)
+    np.random.seed(int(g[pre + 'np_seed']))
+    algo.train_once(b)
+    tr = algo.cg.trace
+    want = g[pre + 'cg:iter_Ap']
+    assert tr['probe_Ax'].shape == want.shape and len(want) == 10
+    for k in range(len(want)):
+        scale = np.abs(want[k]).max()
+        assert np.allclose(tr['probe_Ax'][k], want[k], atol=1e-5 * scale,
+                           rtol=1e-5), k
+    ls = tr['probe_ls']
+    assert np.isclose(ls[0], g[pre + 'cg:ls_loss'][0], atol=1e-7)
+    for k, (loss, kl) in enumerate(ls[1:]):
+        assert np.isclose(loss, g[pre + 'cg:ls_loss'][k + 1], atol=1e-6,
+                          rtol=1e-5), k
+        assert np.isclose(kl, g[pre + 'cg:ls_constraint'][k], atol=1e-7,
+                          rtol=1e-4), k
+
+
 POLICY_OPTION_CASES = ['fixed_std', 'init_small', 'max_clamp', 'min_clamp']
 
 

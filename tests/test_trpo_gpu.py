@@ -88,6 +88,87 @@ def test_trpo_train_once_matches_real_reference(golden, tag):
         pass  # first iteration rejected: parameters equal the golden's (above)
 
 
+def _to_padded(net, flat):
+    """The reference's flat ``parameters()``-order vector in the padded layout."""
+    buf = torch.zeros(net.n_flat, dtype=torch.float32, device=net.device)
+    off = 0
+    for _, v in net.named_views(buf):
+        n = v.numel()
+        v.copy_(torch.from_numpy(
+            np.ascontiguousarray(flat[off:off + n], dtype=np.float32)
+        ).reshape(v.shape))
+        off += n
+    assert off == len(flat)
+    return buf
+
+
+@pytest.mark.parametrize('tag', sorted(TRPO_CASES))
+def test_trpo_per_iterate_pins_against_real_reference(golden, tag):
+    """Ten fp32 conjugate-gradient iterations amplify last-bit differences to
+    ~1e-3 of the step (the end-to-end tolerance above; the reference run is itself
+    one sample of that noise).  Here every operation of the constrained step is
+    pinned on its own at the real reference's OWN iterates
+    (``conjugate_gradient_optimizer.py:69-104,236-277``, recorded by
+    ``make_golden.py``): ``A p_k`` for each of the ten directions the real
+    ``_conjugate_gradient`` visited, and (loss, constraint) of every backtracking
+    candidate of the real descent step -- each at one-operation fp32 accuracy."""
+    g = golden('trpo_train_once')
+    O, A, P, E, mb = [int(v) for v in g[tag + '_cfg']]
+    spec, pol, vf, algo = _make(g, tag, O, A, P, E, mb, **TRPO_CASES[tag])
+    pre = tag + '_it0_'
+    batch = _host_batch(spec, g, pre, O)
+    net = pol.net
+    seen = {}
+    real_train = algo._train
+
+    def probing_train(dbatch, adv, returns, old_ll):
+        M = dbatch.n_samples
+        hyper = algo._policy_optimizer._hyper
+        algo._trpo_share = 1.0
+        # forward + loss at the step's starting point, as _train_policy does
+        loss0, mean_old, dout = algo._policy_loss_pass(dbatch, adv, old_ll, M,
+                                                       None, want_grad=True)
+        mean_old = mean_old.clone()
+        s_old = pol.clamped_log_std()
+        z = torch.empty(net.n_flat, dtype=torch.float32, device=net.device)
+        got = []
+        for p_k in g[pre + 'cg:iter_p']:
+            algo._fisher_vector_product(dbatch, M, _to_padded(net, p_k), z)
+            got.append(_flat_no_pad(net, z))
+        seen['Ap'] = np.stack(got)
+        prev = net.params.clone()
+        descent = _to_padded(net, g[pre + 'cg:descent_step'])
+        ls = [float(loss0.item())]
+        for k in range(len(g[pre + 'cg:ls_constraint'])):
+            net.params.copy_(prev - float(hyper['backtrack_ratio'])**k * descent)
+            l_new, mean_new, _ = algo._policy_loss_pass(dbatch, adv, old_ll, M,
+                                                        None)
+            kl = algo._kl_sum(mean_old, s_old, mean_new,
+                              pol.clamped_log_std(), M)
+            ls.append((float(l_new.item()), float(kl.item()) / M))
+        net.params.copy_(prev)
+        seen['ls'] = ls
+        return real_train(dbatch, adv, returns, old_ll)
+
+    algo._train = probing_train
+    np.random.seed(int(g[pre + 'np_seed']))
+    algo._train_once(0, batch)
+    want = g[pre + 'cg:iter_Ap']
+    assert seen['Ap'].shape == want.shape and len(want) == 10
+    for k in range(len(want)):
+        scale = np.abs(want[k]).max()
+        assert np.allclose(seen['Ap'][k], want[k], atol=1e-5 * scale,
+                           rtol=1e-5), (k, np.abs(seen['Ap'][k] - want[k]).max(),
+                                        scale)
+    ls = seen['ls']
+    assert np.isclose(ls[0], g[pre + 'cg:ls_loss'][0], atol=2e-7)
+    for k, (loss, kl) in enumerate(ls[1:]):
+        assert np.isclose(loss, g[pre + 'cg:ls_loss'][k + 1], atol=1e-6,
+                          rtol=1e-5), (k, loss)
+        assert np.isclose(kl, g[pre + 'cg:ls_constraint'][k], atol=1e-7,
+                          rtol=1e-4), (k, kl)
+
+
 def test_fisher_vector_product_matches_double_backward():
     """``A v`` (tangent forward, Gaussian metric, backward) against the
     reference's Hessian-vector product by double backward (oracle) on the same
