@@ -109,6 +109,7 @@ SIGNATURES = {
     'ga_narrow_step_debug': (c_int, [ptr]),
     'ga_fused_fwd_debug': (c_int, [ptr]),
     'ga_fused_fwd_debug_skew': (c_int, [ptr, c_int]),
+    'ga_fused_dgrad_debug': (c_int, [ptr, c_int, c_int]),
     'ga_set_one_launch_losses': (c_int, [c_int]),
     'ga_mlp_backward_splits': (c_i64, [C.POINTER(MlpDesc), c_i64]),
     'ga_mlp_backward_f32': (c_int, [C.POINTER(MlpDesc), ptr, ptr, c_i64, ptr,

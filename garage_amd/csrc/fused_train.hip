@@ -544,6 +544,7 @@ struct DgradWgrad0Params {
   const int32_t* idx;
   int in_w;            // <= 32
   float* wpart;        // [gx][BN * ld0 + BN]: dW1 [n][ld0], then db1 [n]
+  long long* dbg;      // developer hook: phase timestamps (FT_STAMP / FT_MARK)
 };
 
 template <int BN, int WAVES_M, int WAVES_N>
@@ -575,6 +576,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N,
   const int M = p.g.M;
   const int ld0 = (p.in_w + 3) & ~3;
 
+  FT_STAMP(0);
+  FT_MARK(0);
   // the workgroup's observation rows: loads issued now, staged after the k-loop
   float4 xq[2];
 #pragma unroll
@@ -594,14 +597,22 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N,
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  float csum = 0.f;
-  const bool full = m0 + FT_ROWS <= M;
-  if (full)
-    gemm_mainloop<FT_ROWS, BN, WAVES_M, WAVES_N, true, false, BK, true>(
-        p.g, lds, acc, csum, false, m0, 0, 0, p.g.K, wm0, wn0);
-  else
-    gemm_mainloop<FT_ROWS, BN, WAVES_M, WAVES_N, true, false, BK, false>(
-        p.g, lds, acc, csum, false, m0, 0, 0, p.g.K, wm0, wn0);
+  // (measured and not kept for this k-loop, see DESIGN.md section 5: B fragments
+  // straight from L2 with the dZ2 tile double buffered in LDS and one barrier per
+  // step -- 52.8 us; no LDS and no barrier at all, every wave fetching its own A and
+  // B fragments -- 62.1 us; against 50.9 us for the two-barrier loop below)
+  {
+    float csum = 0.f;
+    const bool full = m0 + FT_ROWS <= M;
+    if (full)
+      gemm_mainloop<FT_ROWS, BN, WAVES_M, WAVES_N, true, false, BK, true>(
+          p.g, lds, acc, csum, false, m0, 0, 0, p.g.K, wm0, wn0);
+    else
+      gemm_mainloop<FT_ROWS, BN, WAVES_M, WAVES_N, true, false, BK, false>(
+          p.g, lds, acc, csum, false, m0, 0, 0, p.g.K, wm0, wn0);
+  }
+  FT_STAMP(1);
+  FT_MARK(1);
 
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -627,6 +638,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N,
     }
   }
   __syncthreads();
+  FT_STAMP(2);
   // dZ1 = (dZ2 W2) (1 - H1^2), kept in the stage only (rows beyond M are zero: their
   // dZ2 rows were masked by the loader)
 #pragma unroll
@@ -641,32 +653,49 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N,
     *reinterpret_cast<float4*>(stage + rr * LDC + 4 * c4) = v;
   }
   __syncthreads();
-  // this workgroup's share of dW1[n][k] = sum_r dZ1[r][n] X[r][k] and of db1[n]
+  FT_STAMP(3);
+  // this workgroup's share of dW1[n][k] = sum_r dZ1[r][n] X[r][k] on the matrix
+  // cores -- [BN x 64] (dZ1^T, read down the staged columns) x [64 x 32] (the staged
+  // observation rows), one 32-row tile of dW1 per wave, two accumulation chains --
+  // and of db1[n] (column sums of dZ1)
   {
-    constexpr int GROUPS = NT / BN;         // 2 (or 4 at BN = 64)
-    constexpr int QPG = (LDXS / 4) / GROUPS;  // observation quads per group: 4 (2)
-    const int n = tid % BN, q0 = (tid / BN) * QPG;
-    float4 g[QPG];
+    const int half = lane >> 5, l31 = lane & 31;
+    float* wp = p.wpart + (int64_t)blockIdx.x * ((int64_t)BN * ld0 + BN);
+    for (int t = wave; t < BN / 32; t += NT / 64) {
+      f32x16 acc0, acc1;
 #pragma unroll
-    for (int qq = 0; qq < QPG; ++qq) g[qq] = make_float4(0.f, 0.f, 0.f, 0.f);
-    float b = 0.f;
-    for (int r = 0; r < FT_ROWS; ++r) {
-      const float d = stage[r * LDC + n];
-      b += d;
+      for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
 #pragma unroll
-      for (int qq = 0; qq < QPG; ++qq) {
-        const float4 x = *reinterpret_cast<const float4*>(xs + r * LDXS + 4 * (q0 + qq));
-        g[qq].x = fmaf(d, x.x, g[qq].x); g[qq].y = fmaf(d, x.y, g[qq].y);
-        g[qq].z = fmaf(d, x.z, g[qq].z); g[qq].w = fmaf(d, x.w, g[qq].w);
+      for (int g = 0; g < FT_ROWS / 8; ++g) {
+        float a[4], b[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int r = 8 * g + 4 * half + q;
+          a[q] = stage[r * LDC + 32 * t + l31];
+          b[q] = xs[r * LDXS + l31];
+        }
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[1], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[2], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[3], acc1, 0, 0, 0);
+      }
+      if (l31 < ld0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
+          wp[(int64_t)n * ld0 + l31] = acc0[r] + acc1[r];
+        }
       }
     }
-    float* wp = p.wpart + (int64_t)blockIdx.x * ((int64_t)BN * ld0 + BN);
-#pragma unroll
-    for (int qq = 0; qq < QPG; ++qq)
-      if (4 * (q0 + qq) < ld0)
-        *reinterpret_cast<float4*>(wp + (int64_t)n * ld0 + 4 * (q0 + qq)) = g[qq];
-    if (tid < BN) wp[(int64_t)BN * ld0 + n] = b;
+    if (tid < BN) {
+      float b = 0.f;
+#pragma unroll 8
+      for (int r = 0; r < FT_ROWS; ++r) b += stage[r * LDC + tid];
+      wp[(int64_t)BN * ld0 + tid] = b;
+    }
   }
+  FT_STAMP(4);
+  FT_MARK(2);
 }
 
 // ---------------------------------------------------------------------------
@@ -867,6 +896,25 @@ extern "C" int ga_fused_fwd_debug_skew(long long* host_out, int n) {
                    hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
 }
 
+static long long* g_dg_dbg = nullptr;
+// the same two hooks for dgrad_wgrad0_kernel: which = 0 -> 16 phase stamps of
+// workgroup 8 (first call arms), which = 1 -> (start, end of k-loop, end) of the
+// first n workgroups
+extern "C" int ga_fused_dgrad_debug(long long* host_out, int which, int n) {
+  if (!g_dg_dbg) {
+    if (hipMalloc(&g_dg_dbg, FT_DBG_WORDS * sizeof(long long)) != hipSuccess) return -1;
+    (void)hipMemset(g_dg_dbg, 0, FT_DBG_WORDS * sizeof(long long));
+    return 1;
+  }
+  (void)hipDeviceSynchronize();
+  if (which == 0)
+    return hipMemcpy(host_out, g_dg_dbg, 16 * sizeof(long long), hipMemcpyDeviceToHost) ==
+                   hipSuccess ? 0 : -1;
+  if (n < 1 || n > FT_DBG_BLOCKS) return -1;
+  return hipMemcpy(host_out, g_dg_dbg + 16, 3 * (size_t)n * sizeof(long long),
+                   hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+
 extern "C" int ga_fused_first_layer_ok(int in_w, int K) {
   return in_w >= 1 && in_w <= 32 && K >= 32 && K % 32 == 0 &&
          (int64_t)K * ((in_w + 3) & ~3) <= FT_W1_FLOATS;
@@ -968,6 +1016,7 @@ extern "C" int ga_fused_dgrad_wgrad0(const float* dZ2, int64_t lddz, const float
   p.g.M = (int)M; p.g.N = width; p.g.K = K;
   p.H = H1; p.ldh = ldh; p.X = X; p.ldx = ldx; p.idx = idx; p.in_w = in_w;
   p.wpart = wpart;
+  p.dbg = ga_fused_tiles(M) <= FT_DBG_BLOCKS ? g_dg_dbg : nullptr;
   const dim3 grid((unsigned)ga_fused_tiles(M));
   const double flops = 2.0 * (double)M * width * ((double)K + in_w);
   hipEvent_t e0 = nullptr, e1 = nullptr;

@@ -144,6 +144,10 @@ int ga_narrow_step_debug(long long* host_out16);
 int ga_fused_fwd_debug(long long* host_out16);
 /* (start, end of the k-loop, end) of the first n <= 4096 workgroups of that launch */
 int ga_fused_fwd_debug_skew(long long* host_out, int n);
+/* the data-gradient + first-layer weight-gradient kernel: which = 0 -> 16 phase
+ * stamps of one workgroup (the first call arms the hook and returns 1), which = 1
+ * -> (start, end of the k-loop, end) of the first n workgroups */
+int ga_fused_dgrad_debug(long long* host_out, int which, int n);
 /* Forward-mode tangent of the MLP (torch/optimizers/conjugate_gradient_optimizer.py
  * :18-66 takes the same product by double backward): with dtheta = tangent (flat
  * parameter layout) and acts = the hidden activations of a forward at the same
