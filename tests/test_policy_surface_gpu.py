@@ -115,7 +115,9 @@ def test_nn_module_surface():
         assert float(m.net.grads.abs().sum()) == 0.0
         assert m.requires_grad_(False) is m and m.apply(lambda x: None) is m
         names = [n for n, _ in m.named_parameters()]
-        assert names[0] == '_module._init_std'
+        # (the reference's attribute names: policy._module, value_function.module)
+        assert names[0] == ('_module._init_std' if m is pol
+                            else 'module._init_std')
         assert len(list(m.parameters())) == len(names)
     assert len(pol.buffers()) == 1 and len(vf.buffers()) == 0  # min_std_param
     obs = torch.randn(4, 5)
