@@ -151,7 +151,7 @@ KIND_NAMES = [
     'gae_scan_rows_kernel / gae_scan_kernel',
     'skinny_fwd_kernel (first-layer forward / head data grad; work = bytes)',
     'skinny_wgrad_kernel (first-layer / head weight grad; work = bytes)',
-    'fwd_head_loss_kernel<256,1,8> (last hidden layer + head + loss + seed)',
+    'fwd_head_loss_kernel<256,1,8,false> (last hidden layer + head + loss + seed)',
     'dgrad_wgrad0_kernel<256,1,8> (data grad + first-layer weight grad)',
     'narrow_train_kernel<64> (forward + loss + backward of a 2 x 64 net)',
 ]
@@ -259,9 +259,16 @@ def roofline_pass(algo, sampler, pol, S, itr):
         if small:
             name = name.replace('<128,128,2,4,', '<64,64,2,2,')
         if width == 64:
-            name = name.replace('<256,1,8>', '<64,2,2>')
+            name = name.replace('<256,1,8', '<64,2,2')
         elif width == 128:
-            name = name.replace('<256,1,8>', '<128,1,4>')
+            name = name.replace('<256,1,8', '<128,1,4')
+        hs = algo.policy.net.hidden_sizes
+        in_w = int(algo.policy.net.dims[0])
+        if (len(hs) == 2 and in_w <= 32 and hs[0] % 32 == 0
+                and hs[0] * ((in_w + 3) // 4 * 4) <= 5120):
+            # the first layer is computed inside the kernel (ga_set_fused_first_layer)
+            name = name.replace(',false> (last hidden layer',
+                                ',true> (first layer + last hidden layer')
         rows.append(dict(kernel=name, total_ms=ms, work=work,
                          launches=int(cnt)))
     return rows

@@ -1,0 +1,29 @@
+#!/bin/bash
+# Developer tool: the round's measurement batch on one MI355X box (gpurun):
+# benches of every config, rocprofv3 kernel stats and the two PMC passes.
+# Usage (on the GPU box, from the repo root): bash tools/final_measure.sh <outdir>
+set -e
+OUT=${1:-gpurun_out/final}
+mkdir -p $OUT
+R=$PWD
+python bench.py > $OUT/c3.log 2> $OUT/c3.err
+python bench.py --no-overlap > $OUT/c3_serial.log 2>&1
+python bench.py --config c2 > $OUT/c2.log 2>&1
+python bench.py --config c5 --steps 3 --warmup 1 > $OUT/c5.log 2>&1
+python bench.py --config c1 > $OUT/c1.log 2>&1
+python bench.py --config c3mb64 --steps 3 --warmup 1 > $OUT/c3mb64.log 2>&1
+python bench.py --algo trpo > $OUT/trpo.log 2>&1
+python bench.py --config c3scan > $OUT/c3scan.log 2>&1
+python bench.py --config c4scan > $OUT/c4scan.log 2>&1
+echo benches done
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof_no -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-envs 0 --no-overlap > $R/$OUT/prof_no.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof_ov -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-envs 0 > $R/$OUT/prof_ov.log 2>&1
+echo kernel stats done
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/$OUT/pmc_fetch -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-envs 0 --no-roofline --no-overlap > $R/$OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/$OUT/pmc_write -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-envs 0 --no-roofline --no-overlap > $R/$OUT/pmc_write.log 2>&1
+cd $R
+# keep only what is small enough to travel back
+find $OUT -name '*_kernel_trace.csv' -delete
+find $OUT -name '*_agent_info.csv' -delete
+ls -la $OUT $OUT/*/* | head -40
