@@ -24,10 +24,15 @@ $(OUT)/%.o: $(CSRC)/%.cpp $(CSRC)/prof.h $(CSRC)/small_step.h $(CSRC)/fused_trai
 $(OUT)/libgarage_amd.so: $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(OBJS) -ldl -o $@
 
-clean:
-	rm -rf $(OUT)/*.o $(OUT)/*.so
+# developer tool: the matrix pipe's own ceiling (register-only MFMA loops)
+mfma-peak: tools/mfma_peak.hip
+	@mkdir -p $(OUT)
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -Wno-unused-result $< -o $(OUT)/mfma_peak
 
-.PHONY: all clean
+clean:
+	rm -rf $(OUT)/*.o $(OUT)/*.so $(OUT)/mfma_peak
+
+.PHONY: all clean mfma-peak
 
 # Host-side epoch / rollout loops under AddressSanitizer + UBSan on the CPU, with
 # every kernel entry point replaced by a recording fake (tests/host/).
