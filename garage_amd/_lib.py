@@ -16,7 +16,8 @@ c_f32, c_f64, c_int, ptr = C.c_float, C.c_double, C.c_int, C.c_void_p
 class MlpDesc(C.Structure):
     """``ga_mlp_desc``."""
     _fields_ = [('n_layers', c_i32), ('dims', c_i32 * 9), ('w_off', c_i64 * 8),
-                ('b_off', c_i64 * 8), ('act_off', c_i64 * 8)]
+                ('b_off', c_i64 * 8), ('act_off', c_i64 * 8),
+                ('hidden_act', c_i32)]
 
 
 class SynthEnv(C.Structure):
@@ -82,6 +83,8 @@ class UpdateArgs(C.Structure):
                 ('grad_scales_host', ptr), ('partials', ptr),
                 ('partials_floats', c_i64), ('phase', c_i32)]
 
+
+ABI_VERSION = 3  # ga_abi_version() of the library these structs mirror
 
 # name -> (restype, argtypes); mirrors include/garage_amd.h one to one.
 SIGNATURES = {
@@ -235,6 +238,12 @@ def load():
             '(or `python -c "import __graft_entry__ as g; g.build()"`) in the '
             'repository root. There is no CPU fallback.'.format(LIB_PATH))
     lib = C.CDLL(LIB_PATH)
+    lib.ga_abi_version.restype = c_int
+    if lib.ga_abi_version() != ABI_VERSION:
+        raise ImportError(
+            'garage_amd: {} was built from another version of the sources (ABI {} '
+            'against {} here: the argument structs differ). Run `make`.'.format(
+                LIB_PATH, lib.ga_abi_version(), ABI_VERSION))
     for name, (restype, argtypes) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError = missing export: fail loudly
         fn.restype = restype

@@ -212,16 +212,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_f32_kernel(
             const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
             v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
           }
-          if (p.act == 1) {
-            v.x = tanh_fast(v.x); v.y = tanh_fast(v.y);
-            v.z = tanh_fast(v.z); v.w = tanh_fast(v.w);
+          if (p.act) {
+            v.x = act_apply(v.x, p.act); v.y = act_apply(v.y, p.act);
+            v.z = act_apply(v.z, p.act); v.w = act_apply(v.w, p.act);
           }
         }
         if ((p.epi == EPI_BIAS_ACT && p.H) || p.epi == EPI_MUL_DTANH) {
           const float4 h =
               *reinterpret_cast<const float4*>(p.H + (int64_t)m * p.ldh + n);
-          v.x *= (1.f - h.x * h.x); v.y *= (1.f - h.y * h.y);
-          v.z *= (1.f - h.z * h.z); v.w *= (1.f - h.w * h.w);
+          v.x *= act_slope(h.x, p.hact); v.y *= act_slope(h.y, p.hact);
+          v.z *= act_slope(h.z, p.hact); v.w *= act_slope(h.w, p.hact);
         }
         *reinterpret_cast<float4*>(dst) = v;
         if constexpr (HEAD) *reinterpret_cast<float4*>(lds + rr * LDC + 4 * c4) = v;
@@ -258,14 +258,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_f32_kernel(
         if (p.accum) v += Cout[(int64_t)m * p.c_rs + (int64_t)n * p.c_cs];
         if (p.epi == EPI_BIAS_ACT) {
           v += bias;
-          if (p.act == 1) v = tanh_fast(v);
+          v = act_apply(v, p.act);
           if (p.H) {
             const float h = p.H[(int64_t)m * p.ldh + n];
-            v *= (1.f - h * h);
+            v *= act_slope(h, p.hact);
           }
         } else if (p.epi == EPI_MUL_DTANH) {
           const float h = p.H[(int64_t)m * p.ldh + n];
-          v *= (1.f - h * h);
+          v *= act_slope(h, p.hact);
         }
         Cout[(int64_t)m * p.c_rs + (int64_t)n * p.c_cs] = v;
       }
@@ -387,6 +387,7 @@ struct ga_mlp_desc {
   int64_t b_off[8];    // offset (floats) of b_l [dims[l+1]]
   int64_t act_off[8];  // offset (floats) of layer l's output in the activation
                        // workspace, row stride round4(dims[l + 1]) (hidden layers)
+  int32_t hidden_act;  // 0 tanh, 1 relu, 2 none
 };
 
 // The whole-network forward in one launch (policy_fused.hip) for nets whose
@@ -456,6 +457,8 @@ static int check_desc(const ga_mlp_desc* d, const char* who) {
   for (int l = 0; l < d->n_layers; ++l)
     GA_REQUIRE(d->w_off[l] % 4 == 0 && d->act_off[l] % 4 == 0,
                "%s: offsets of layer %d not 16-B aligned", who, l);
+  GA_REQUIRE(d->hidden_act >= 0 && d->hidden_act <= 2, "%s: hidden_act %d not in 0..2",
+             who, d->hidden_act);
   return GA_OK;
 }
 
@@ -476,7 +479,7 @@ extern "C" int ga_mlp_forward_f32(const ga_mlp_desc* d, const float* params,
   GA_REQUIRE(ga_aligned16(params) && ga_aligned16(X) && (!acts || ga_aligned16(acts)),
              "ga_mlp_forward_f32: pointers must be 16-B aligned");
   if (M == 0) return GA_OK;
-  if (out && g_fused_forward && ga_policy_step_fused_supported(d))
+  if (out && g_fused_forward && d->hidden_act == 0 && ga_policy_step_fused_supported(d))
     return ga_mlp_forward_fused_f32(d, params, X, ldx, row_idx, M, acts, out, ldo,
                                     stream);
   const int L = d->n_layers;
@@ -498,9 +501,10 @@ extern "C" int ga_mlp_forward_f32(const ga_mlp_desc* d, const float* params,
     p.M = (int)M; p.N = d->dims[l + 1]; p.K = d->dims[l];
     p.epi = EPI_BIAS_ACT;
     p.bias = params + d->b_off[l];
-    p.act = last ? 0 : 1;
+    p.act = last ? 0 : act_forward_code(d->hidden_act);
     p.k_per_split = (int)ga_ceil_div(p.K, BK) * BK;
-    if (g_skinny && p.K <= 32 && p.N > 32) {
+    // (the streaming kernels know tanh and the identity)
+    if (g_skinny && p.act <= 1 && p.K <= 32 && p.N > 32) {
       rc = ga_skinny_forward(p.A, p.lda, p.a_idx, p.B, p.ldb, true, p.bias, p.act,
                              nullptr, 0, p.C, p.c_rs, p.M, p.N, p.K, stream);
       if (rc < 0) return rc;
@@ -638,7 +642,8 @@ extern "C" int ga_mlp_backward_range_f32(const ga_mlp_desc* d, const float* para
       } else if (g_skinny && out_w <= 32 && in_w > 32) {
         // head layer: the same pass over the hidden activations also yields the
         // data gradient of the layer below (it needs dz and tanh' of `in` only)
-        const bool with_dz = g_fuse_head_dgrad && l > 0 && in_idx == nullptr;
+        const bool with_dz =
+            g_fuse_head_dgrad && l > 0 && in_idx == nullptr && d->hidden_act == 0;
         rc = ga_skinny_wgrad(in, ldin, in_idx, dz, lddz, nullptr, (int)M, in_w, out_w, kps,
                              (int)n_splits, grad_slabs + d->w_off[l], 1, round4(in_w),
                              slab_stride, nullptr, grad_slabs + d->b_off[l],
@@ -669,9 +674,10 @@ extern "C" int ga_mlp_backward_range_f32(const ga_mlp_desc* d, const float* para
       p.M = (int)M; p.N = in_w; p.K = out_w;
       p.epi = EPI_MUL_DTANH;
       p.H = acts + d->act_off[l - 1]; p.ldh = round4(in_w);
+      p.hact = d->hidden_act;
       p.k_per_split = (int)ga_ceil_div(p.K, BK) * BK;
       rc = 1;
-      if (g_skinny && p.K <= 32 && p.N > 32)
+      if (g_skinny && d->hidden_act == 0 && p.K <= 32 && p.N > 32)
         rc = ga_skinny_forward(p.A, p.lda, nullptr, p.B, p.ldb, false, nullptr, 0, p.H,
                                p.ldh, p.C, p.c_rs, p.M, p.N, p.K, stream);
       if (rc < 0) return rc;
@@ -725,7 +731,7 @@ extern "C" int ga_mlp_jvp_f32(const ga_mlp_desc* d, const float* params,
     p.C = C; p.c_rs = ldc; p.c_cs = 1;
     p.M = (int)M; p.N = out_w; p.K = in_w;
     p.epi = EPI_BIAS_ACT; p.bias = tangent + d->b_off[l]; p.act = 0;
-    if (l == 0) { p.H = H; p.ldh = ldc; }
+    if (l == 0) { p.H = H; p.ldh = ldc; p.hact = d->hidden_act; }
     p.k_per_split = (int)ga_ceil_div(p.K, BK) * BK;
     rc = launch_gemm<true, true>(p, 1, stream);
     if (rc) return rc;
@@ -738,7 +744,7 @@ extern "C" int ga_mlp_jvp_f32(const ga_mlp_desc* d, const float* params,
       q.C = C; q.c_rs = ldc; q.c_cs = 1;
       q.M = (int)M; q.N = out_w; q.K = in_w;
       q.accum = 1;
-      if (H) { q.epi = EPI_MUL_DTANH; q.H = H; q.ldh = ldc; }
+      if (H) { q.epi = EPI_MUL_DTANH; q.H = H; q.ldh = ldc; q.hact = d->hidden_act; }
       else q.epi = EPI_PLAIN;
       q.k_per_split = (int)ga_ceil_div(q.K, BK) * BK;
       rc = launch_gemm<true, true>(q, 1, stream);

@@ -26,6 +26,19 @@ __device__ __forceinline__ float tanh_fast(float x) {
   return 1.f - 2.f * __frcp_rn(e + 1.f);
 }
 
+// Hidden activations.  Forward code (GemmParams::act): 0 none, 1 tanh, 2 relu.
+// Network code (ga_mlp_desc::hidden_act, GemmParams::hact): 0 tanh (what a zeroed
+// descriptor means), 1 relu, 2 none -- the slope is taken from the OUTPUT h.
+__device__ __forceinline__ float act_apply(float v, int act) {
+  return act == 1 ? tanh_fast(v) : (act == 2 ? fmaxf(v, 0.f) : v);
+}
+__device__ __forceinline__ float act_slope(float h, int hact) {
+  return hact == 0 ? 1.f - h * h : (hact == 1 ? (h > 0.f ? 1.f : 0.f) : 1.f);
+}
+inline int act_forward_code(int hidden_act) {
+  return hidden_act == 0 ? 1 : (hidden_act == 1 ? 2 : 0);
+}
+
 struct GemmParams {
   const float* A;
   int64_t lda;           // floats between consecutive memory lines of A
@@ -39,8 +52,9 @@ struct GemmParams {
   int epi;
   const float* bias;     // EPI_BIAS_ACT: per-n bias (may be null)
   int act;               // 0 identity, 1 tanh
-  const float* H;        // EPI_MUL_DTANH (or EPI_BIAS_ACT with H set): tanh
-  int64_t ldh;           // outputs H[m * ldh + n]; the result is scaled by 1 - H^2
+  const float* H;        // EPI_MUL_DTANH (or EPI_BIAS_ACT with H set): activation
+  int64_t ldh;           // outputs H[m * ldh + n]; the result is scaled by the
+  int hact;              // activation's slope there (network code, 0 = tanh)
   int accum;             // 1: add the product to what C already holds
   int k_per_split;       // multiple of BK
   int64_t c_split_stride;

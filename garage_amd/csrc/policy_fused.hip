@@ -505,6 +505,7 @@ struct ga_mlp_desc_c {
   int64_t w_off[8];
   int64_t b_off[8];
   int64_t act_off[8];
+  int32_t hidden_act;  // 0 tanh, 1 relu, 2 none: these kernels implement tanh
 };
 
 struct ga_head_args_c {
@@ -523,6 +524,7 @@ struct ga_head_args_c {
 // 1 when ga_policy_step_fused_f32 supports this network shape.
 extern "C" int ga_policy_step_fused_supported(const ga_mlp_desc_c* d) {
   if (!d || d->n_layers < 1 || d->n_layers > 8) return 0;
+  if (d->hidden_act != 0) return 0;  // tanh hidden layers only
   for (int l = 0; l < d->n_layers; ++l)
     if (d->dims[l] > HMAX) return 0;  // every layer INPUT lives in an LDS tile
   if (d->dims[d->n_layers] > MAX_OUT) return 0;

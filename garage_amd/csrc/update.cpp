@@ -123,6 +123,7 @@ FusedPlan fused_plan(const ga_mlp_desc* d, int64_t M) {
   FusedPlan f;
   const int L = d->n_layers;
   if (L < 2 || L > 8 || M < 1) return f;
+  if (d->hidden_act != 0) return f;  // the fused kernels implement tanh hidden layers
   if (g_narrow_step && ga_narrow_step_supported(L, d->dims)) {
     f.ok = f.narrow = true;
     f.tiles = ga_fused_tiles(M);
@@ -413,7 +414,7 @@ int run_minibatch(const ga_update_args* a, int64_t k, ga_stream_t stream,
   // they hold min(S, mb) x 2H floats each, enough from 32 rows up)
   if (g_small_step && !g_fuse_head && !a->comm && a->phase != 1 && a->kind >= 0 && a->kind <= 2 &&
       (a->algo == 0 || a->algo == 1) && a->acts && a->dacts &&
-      workspace_rows(a) >= 32 &&
+      workspace_rows(a) >= 32 && a->desc->hidden_act == 0 &&
       ga_small_step_supported(L, a->desc->dims, M) &&
       ga_small_step_resident(a->desc->dims[1], 2)) {
     ga_small_step_args s;

@@ -39,7 +39,8 @@ def reduction_workspace(device, tag=0):
 
 
 class FlatMLP:
-    """One tanh MLP (+ scalar log-std slot) as a single padded fp32 buffer.
+    """One MLP (tanh, relu or linear hidden layers, + a scalar log-std slot) as a
+    single padded fp32 buffer.
 
     Layout (floats): ``[log_std, 0, 0, 0]`` then, per linear layer,
     ``W[out][round4(in)]`` and ``b[round4(out)]``.  Gradients, Adam moments and
@@ -48,7 +49,11 @@ class FlatMLP:
     follow ``GaussianMLPModule`` (torch/modules/gaussian_mlp_module.py:195-305).
     """
 
-    def __init__(self, in_dim, out_dim, hidden_sizes, device):
+    # ga_mlp_desc.hidden_act
+    HIDDEN_ACTS = {'tanh': 0, 'relu': 1, 'none': 2}
+
+    def __init__(self, in_dim, out_dim, hidden_sizes, device, hidden_act='tanh'):
+        self.hidden_act = hidden_act
         self.in_dim, self.out_dim = int(in_dim), int(out_dim)
         self.hidden_sizes = tuple(int(h) for h in hidden_sizes)
         dims = (self.in_dim, ) + self.hidden_sizes + (self.out_dim, )
@@ -76,6 +81,7 @@ class FlatMLP:
         self.exp_avg_sq = torch.zeros_like(self.params)
         self.adam_steps = 0
         d = _lib.MlpDesc()
+        d.hidden_act = self.HIDDEN_ACTS[hidden_act]
         d.n_layers = len(dims) - 1
         for i, v in enumerate(dims):
             d.dims[i] = v

@@ -25,18 +25,34 @@ from garage_amd.engine import (FlatMLP, pad_rows, reduction_workspace,
                                require_gpu, round4)
 
 
+def _hidden_act(hidden_nonlinearity):
+    """``hidden_nonlinearity`` of the reference's MLP modules
+    (``torch/modules/mlp_module.py:43-44``, wrapped by ``NonLinearity``,
+    ``multi_headed_mlp_module.py:154-197``: a callable or an ``nn.Module``
+    class / instance, ``None`` = linear) as the kernels' activation name."""
+    import torch.nn.functional as F
+    h = hidden_nonlinearity
+    if h is None:
+        return 'none'
+    if h in (torch.tanh, 'tanh', nn.Tanh, F.tanh) or isinstance(h, nn.Tanh):
+        return 'tanh'
+    if h in (torch.relu, 'relu', nn.ReLU, F.relu) or isinstance(h, nn.ReLU):
+        return 'relu'
+    raise NotImplementedError(
+        'garage_amd kernels implement tanh (the GaussianMLP* default), relu and '
+        'linear hidden layers; got {!r}'.format(hidden_nonlinearity))
+
+
 def _check_supported(hidden_nonlinearity, output_nonlinearity,
                      std_parameterization, layer_normalization):
-    if hidden_nonlinearity not in (torch.tanh, 'tanh', nn.Tanh):
-        raise NotImplementedError(
-            'garage_amd kernels implement tanh hidden layers (the '
-            'GaussianMLP* default); got {!r}'.format(hidden_nonlinearity))
+    act = _hidden_act(hidden_nonlinearity)
     if output_nonlinearity is not None:
         raise NotImplementedError('output_nonlinearity must be None')
     if std_parameterization != 'exp':
         raise NotImplementedError("only std_parameterization='exp'")
     if layer_normalization:
         raise NotImplementedError('layer_normalization is not supported')
+    return act
 
 
 def _reference_init(mlp, hidden_w_init, hidden_b_init, output_w_init,
@@ -69,9 +85,10 @@ class _GaussianMLP:
 
     def _build(self, in_dim, out_dim, hidden_sizes, hidden_w_init,
                hidden_b_init, output_w_init, output_b_init, learn_std,
-               init_std, min_std, max_std, device):
+               init_std, min_std, max_std, device, hidden_act='tanh'):
         self.device = device or require_gpu()
-        self.net = FlatMLP(in_dim, out_dim, hidden_sizes, self.device)
+        self.net = FlatMLP(in_dim, out_dim, hidden_sizes, self.device,
+                           hidden_act=hidden_act)
         _reference_init(self.net, hidden_w_init, hidden_b_init, output_w_init,
                         output_b_init)
         self._learn_std = bool(learn_std)
@@ -174,7 +191,8 @@ class _GaussianMLP:
                 'garage_amd modules live on the GPU; there is no CPU fallback')
         if device.index is not None and device != self.device:
             net = FlatMLP(self.net.in_dim, self.net.out_dim,
-                          self.net.hidden_sizes, device)
+                          self.net.hidden_sizes, device,
+                          hidden_act=self.net.hidden_act)
             for k in ('params', 'grads', 'exp_avg', 'exp_avg_sq'):
                 getattr(net, k).copy_(getattr(self.net, k))
             net.adam_steps = self.net.adam_steps
@@ -254,6 +272,7 @@ class _GaussianMLP:
         state = {k: v for k, v in self.__dict__.items()
                  if k not in ('net', 'device')}
         state['_hidden_sizes'] = self.net.hidden_sizes
+        state['_hidden_act'] = self.net.hidden_act
         state['_dims'] = (self.net.in_dim, self.net.out_dim)
         for k in ('params', 'exp_avg', 'exp_avg_sq'):
             state['_net_' + k] = getattr(self.net, k).cpu().numpy()
@@ -262,13 +281,14 @@ class _GaussianMLP:
 
     def __setstate__(self, state):
         hidden = state.pop('_hidden_sizes')
+        act = state.pop('_hidden_act', 'tanh')
         in_dim, out_dim = state.pop('_dims')
         bufs = {k: state.pop('_net_' + k)
                 for k in ('params', 'exp_avg', 'exp_avg_sq')}
         steps = state.pop('_net_steps')
         self.__dict__.update(state)
         self.device = require_gpu()
-        self.net = FlatMLP(in_dim, out_dim, hidden, self.device)
+        self.net = FlatMLP(in_dim, out_dim, hidden, self.device, hidden_act=act)
         for k, v in bufs.items():
             getattr(self.net, k).copy_(torch.from_numpy(v))
         self.net.adam_steps = steps
@@ -294,8 +314,8 @@ class GaussianMLPPolicy(_GaussianMLP):
                  layer_normalization=False,
                  name='GaussianMLPPolicy',
                  device=None):
-        _check_supported(hidden_nonlinearity, output_nonlinearity,
-                         std_parameterization, layer_normalization)
+        act = _check_supported(hidden_nonlinearity, output_nonlinearity,
+                               std_parameterization, layer_normalization)
         if is_discrete(env_spec.action_space):
             raise ValueError('GaussianMLPPolicy needs a continuous action '
                              'space')
@@ -305,7 +325,8 @@ class GaussianMLPPolicy(_GaussianMLP):
         self._action_dim = env_spec.action_space.flat_dim
         self._build(self._obs_dim, self._action_dim, hidden_sizes,
                     hidden_w_init, hidden_b_init, output_w_init, output_b_init,
-                    learn_std, init_std, min_std, max_std, device)
+                    learn_std, init_std, min_std, max_std, device,
+                    hidden_act=act)
         # derived from torch's seed without consuming the global stream, so the
         # objects constructed after this one still match the reference's init
         self._sample_seed = int(torch.initial_seed() & 0x7FFFFFFF)
@@ -411,7 +432,8 @@ class CategoricalMLPPolicy(_GaussianMLP):
                  double_softmax=True,
                  name='CategoricalMLPPolicy',
                  device=None):
-        _check_supported(hidden_nonlinearity, None, 'exp', layer_normalization)
+        act = _check_supported(hidden_nonlinearity, None, 'exp',
+                               layer_normalization)
         if not is_discrete(env_spec.action_space):
             raise ValueError('CategoricalMLPPolicy only works '
                              'with akro.Discrete action space.')
@@ -422,7 +444,7 @@ class CategoricalMLPPolicy(_GaussianMLP):
         self._action_dim = env_spec.action_space.n
         self._build(self._obs_dim, self._action_dim, hidden_sizes,
                     hidden_w_init, hidden_b_init, output_w_init, output_b_init,
-                    False, 1.0, None, None, device)
+                    False, 1.0, None, None, device, hidden_act=act)
         self._sample_seed = int(torch.initial_seed() & 0x7FFFFFFF)
         self._sample_calls = 0
 
@@ -494,13 +516,13 @@ class GaussianMLPValueFunction(_GaussianMLP):
                  layer_normalization=False,
                  name='GaussianMLPValueFunction',
                  device=None):
-        _check_supported(hidden_nonlinearity, output_nonlinearity, 'exp',
-                         layer_normalization)
+        act = _check_supported(hidden_nonlinearity, output_nonlinearity, 'exp',
+                               layer_normalization)
         self._env_spec = env_spec
         self.name = name
         self._build(env_spec.observation_space.flat_dim, 1, hidden_sizes,
                     hidden_w_init, hidden_b_init, output_w_init, output_b_init,
-                    learn_std, init_std, None, None, device)
+                    learn_std, init_std, None, None, device, hidden_act=act)
 
     def values(self, obs_dev, M=None, row_idx=None):
         """``(M, 4)`` device tensor, the value in column 0."""

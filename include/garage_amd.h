@@ -29,7 +29,7 @@ extern "C" {
 
 typedef void* ga_stream_t; /* hipStream_t */
 
-int ga_abi_version(void); /* 2 */
+int ga_abi_version(void); /* 3 */
 const char* ga_last_error(void);
 
 /* ---- returns + GAE(lambda) -------------------------------------------------
@@ -67,8 +67,8 @@ int ga_set_gae_rows_steps_per_lane(int steps);
  * Replaces MLPModule / MultiHeadedMLPModule.forward
  * (torch/modules/multi_headed_mlp_module.py:136-151) and its autograd backward
  * as used by VPG._train_policy / _train_value_function (vpg.py:250-293).
- * Hidden activations are tanh (the GaussianMLP* defaults,
- * torch/policies/gaussian_mlp_policy.py:44-60). */
+ * Hidden activations: tanh (the GaussianMLP* defaults,
+ * torch/policies/gaussian_mlp_policy.py:44-60), relu or none. */
 typedef struct {
   int32_t n_layers;   /* linear layers incl. the output layer, 1..8 */
   int32_t dims[9];    /* dims[0] = input width, dims[l+1] = width of layer l */
@@ -76,6 +76,11 @@ typedef struct {
   int64_t b_off[8];   /* b_l [dims[l+1]] offset (floats) in params */
   int64_t act_off[8]; /* hidden layer l output offset in the activation workspace,
                          row stride round4(dims[l+1]) */
+  int32_t hidden_act; /* hidden_nonlinearity of MLPModule
+                         (torch/modules/mlp_module.py:43-44): 0 = tanh (the
+                         GaussianMLP* default; what a zeroed descriptor means),
+                         1 = relu, 2 = none.  The fused / one-launch kernels
+                         implement tanh; other networks take the per-layer GEMMs. */
 } ga_mlp_desc;
 
 /* out[M, ldo] = MLP(X[row_idx[i]] or X[i]); acts keeps the hidden outputs. */

@@ -2,7 +2,7 @@
 
 TEST INFRASTRUCTURE (see ``oracle/__init__.py``).  Restates
   * ``torch/modules/multi_headed_mlp_module.py:136-151`` + ``mlp_module.py:62-73``
-    (Linear -> tanh stack, linear output head)
+    (Linear -> hidden_nonlinearity stack -- tanh by default -- linear output head)
   * ``torch/modules/gaussian_mlp_module.py:158-192,288-305`` (scalar log-std
     broadcast, lower clamp at log(min_std), exp parameterisation,
     ``Independent(Normal(mean, std), 1)``)
@@ -16,6 +16,7 @@ Parameters live in an ordered ``dict[str, torch.Tensor]`` that uses the
 reference's ``state_dict`` key names, so a golden ``state_dict`` captured from
 the real classes drops straight in.
 """
+import contextlib
 import math
 from collections import OrderedDict
 
@@ -72,13 +73,30 @@ def n_hidden(params, prefix):
     return i
 
 
+# ``hidden_nonlinearity`` (mlp_module.py:43-44) is a constructor argument of the
+# reference modules, not part of their state_dict: the parameter dicts cannot carry
+# it, so it is set around a computation, per network (None = linear).
+_HIDDEN = [{POLICY_PREFIX: torch.tanh, VALUE_PREFIX: torch.tanh}]
+
+
+@contextlib.contextmanager
+def hidden_nonlinearity(policy=torch.tanh, value=torch.tanh):
+    _HIDDEN.append({POLICY_PREFIX: policy, VALUE_PREFIX: value})
+    try:
+        yield
+    finally:
+        _HIDDEN.pop()
+
+
 def mlp_mean(params, prefix, x):
-    """tanh MLP trunk + linear head."""
+    """MLP trunk (tanh unless ``hidden_nonlinearity`` says otherwise) + linear head."""
+    act = _HIDDEN[-1].get(prefix, torch.tanh)
     for i in range(n_hidden(params, prefix)):
         base = '{}_mean_module._layers.{}.linear.'.format(prefix, i)
-        x = torch.tanh(
-            torch.nn.functional.linear(x, params[base + 'weight'],
-                                       params[base + 'bias']))
+        x = torch.nn.functional.linear(x, params[base + 'weight'],
+                                       params[base + 'bias'])
+        if act is not None:
+            x = act(x)
     base = prefix + '_mean_module._output_layers.0.linear.'
     return torch.nn.functional.linear(x, params[base + 'weight'],
                                       params[base + 'bias'])

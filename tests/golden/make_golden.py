@@ -622,6 +622,13 @@ def gen_policy_options():
         dict(tag='max_clamp', pol=dict(max_std=0.5, init_std=1.0)),
         dict(tag='min_clamp', pol=dict(min_std=0.2, init_std=0.1)),
         dict(tag='init_small', pol=dict(init_std=0.3)),
+        # hidden_nonlinearity of both networks (mlp_module.py:43-44 through
+        # NonLinearity, multi_headed_mlp_module.py:154-197)
+        dict(tag='relu', pol=dict(hidden_nonlinearity=torch.relu),
+             vf=dict(hidden_nonlinearity=torch.relu)),
+        dict(tag='linear', pol=dict(hidden_nonlinearity=None),
+             vf=dict(hidden_nonlinearity=None)),
+        dict(tag='relu_policy_tanh_vf', pol=dict(hidden_nonlinearity=torch.nn.ReLU)),
     ]
     out = {}
     for case in cases:
@@ -634,7 +641,15 @@ def gen_policy_options():
         torch.manual_seed(17)
         rng = np.random.RandomState(17)
         pol = GaussianMLPPolicy(spec, hidden_sizes=hs, **case['pol'])
-        vf = GaussianMLPValueFunction(spec, hidden_sizes=hs)
+        vf = GaussianMLPValueFunction(spec, hidden_sizes=hs, **case.get('vf', {}))
+        if 'vf' in case or 'hidden_nonlinearity' in case['pol']:
+            # forward outputs of the freshly built networks on fixed inputs
+            x = torch.from_numpy(
+                np.random.RandomState(3).randn(6, O).astype(np.float32))
+            with torch.no_grad():
+                out[tag + '_fwd_obs'] = x.numpy()
+                out[tag + '_fwd_mean'] = pol(x)[0].mean.numpy()
+                out[tag + '_fwd_value'] = vf(x).numpy()
         out.update(state_arrays(tag + '_pol0:', pol))
         out.update(state_arrays(tag + '_vf0:', vf))
         algo = PPO(env_spec=spec, policy=pol, value_function=vf, sampler=None,

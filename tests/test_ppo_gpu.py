@@ -629,6 +629,162 @@ def test_policy_std_options_match_real_reference(golden, tag):
             assert np.allclose(v.numpy(), g[pre + 'vf:' + k], atol=2e-6), k
 
 
+ACTIVATION_CASES = {
+    # tag: (policy hidden_nonlinearity, value-function hidden_nonlinearity)
+    'relu': (torch.relu, torch.relu),
+    'linear': (None, None),
+    'relu_policy_tanh_vf': (torch.nn.ReLU, torch.tanh),
+}
+
+
+@pytest.mark.parametrize('tag', sorted(ACTIVATION_CASES))
+def test_hidden_nonlinearities_match_real_reference(golden, tag):
+    """``hidden_nonlinearity`` = relu / None (``torch/modules/mlp_module.py:43-44``):
+    forward outputs of the real networks and two real PPO iterations
+    (tests/golden/policy_options.npz).  Such networks take the per-layer GEMM
+    kernels (the fused / one-launch kernels implement tanh)."""
+    from garage_amd.algos import PPO
+    from garage_amd.engine import pad_rows
+    from garage_amd.optimizers import OptimizerWrapper
+    from garage_amd.policies import GaussianMLPPolicy, GaussianMLPValueFunction
+    g = golden('policy_options')
+    O, A, P, E, mb = [int(v) for v in g[tag + '_cfg']]
+    spec = _spec(O, A, P)
+    pa, va = ACTIVATION_CASES[tag]
+    pol = GaussianMLPPolicy(spec, hidden_sizes=(8, 8), hidden_nonlinearity=pa)
+    vf = GaussianMLPValueFunction(spec, hidden_sizes=(8, 8),
+                                  hidden_nonlinearity=va)
+    pol.load_state_dict(_sd(g, tag + '_pol0:'))
+    vf.load_state_dict(_sd(g, tag + '_vf0:'))
+    x = torch.from_numpy(g[tag + '_fwd_obs'])
+    dist, _ = pol.forward(x)
+    assert np.allclose(dist.mean.cpu().numpy(), g[tag + '_fwd_mean'], atol=2e-6)
+    assert np.allclose(vf.forward(x).cpu().numpy().reshape(-1),
+                       g[tag + '_fwd_value'].reshape(-1), atol=2e-6)
+    algo = PPO(env_spec=spec, policy=pol, value_function=vf, sampler=None,
+               policy_optimizer=OptimizerWrapper(
+                   (torch.optim.Adam, dict(lr=2.5e-3)), pol,
+                   max_optimization_epochs=E, minibatch_size=mb),
+               vf_optimizer=OptimizerWrapper(
+                   (torch.optim.Adam, dict(lr=2.5e-3)), vf,
+                   max_optimization_epochs=E, minibatch_size=mb))
+    for it in range(2):
+        pre = '%s_it%d_' % (tag, it)
+        batch = _host_batch(spec, g, pre, O)
+        np.random.seed(int(g[pre + 'np_seed']))
+        algo._train_once(it, batch)
+        for mine, theirs in LOG_KEYS.items():
+            want = float(g[pre + 'log:' + theirs])
+            assert np.isclose(algo.last_tabular[mine], want, atol=1e-5,
+                              rtol=1e-5), (mine, it, algo.last_tabular[mine],
+                                           want)
+        for k, v in pol.state_dict().items():
+            assert np.allclose(v.numpy(), g[pre + 'pol:' + k], atol=2e-6), k
+        for k, v in vf.state_dict().items():
+            assert np.allclose(v.numpy(), g[pre + 'vf:' + k], atol=2e-6), k
+
+
+@pytest.mark.parametrize('act', ['relu', 'none'])
+def test_hidden_nonlinearity_at_c3_shape_against_oracle(act):
+    """A relu / linear MLP(256,256) on a 3000-sample batch (the MFMA tile kernels,
+    split-K slabs, the streaming weight-gradient kernels without their tanh'
+    fusion): one PPO iteration against the oracle."""
+    from garage_amd._dtypes import EpisodeBatch, StepType
+    from garage_amd.algos import PPO
+    from garage_amd.optimizers import OptimizerWrapper
+    from garage_amd.policies import GaussianMLPPolicy, GaussianMLPValueFunction
+    from oracle import batch as ob
+    from oracle import networks as nets
+    from oracle.ppo import OraclePPO
+    fn = torch.relu if act == 'relu' else None
+    O, A, P = 17, 6, 32
+    spec = _spec(O, A, P)
+    torch.manual_seed(8)
+    rng = np.random.RandomState(8)
+    pol = GaussianMLPPolicy(spec, hidden_sizes=(256, 256), hidden_nonlinearity=fn)
+    vf = GaussianMLPValueFunction(spec, hidden_sizes=(256, 256),
+                                  hidden_nonlinearity=fn)
+    lens = rng.randint(4, P + 1, size=150)
+    lens[::5] = P
+    S = int(lens.sum())
+    st = []
+    for L in lens:
+        t = [1] * L
+        t[0] = 0
+        t[-1] = 3 if L == P else 2
+        st += t
+    obs = rng.randn(S, O).astype(np.float32)
+    acts = rng.randn(S, A).astype(np.float32)
+    rew = rng.randn(S)
+    E, mb = 2, 700
+    with nets.hidden_nonlinearity(policy=fn, value=fn):
+        oracle = OraclePPO(OrderedDict(pol.state_dict()),
+                           OrderedDict(vf.state_dict()), max_episode_length=P,
+                           max_optimization_epochs=E, minibatch_size=mb,
+                           policy_lr=1e-3, vf_lr=1e-3)
+        b = ob.OracleEpisodeBatch(
+            observations=obs, last_observations=np.zeros((len(lens), O),
+                                                         np.float32),
+            actions=acts, rewards=rew, step_types=np.asarray(st), lengths=lens,
+            max_episode_length=P)
+        np.random.seed(4)
+        want = oracle.train_once(b)
+        wpol, wvf = oracle.state()
+    algo = PPO(env_spec=spec, policy=pol, value_function=vf, sampler=None,
+               policy_optimizer=OptimizerWrapper(
+                   (torch.optim.Adam, dict(lr=1e-3)), pol,
+                   max_optimization_epochs=E, minibatch_size=mb),
+               vf_optimizer=OptimizerWrapper(
+                   (torch.optim.Adam, dict(lr=1e-3)), vf,
+                   max_optimization_epochs=E, minibatch_size=mb))
+    batch = EpisodeBatch(env_spec=spec, episode_infos={}, observations=obs,
+                         last_observations=np.zeros((len(lens), O), np.float32),
+                         actions=acts, rewards=rew, env_infos={}, agent_infos={},
+                         step_types=np.asarray([StepType(s) for s in st],
+                                               dtype=object),
+                         lengths=lens.astype('l'))
+    np.random.seed(4)
+    algo._train_once(0, batch)
+    for k in ('policy/LossBefore', 'policy/LossAfter', 'policy/KL',
+              'policy/Entropy', 'vf/LossBefore', 'vf/LossAfter'):
+        assert np.isclose(algo.last_tabular[k], want[k], atol=2e-5,
+                          rtol=2e-4), (k, algo.last_tabular[k], want[k])
+    for mine, theirs in ((pol.state_dict(), wpol), (vf.state_dict(), wvf)):
+        for k, v in mine.items():
+            d = np.abs(v.numpy() - np.asarray(theirs[k]))
+            assert d.max() <= 1e-4 and d.mean() <= 2e-6, (k, d.max(), d.mean())
+
+
+def test_rollout_with_relu_policy_stores_the_relu_means():
+    """The fused rollout step implements tanh: a relu policy samples through the
+    per-layer forward + head kernels; the stored ``agent_infos['mean']`` are the
+    relu network's outputs on the stored observations (oracle forward)."""
+    from garage_amd.envs import SyntheticVecEnv
+    from garage_amd.policies import GaussianMLPPolicy
+    from garage_amd.sampler import GpuVecSampler, GpuVecWorker
+    from oracle import networks as nets
+    n, O, A, P = 48, 7, 3, 12
+    torch.manual_seed(2)
+    env = SyntheticVecEnv(n, O, A, P, min_len=4, seed=5)
+    pol = GaussianMLPPolicy(env.spec, hidden_sizes=(32, 32),
+                            hidden_nonlinearity=torch.relu)
+    sampler = GpuVecSampler(agents=pol, envs=env, max_episode_length=P,
+                            n_workers=1, worker_class=GpuVecWorker,
+                            worker_args=dict(n_envs=n))
+    eps = sampler.obtain_samples(0, n * P, agent_update=None)
+    params = OrderedDict(pol.state_dict())
+    with nets.hidden_nonlinearity(policy=torch.relu), torch.no_grad():
+        want = nets.policy_forward(
+            params, torch.from_numpy(np.asarray(eps.observations)))[0].mean
+    assert np.allclose(np.asarray(eps.agent_infos['mean']), want.numpy(),
+                       atol=2e-6)
+    # ... and they differ from what a tanh network with the same weights gives
+    with torch.no_grad():
+        tanh_mean = nets.policy_forward(
+            params, torch.from_numpy(np.asarray(eps.observations)))[0].mean
+    assert not np.allclose(want.numpy(), tanh_mean.numpy(), atol=1e-3)
+
+
 SHAPE_CASES = [
     # (obs, act, policy hidden, value hidden, kwargs)
     (33, 17, (100, 37), (24, ), dict()),
