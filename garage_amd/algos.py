@@ -422,13 +422,8 @@ class VPG:
         return np.mean(undiscounted)
 
     def _clamped(self, params):
-        s = float(params[0].item())
-        pol = self.policy
-        if pol._min_log_std is not None:
-            s = max(s, pol._min_log_std)
-        if pol._max_log_std is not None:
-            s = min(s, pol._max_log_std)
-        return s
+        """Log std of the policy for the parameters in ``params``."""
+        return self.policy.log_std_of(float(params[0].item()))[0]
 
     def _mean_kl(self, mean_old, mean_old_pad, s_old, mean_new, zero_obs, S,
                  n_pad, n_cells):
@@ -1045,13 +1040,12 @@ class TRPO(VPG):
             self._comm.all_reduce(g, 'sum')
         # the log-std block: d2/ds2 of sum_a [s - s_old + exp(2(s_old - s))/2]
         # = 2 A at s == s_old, through the clamp's pass-through gradient
-        s_raw = float(net.params[0].item())
-        live = getattr(pol, '_learn_std', True)
-        if has_min and s_raw < mn:
-            live = False
-        if has_max and s_raw > mx:
-            live = False
-        g[0:1].copy_(vec[0:1] * (2.0 * net.out_dim if live else 0.0))
+        # (and the std parameterisation: log std = f(p) has d2 KL / dp2 =
+        # f'(p)^2 d2 KL / ds2 there, the first derivative of the KL being zero)
+        chain = pol.log_std_of(float(net.params[0].item()))[1]
+        if not getattr(pol, '_learn_std', True):
+            chain = 0.0
+        g[0:1].copy_(vec[0:1] * (2.0 * net.out_dim * chain * chain))
         out.copy_(g)
         call('ga_axpby_f32', float(hyper['hvp_reg_coeff']), dptr(vec), 1.0,
              dptr(out), out.numel(), stream_ptr())

@@ -60,6 +60,29 @@ __device__ __forceinline__ void ga_xcd_group(int id, int n_groups, int n_members
   }
 }
 
+// The scalar std parameter of GaussianMLPBaseModule.forward
+// (torch/modules/gaussian_mlp_module.py:165-181): clamp to [log min_std,
+// log max_std], then 'exp' -> log std = p, or 'softplus' -> std =
+// log(1 + exp(exp(p))).  `has_min` carries two flags: bit 0 = a lower clamp is
+// present, bit 1 = softplus parameterisation.  Returns log std and
+// *chain = d(log std) / d(parameter) (0 through an active clamp: torch.clamp
+// passes no gradient outside the range).
+__host__ __device__ inline float ga_log_std(float param, int has_min, float min_log_std,
+                                            int has_max, float max_log_std,
+                                            float* chain) {
+  float p = param, c = 1.f;
+  if ((has_min & 1) && p < min_log_std) { p = min_log_std; c = 0.f; }
+  if (has_max && p > max_log_std) { p = max_log_std; c = 0.f; }
+  if (has_min & 2) {
+    const float e = expf(p);
+    const float sp = logf(1.f + expf(e));  // the reference's .exp().exp().add(1).log()
+    c *= e / ((1.f + expf(-e)) * sp);
+    p = logf(sp);
+  }
+  if (chain) *chain = c;
+  return p;
+}
+
 __device__ __forceinline__ float ga_wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);

@@ -176,9 +176,8 @@ __device__ __forceinline__ void lr_finish(const LossRowArgs& a, double first, do
     *dlogstd = (float)(second / (double)M);
     return;
   }
-  bool s_grad = true;
-  if (a.has_min && s < a.min_log_std) { s = a.min_log_std; s_grad = false; }
-  if (a.has_max && s > a.max_log_std) { s = a.max_log_std; s_grad = false; }
+  float chain;
+  s = ga_log_std(s, a.has_min, a.min_log_std, a.has_max, a.max_log_std, &chain);
   double mean_obj = first / (double)M;
   double dls = second / (double)M;
   if (a.ent_regularized) {
@@ -192,7 +191,7 @@ __device__ __forceinline__ void lr_finish(const LossRowArgs& a, double first, do
     if (!a.ent_stop_grad) dls += -(double)(a.ent_coeff * dent);
   }
   *loss = (float)(-mean_obj);
-  *dlogstd = s_grad ? (float)dls : 0.f;
+  *dlogstd = chain != 0.f ? (float)dls * chain : 0.f;
 }
 
 }  // namespace

@@ -99,10 +99,8 @@ __device__ void ppo_gaussian_finish(double obj, double ds, const float* log_std,
                                     int ent_softplus, int ent_stop_grad,
                                     float* loss_out, float* grad_slab0,
                                     int64_t slab_stride, int64_t n_splits) {
-  float s = *log_std;
-  bool s_grad = true;
-  if (has_min && s < min_log_std) { s = min_log_std; s_grad = false; }
-  if (has_max && s > max_log_std) { s = max_log_std; s_grad = false; }
+  float chain;
+  const float s = ga_log_std(*log_std, has_min, min_log_std, has_max, max_log_std, &chain);
   double mean_obj = obj / (double)M;
   double dlogstd = ds / (double)M;  // d(-mean obj)/ds through the likelihood
   if (ent_regularized) {
@@ -118,18 +116,16 @@ __device__ void ppo_gaussian_finish(double obj, double ds, const float* log_std,
   }
   *loss_out = (float)(-mean_obj);
   if (grad_slab0) {
-    grad_slab0[0] = s_grad ? (float)dlogstd : 0.f;
+    // (through the clamp and the std parameterisation: 0 when the clamp is active)
+    grad_slab0[0] = chain != 0.f ? (float)dlogstd * chain : 0.f;
     for (int64_t k = 1; k < n_splits; ++k) grad_slab0[k * slab_stride] = 0.f;
   }
 }
 
 __global__ __launch_bounds__(256) void ppo_gaussian_loss_kernel(PpoLossParams p) {
   __shared__ double red[4];
-  float s_raw = *p.log_std;
-  float s = s_raw;
-  bool s_grad = true;  // clamp passes gradient inside [min, max] (inclusive)
-  if (p.has_min && s < p.min_log_std) { s = p.min_log_std; s_grad = false; }
-  if (p.has_max && s > p.max_log_std) { s = p.max_log_std; s_grad = false; }
+  const float s = ga_log_std(*p.log_std, p.has_min, p.min_log_std, p.has_max,
+                             p.max_log_std, nullptr);
   const float inv_var = expf(-2.f * s);
   const float lognorm = s + (float)HALF_LOG_2PI;
   const float invM = 1.f / (float)p.M;
@@ -196,8 +192,6 @@ __global__ __launch_bounds__(256) void ppo_gaussian_loss_kernel(PpoLossParams p)
                         p.max_log_std, p.M, p.A, p.ent_coeff, p.ent_regularized,
                         p.ent_softplus, p.ent_stop_grad, p.loss_out, p.grad_slab0,
                         p.slab_stride, p.n_splits);
-  (void)s_grad;
-  (void)s_raw;
 }
 
 struct PpoFinalizeParams {
@@ -1052,9 +1046,7 @@ __global__ __launch_bounds__(256) void fisher_seed_kernel(
     const float* tmean, int64_t ldt, int64_t M, int A, const float* log_std,
     int has_min, float min_log_std, int has_max, float max_log_std, float* dout,
     int64_t ldd) {
-  float s = *log_std;
-  if (has_min && s < min_log_std) s = min_log_std;
-  if (has_max && s > max_log_std) s = max_log_std;
+  const float s = ga_log_std(*log_std, has_min, min_log_std, has_max, max_log_std, nullptr);
   const float scale = expf(-2.f * s) / (float)M;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= M) return;
@@ -1179,9 +1171,8 @@ __global__ __launch_bounds__(HL_THREADS) void head_ppo_gaussian_kernel(HeadLayer
   __shared__ double red[4];
   stage_head(L, p.A, wlds);
   __syncthreads();
-  float s = *p.log_std;
-  if (p.has_min && s < p.min_log_std) s = p.min_log_std;
-  if (p.has_max && s > p.max_log_std) s = p.max_log_std;
+  const float s = ga_log_std(*p.log_std, p.has_min, p.min_log_std, p.has_max,
+                             p.max_log_std, nullptr);
   const float inv_var = expf(-2.f * s);
   const float lognorm = s + (float)HALF_LOG_2PI;
   const float invM = 1.f / (float)p.M;

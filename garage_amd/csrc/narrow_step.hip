@@ -268,10 +268,8 @@ __global__ __launch_bounds__(NS_THREADS) void narrow_train_kernel(NarrowParams p
     float s = 0.f, inv_var = 1.f;
     if (L.kind != 2) {
       s = *L.log_std;
-      if (L.kind == 0) {
-        if (L.has_min && s < L.min_log_std) s = L.min_log_std;
-        if (L.has_max && s > L.max_log_std) s = L.max_log_std;
-      }
+      if (L.kind == 0)
+        s = ga_log_std(s, L.has_min, L.min_log_std, L.has_max, L.max_log_std, nullptr);
       inv_var = expf(-2.f * s);
     }
     float out[8], dout[8];

@@ -272,9 +272,8 @@ __global__ __launch_bounds__(256) void policy_step_fused_kernel(FusedParams p) {
           for (int j = 0; j < N; ++j) p.head_buf[cell * p.ldh + j] = h[j];
       }
       if (p.kind == 0) {
-        float s = p.params[0];
-        if (p.has_min) s = fmaxf(s, p.min_log_std);
-        if (p.has_max) s = fminf(s, p.max_log_std);
+        const float s = ga_log_std(p.params[0], p.has_min, p.min_log_std, p.has_max,
+                                   p.max_log_std, nullptr);
         const float sd = expf(s);
         for (int b = 0; b * 4 < N; ++b) {
           float z[4];

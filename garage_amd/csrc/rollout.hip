@@ -230,9 +230,8 @@ __device__ __forceinline__ void box_muller(uint32_t u0, uint32_t u1, float* z0,
 __global__ __launch_bounds__(256) void gaussian_head_kernel(HeadParams p) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= p.n) return;
-  float s = *p.log_std;
-  if (p.has_min) s = fmaxf(s, p.min_log_std);
-  if (p.has_max) s = fminf(s, p.max_log_std);
+  const float s = ga_log_std(*p.log_std, p.has_min, p.min_log_std, p.has_max,
+                             p.max_log_std, nullptr);
   const float std = expf(s);
   const uint32_t env = (uint32_t)(p.env_id0 + i);
   const float* mu = p.head + i * p.ldh;

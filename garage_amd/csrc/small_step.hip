@@ -458,15 +458,15 @@ __global__ __launch_bounds__(SS_THREADS) void small_step_kernel(SmallStepParams 
   // ---- B.2: loss and d(loss)/d(out), one lane per row (wave 0)
   if (tid < 64) {
     const float invM = 1.f / (float)M;
-    float s = p.params[0];
+    float s = p.params[0], s_chain = 1.f;
     bool s_grad = true;
     double obj = 0.0, ds = 0.0;
     float dm[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) dm[j] = 0.f;
     if (p.kind == 0) {
-      if (p.has_min && s < p.min_log_std) { s = p.min_log_std; s_grad = false; }
-      if (p.has_max && s > p.max_log_std) { s = p.max_log_std; s_grad = false; }
+      s = ga_log_std(s, p.has_min, p.min_log_std, p.has_max, p.max_log_std, &s_chain);
+      s_grad = s_chain != 0.f;
       const float inv_var = expf(-2.f * s);
       const float lognorm = s + (float)SS_HALF_LOG_2PI;
       if (live) {
@@ -607,7 +607,7 @@ __global__ __launch_bounds__(SS_THREADS) void small_step_kernel(SmallStepParams 
         if (!p.ent_stop_grad) dls += -(double)(p.ent_coeff * dent);
       }
       if (blockIdx.x == 0) *p.loss_out = (float)(p.kind == 1 ? mean : -mean);
-      dlogstd_s = s_grad ? (float)dls : 0.f;
+      dlogstd_s = s_grad ? (float)dls * s_chain : 0.f;
     }
   }
   __syncthreads();

@@ -48,8 +48,8 @@ def _check_supported(hidden_nonlinearity, output_nonlinearity,
     act = _hidden_act(hidden_nonlinearity)
     if output_nonlinearity is not None:
         raise NotImplementedError('output_nonlinearity must be None')
-    if std_parameterization != 'exp':
-        raise NotImplementedError("only std_parameterization='exp'")
+    if std_parameterization not in ('exp', 'softplus'):
+        raise NotImplementedError  # gaussian_mlp_module.py:120-121
     if layer_normalization:
         raise NotImplementedError('layer_normalization is not supported')
     return act
@@ -99,21 +99,41 @@ class _GaussianMLP:
             torch.Tensor([max_std]).log())
 
     # -- std handling ---------------------------------------------------------
+    _std_softplus = False  # std_parameterization='softplus' (Gaussian policy only)
+
     def _std_args(self):
-        """(has_min, min, has_max, max) as the kernels take them."""
-        return (int(self._min_log_std is not None),
+        """(has_min, min, has_max, max) as the kernels take them; bit 1 of
+        ``has_min`` says "softplus parameterisation" (``ga_log_std``, common.h)."""
+        return (int(self._min_log_std is not None) |
+                (2 if self._std_softplus else 0),
                 float(self._min_log_std or 0.0),
                 int(self._max_log_std is not None),
                 float(self._max_log_std or 0.0))
 
+    def log_std_of(self, raw):
+        """``(log std, d log std / d parameter)`` for a raw parameter value:
+        clamp, then ``exp`` (identity on the log) or ``softplus`` -- std =
+        log(1 + exp(exp(p))) -- in fp32 like
+        ``GaussianMLPBaseModule.forward`` (gaussian_mlp_module.py:165-181)."""
+        p, chain = np.float32(raw), np.float32(1.0)
+        if self._min_log_std is not None and p < self._min_log_std:
+            p, chain = np.float32(self._min_log_std), np.float32(0.0)
+        if self._max_log_std is not None and p > self._max_log_std:
+            p, chain = np.float32(self._max_log_std), np.float32(0.0)
+        if self._std_softplus:
+            with np.errstate(over='ignore'):
+                e = np.exp(p, dtype=np.float32)
+                sp = np.log(np.float32(1.0) + np.exp(e, dtype=np.float32),
+                            dtype=np.float32)
+                chain = chain * e / ((np.float32(1.0) + np.exp(-e, dtype=np.float32))
+                                     * sp)
+                p = np.log(sp, dtype=np.float32)
+        return float(p), float(chain)
+
     def clamped_log_std(self):
-        """Host value of the (clamped) scalar log-std: one tiny D2H copy."""
-        s = float(self.net.params[0].item())
-        if self._min_log_std is not None:
-            s = max(s, self._min_log_std)
-        if self._max_log_std is not None:
-            s = min(s, self._max_log_std)
-        return s
+        """Host value of the policy's log std (clamped parameter through the std
+        parameterisation): one tiny D2H copy."""
+        return self.log_std_of(float(self.net.params[0].item()))[0]
 
     # -- torch.nn.Module-like surface -----------------------------------------
     def _std_key(self):
@@ -327,6 +347,7 @@ class GaussianMLPPolicy(_GaussianMLP):
                     hidden_w_init, hidden_b_init, output_w_init, output_b_init,
                     learn_std, init_std, min_std, max_std, device,
                     hidden_act=act)
+        self._std_softplus = std_parameterization == 'softplus'
         # derived from torch's seed without consuming the global stream, so the
         # objects constructed after this one still match the reference's init
         self._sample_seed = int(torch.initial_seed() & 0x7FFFFFFF)

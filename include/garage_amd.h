@@ -30,6 +30,14 @@ extern "C" {
 typedef void* ga_stream_t; /* hipStream_t */
 
 int ga_abi_version(void); /* 3 */
+/* Wherever a policy's scalar std parameter crosses this interface it comes as
+ * (log_std pointer, has_min, min_log_std, has_max, max_log_std) and goes through
+ * GaussianMLPBaseModule.forward's transformation
+ * (torch/modules/gaussian_mlp_module.py:165-181): clamp to [min, max], then
+ * std = exp(p) or, when bit 1 of `has_min` is set (std_parameterization =
+ * 'softplus'), std = log(1 + exp(exp(p))).  Bit 0 of `has_min` = the lower clamp is
+ * present.  The gradient written for the parameter includes the transformation's
+ * slope (0 through an active clamp). */
 const char* ga_last_error(void);
 
 /* ---- returns + GAE(lambda) -------------------------------------------------

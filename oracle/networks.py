@@ -88,6 +88,20 @@ def hidden_nonlinearity(policy=torch.tanh, value=torch.tanh):
         _HIDDEN.pop()
 
 
+# ``std_parameterization`` of the policy likewise ('exp' or 'softplus',
+# gaussian_mlp_module.py:178-181)
+_STD_PARAM = ['exp']
+
+
+@contextlib.contextmanager
+def std_parameterization(kind):
+    _STD_PARAM.append(kind)
+    try:
+        yield
+    finally:
+        _STD_PARAM.pop()
+
+
 def mlp_mean(params, prefix, x):
     """MLP trunk (tanh unless ``hidden_nonlinearity`` says otherwise) + linear head."""
     act = _HIDDEN[-1].get(prefix, torch.tanh)
@@ -115,7 +129,11 @@ def gaussian_dist(params, prefix, x):
         log_std = log_std.clamp(
             min=params[lo].item() if lo in params else None,
             max=params[hi].item() if hi in params else None)
-    return Independent(Normal(mean, log_std.exp()), 1)
+    if _STD_PARAM[-1] == 'softplus' and prefix == POLICY_PREFIX:
+        std = log_std.exp().exp().add(1.).log()  # gaussian_mlp_module.py:181
+    else:
+        std = log_std.exp()
+    return Independent(Normal(mean, std), 1)
 
 
 def policy_forward(params, obs):

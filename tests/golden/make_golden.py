@@ -629,6 +629,12 @@ def gen_policy_options():
         dict(tag='linear', pol=dict(hidden_nonlinearity=None),
              vf=dict(hidden_nonlinearity=None)),
         dict(tag='relu_policy_tanh_vf', pol=dict(hidden_nonlinearity=torch.nn.ReLU)),
+        # std = log(1 + exp(exp(p))) (gaussian_mlp_module.py:180-181), free and
+        # with an active upper clamp on p
+        dict(tag='softplus', pol=dict(std_parameterization='softplus',
+                                      init_std=0.5)),
+        dict(tag='softplus_max_clamp', pol=dict(std_parameterization='softplus',
+                                                max_std=0.8, init_std=1.0)),
     ]
     out = {}
     for case in cases:
@@ -642,13 +648,15 @@ def gen_policy_options():
         rng = np.random.RandomState(17)
         pol = GaussianMLPPolicy(spec, hidden_sizes=hs, **case['pol'])
         vf = GaussianMLPValueFunction(spec, hidden_sizes=hs, **case.get('vf', {}))
-        if 'vf' in case or 'hidden_nonlinearity' in case['pol']:
+        if ('vf' in case or 'hidden_nonlinearity' in case['pol']
+                or 'std_parameterization' in case['pol']):
             # forward outputs of the freshly built networks on fixed inputs
             x = torch.from_numpy(
                 np.random.RandomState(3).randn(6, O).astype(np.float32))
             with torch.no_grad():
                 out[tag + '_fwd_obs'] = x.numpy()
                 out[tag + '_fwd_mean'] = pol(x)[0].mean.numpy()
+                out[tag + '_fwd_log_std'] = pol(x)[1]['log_std'].numpy()
                 out[tag + '_fwd_value'] = vf(x).numpy()
         out.update(state_arrays(tag + '_pol0:', pol))
         out.update(state_arrays(tag + '_vf0:', vf))

@@ -2,6 +2,8 @@
 against goldens captured from the real reference and against the oracle."""
 from collections import OrderedDict
 
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -753,6 +755,187 @@ def test_hidden_nonlinearity_at_c3_shape_against_oracle(act):
         for k, v in mine.items():
             d = np.abs(v.numpy() - np.asarray(theirs[k]))
             assert d.max() <= 1e-4 and d.mean() <= 2e-6, (k, d.max(), d.mean())
+
+
+SOFTPLUS_CASES = {
+    'softplus': dict(std_parameterization='softplus', init_std=0.5),
+    'softplus_max_clamp': dict(std_parameterization='softplus', max_std=0.8,
+                               init_std=1.0),
+}
+
+
+@pytest.mark.parametrize('fused', [True, False])
+@pytest.mark.parametrize('tag', sorted(SOFTPLUS_CASES))
+def test_softplus_std_matches_real_reference(golden, tag, fused):
+    """``std_parameterization='softplus'`` (``gaussian_mlp_module.py:178-181``:
+    std = log(1 + exp(exp(p))), clamp on ``p`` first): the stored log-std and two
+    real PPO iterations, through the one-launch small-minibatch step (default for
+    these shapes) and through the per-layer loss kernels."""
+    from garage_amd import _lib
+    from garage_amd.algos import PPO
+    from garage_amd.optimizers import OptimizerWrapper
+    from garage_amd.policies import GaussianMLPPolicy, GaussianMLPValueFunction
+    lib = _lib.load()
+    g = golden('policy_options')
+    O, A, P, E, mb = [int(v) for v in g[tag + '_cfg']]
+    spec = _spec(O, A, P)
+    pol = GaussianMLPPolicy(spec, hidden_sizes=(8, 8), **SOFTPLUS_CASES[tag])
+    vf = GaussianMLPValueFunction(spec, hidden_sizes=(8, 8))
+    pol.load_state_dict(_sd(g, tag + '_pol0:'))
+    vf.load_state_dict(_sd(g, tag + '_vf0:'))
+    x = torch.from_numpy(g[tag + '_fwd_obs'])
+    dist, info = pol.forward(x)
+    assert np.allclose(dist.mean.cpu().numpy(), g[tag + '_fwd_mean'], atol=2e-6)
+    assert np.allclose(info['log_std'].cpu().numpy(), g[tag + '_fwd_log_std'],
+                       atol=2e-6)
+    algo = PPO(env_spec=spec, policy=pol, value_function=vf, sampler=None,
+               policy_optimizer=OptimizerWrapper(
+                   (torch.optim.Adam, dict(lr=2.5e-3)), pol,
+                   max_optimization_epochs=E, minibatch_size=mb),
+               vf_optimizer=OptimizerWrapper(
+                   (torch.optim.Adam, dict(lr=2.5e-3)), vf,
+                   max_optimization_epochs=E, minibatch_size=mb))
+    try:
+        lib.ga_set_small_step(1 if fused else 0)
+        lib.ga_set_fused_train(1 if fused else 0)
+        for it in range(2):
+            pre = '%s_it%d_' % (tag, it)
+            batch = _host_batch(spec, g, pre, O)
+            np.random.seed(int(g[pre + 'np_seed']))
+            algo._train_once(it, batch)
+            for mine, theirs in LOG_KEYS.items():
+                want = float(g[pre + 'log:' + theirs])
+                assert np.isclose(algo.last_tabular[mine], want, atol=1e-5,
+                                  rtol=1e-5), (mine, it, algo.last_tabular[mine],
+                                               want)
+            for k, v in pol.state_dict().items():
+                assert np.allclose(v.numpy(), g[pre + 'pol:' + k], atol=2e-6), k
+            for k, v in vf.state_dict().items():
+                assert np.allclose(v.numpy(), g[pre + 'vf:' + k], atol=2e-6), k
+    finally:
+        lib.ga_set_small_step(1)
+        lib.ga_set_fused_train(1)
+
+
+@pytest.mark.parametrize('path', ['small_step', 'narrow_step', 'fused_train',
+                                  'per_layer'])
+def test_softplus_std_through_every_update_path_against_oracle(path):
+    """The softplus std (and its chain factor on the log-std gradient) in each
+    kernel family that evaluates the Gaussian loss: the one-launch small-minibatch
+    step, the one-launch narrow step, the fused GEMM-epilogue kernels, the
+    per-layer loss kernels -- one PPO iteration with an entropy term against the
+    oracle."""
+    from garage_amd import _lib
+    from garage_amd._dtypes import EpisodeBatch, StepType
+    from garage_amd.algos import PPO
+    from garage_amd.optimizers import OptimizerWrapper
+    from garage_amd.policies import GaussianMLPPolicy, GaussianMLPValueFunction
+    from oracle import batch as ob
+    from oracle import networks as nets
+    from oracle.ppo import OraclePPO
+    lib = _lib.load()
+    hidden, mb = {'small_step': ((64, 64), 50), 'narrow_step': ((64, 64), 300),
+                  'fused_train': ((128, 128), 500),
+                  'per_layer': ((128, 128), 500)}[path]
+    O, A, P = 11, 3, 24
+    spec = _spec(O, A, P)
+    torch.manual_seed(12)
+    rng = np.random.RandomState(12)
+    pol = GaussianMLPPolicy(spec, hidden_sizes=hidden, init_std=0.6,
+                            std_parameterization='softplus')
+    vf = GaussianMLPValueFunction(spec, hidden_sizes=hidden)
+    lens = rng.randint(4, P + 1, size=70)
+    lens[::5] = P
+    S = int(lens.sum())
+    st = []
+    for L in lens:
+        t = [1] * L
+        t[0] = 0
+        t[-1] = 3 if L == P else 2
+        st += t
+    obs = rng.randn(S, O).astype(np.float32)
+    acts = rng.randn(S, A).astype(np.float32)
+    rew = rng.randn(S)
+    E = 2
+    kw = dict(entropy_method='regularized', policy_ent_coeff=0.02)
+    with nets.std_parameterization('softplus'):
+        oracle = OraclePPO(OrderedDict(pol.state_dict()),
+                           OrderedDict(vf.state_dict()), max_episode_length=P,
+                           max_optimization_epochs=E, minibatch_size=mb,
+                           policy_lr=1e-3, vf_lr=1e-3, **kw)
+        b = ob.OracleEpisodeBatch(
+            observations=obs, last_observations=np.zeros((len(lens), O),
+                                                         np.float32),
+            actions=acts, rewards=rew, step_types=np.asarray(st), lengths=lens,
+            max_episode_length=P)
+        np.random.seed(4)
+        want = oracle.train_once(b)
+        wpol, wvf = oracle.state()
+    algo = PPO(env_spec=spec, policy=pol, value_function=vf, sampler=None,
+               policy_optimizer=OptimizerWrapper(
+                   (torch.optim.Adam, dict(lr=1e-3)), pol,
+                   max_optimization_epochs=E, minibatch_size=mb),
+               vf_optimizer=OptimizerWrapper(
+                   (torch.optim.Adam, dict(lr=1e-3)), vf,
+                   max_optimization_epochs=E, minibatch_size=mb), **kw)
+    batch = EpisodeBatch(env_spec=spec, episode_infos={}, observations=obs,
+                         last_observations=np.zeros((len(lens), O), np.float32),
+                         actions=acts, rewards=rew, env_infos={}, agent_infos={},
+                         step_types=np.asarray([StepType(s) for s in st],
+                                               dtype=object),
+                         lengths=lens.astype('l'))
+    launches0 = lib.ga_small_step_launches()
+    try:
+        if path == 'per_layer':
+            lib.ga_set_fused_train(0)
+            lib.ga_set_small_step(0)
+        np.random.seed(4)
+        algo._train_once(0, batch)
+    finally:
+        lib.ga_set_fused_train(1)
+        lib.ga_set_small_step(1)
+    assert (lib.ga_small_step_launches() > launches0) == (path == 'small_step')
+    for k in ('policy/LossBefore', 'policy/LossAfter', 'policy/KL',
+              'policy/Entropy', 'vf/LossBefore', 'vf/LossAfter'):
+        assert np.isclose(algo.last_tabular[k], want[k], atol=2e-5,
+                          rtol=2e-4), (k, algo.last_tabular[k], want[k])
+    for mine, theirs in ((pol.state_dict(), wpol), (vf.state_dict(), wvf)):
+        for k, v in mine.items():
+            d = np.abs(v.numpy() - np.asarray(theirs[k]))
+            assert d.max() <= 1e-4 and d.mean() <= 2e-6, (k, d.max(), d.mean())
+    # the log-std parameter moved, and by what the oracle says
+    k = '_module._init_std'
+    assert abs(float(pol.state_dict()[k]) - math.log(0.6)) > 1e-4
+    assert np.isclose(float(pol.state_dict()[k]), float(np.asarray(wpol[k])),
+                      atol=2e-6)
+
+
+@pytest.mark.parametrize('hidden', [(32, 32), (300, )])
+def test_rollout_samples_with_the_softplus_std(hidden):
+    """Both sampling kernels (the fused rollout step for nets up to 256 wide, the
+    head kernel behind the per-layer forward otherwise) draw actions with std =
+    log(1 + exp(exp(p))): the spread of action - mean over ~7000 draws, and the
+    stored ``agent_infos['log_std']``."""
+    from garage_amd.envs import SyntheticVecEnv
+    from garage_amd.policies import GaussianMLPPolicy
+    from garage_amd.sampler import GpuVecSampler, GpuVecWorker
+    n, O, A, P = 96, 5, 3, 24
+    torch.manual_seed(3)
+    env = SyntheticVecEnv(n, O, A, P, seed=9)
+    pol = GaussianMLPPolicy(env.spec, hidden_sizes=hidden, init_std=0.4,
+                            std_parameterization='softplus')
+    want_std = math.log1p(math.exp(0.4))  # exp(p) = 0.4
+    sampler = GpuVecSampler(agents=pol, envs=env, max_episode_length=P,
+                            n_workers=1, worker_class=GpuVecWorker,
+                            worker_args=dict(n_envs=n))
+    eps = sampler.obtain_samples(0, n * P, agent_update=None)
+    resid = np.asarray(eps.actions) - np.asarray(eps.agent_infos['mean'])
+    assert resid.size >= 6000
+    assert abs(resid.std() / want_std - 1.0) < 0.05, (resid.std(), want_std)
+    assert np.allclose(np.asarray(eps.agent_infos['log_std']),
+                       math.log(want_std), atol=1e-6)
+    # (with the exp parameterisation the same parameter would give std 0.4)
+    assert abs(resid.std() / 0.4 - 1.0) > 0.5
 
 
 def test_rollout_with_relu_policy_stores_the_relu_means():
