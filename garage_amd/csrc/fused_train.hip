@@ -15,11 +15,18 @@
 //       few KB of partial sums per workgroup.  H itself is never stored.
 //       Replaces: head GEMM, loss kernel, loss finalize, head weight-gradient +
 //       data-gradient streaming kernel (4 launches, 2 passes over [M x width]).
+//       L1 instantiation (two hidden layers, <= 32 inputs): the layer below is the
+//       network's first layer and its output -- this GEMM's A operand -- is
+//       produced in the kernel, 32 columns at a time, on v_mfma_f32_16x16x4_f32
+//       (and written once for the backward pass); the B fragments then come
+//       straight from L2 and the k-loop has one barrier per step.  Replaces the
+//       first-layer streaming launch and a read of [M x width].
 //
 //   dgrad_wgrad0_kernel    data gradient into the FIRST hidden layer
 //       dZ1 = (dZ2 W2) (1 - H1^2)  on 64-row tiles spanning H1's whole width, then
 //       this workgroup's share of the first layer's weight and bias gradient
-//       dW1 = dZ1^T X,  db1 = 1^T dZ1  (X: <= 32 observation columns, gathered).
+//       dW1 = dZ1^T X (a [width x 64] x [64 x 32] MFMA product per tile),
+//       db1 = 1^T dZ1  (X: <= 32 observation columns, gathered).
 //       dZ1 is never stored.  Replaces the first-layer weight-gradient streaming
 //       kernel and one [M x width] store + load.
 //
