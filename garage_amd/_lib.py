@@ -17,7 +17,7 @@ class MlpDesc(C.Structure):
     """``ga_mlp_desc``."""
     _fields_ = [('n_layers', c_i32), ('dims', c_i32 * 9), ('w_off', c_i64 * 8),
                 ('b_off', c_i64 * 8), ('act_off', c_i64 * 8),
-                ('hidden_act', c_i32)]
+                ('hidden_act', c_i32), ('output_act', c_i32)]
 
 
 class SynthEnv(C.Structure):
@@ -93,6 +93,8 @@ SIGNATURES = {
     'ga_gae_scan_f32': (c_int, [ptr, ptr, ptr, ptr, ptr, c_i64, c_i64, c_i64,
                                 c_i64, c_int, c_int, c_f64, c_f64, c_f32,
                                 c_f32, ptr, ptr, ptr]),
+    'ga_act_slope_mul_f32': (c_int, [ptr, c_i64, ptr, c_i64, c_i64, c_int, c_int,
+                                     ptr]),
     'ga_set_gae_fixed_fast_path': (c_int, [c_int]),
     'ga_set_gae_rows_steps_per_lane': (c_int, [c_int]),
     'ga_mlp_forward_f32': (c_int, [C.POINTER(MlpDesc), ptr, ptr, c_i64, ptr,

@@ -388,6 +388,7 @@ struct ga_mlp_desc {
   int64_t act_off[8];  // offset (floats) of layer l's output in the activation
                        // workspace, row stride round4(dims[l + 1]) (hidden layers)
   int32_t hidden_act;  // 0 tanh, 1 relu, 2 none
+  int32_t output_act;  // 0 none, 1 tanh, 2 relu (forward codes)
 };
 
 // The whole-network forward in one launch (policy_fused.hip) for nets whose
@@ -459,6 +460,8 @@ static int check_desc(const ga_mlp_desc* d, const char* who) {
                "%s: offsets of layer %d not 16-B aligned", who, l);
   GA_REQUIRE(d->hidden_act >= 0 && d->hidden_act <= 2, "%s: hidden_act %d not in 0..2",
              who, d->hidden_act);
+  GA_REQUIRE(d->output_act >= 0 && d->output_act <= 2, "%s: output_act %d not in 0..2",
+             who, d->output_act);
   return GA_OK;
 }
 
@@ -479,7 +482,8 @@ extern "C" int ga_mlp_forward_f32(const ga_mlp_desc* d, const float* params,
   GA_REQUIRE(ga_aligned16(params) && ga_aligned16(X) && (!acts || ga_aligned16(acts)),
              "ga_mlp_forward_f32: pointers must be 16-B aligned");
   if (M == 0) return GA_OK;
-  if (out && g_fused_forward && d->hidden_act == 0 && ga_policy_step_fused_supported(d))
+  if (out && g_fused_forward && d->hidden_act == 0 && d->output_act == 0 &&
+      ga_policy_step_fused_supported(d))
     return ga_mlp_forward_fused_f32(d, params, X, ldx, row_idx, M, acts, out, ldo,
                                     stream);
   const int L = d->n_layers;
@@ -501,7 +505,7 @@ extern "C" int ga_mlp_forward_f32(const ga_mlp_desc* d, const float* params,
     p.M = (int)M; p.N = d->dims[l + 1]; p.K = d->dims[l];
     p.epi = EPI_BIAS_ACT;
     p.bias = params + d->b_off[l];
-    p.act = last ? 0 : act_forward_code(d->hidden_act);
+    p.act = last ? d->output_act : act_forward_code(d->hidden_act);
     p.k_per_split = (int)ga_ceil_div(p.K, BK) * BK;
     // (the streaming kernels know tanh and the identity)
     if (g_skinny && p.act <= 1 && p.K <= 32 && p.N > 32) {
@@ -510,7 +514,7 @@ extern "C" int ga_mlp_forward_f32(const ga_mlp_desc* d, const float* params,
       if (rc < 0) return rc;
       if (rc == 0) continue;
     }
-    if (out && l == L - 2 &&
+    if (out && l == L - 2 && d->output_act == 0 &&
         (g_fuse_head_forward == 2 || (g_fuse_head_forward == 1 && p.N <= 128))) {
       p.head_W = params + d->w_off[L - 1];
       p.head_ldw = round4(d->dims[L - 1]);
@@ -751,6 +755,33 @@ extern "C" int ga_mlp_jvp_f32(const ga_mlp_desc* d, const float* params,
       if (rc) return rc;
     }
   }
+  return GA_OK;
+}
+
+namespace {
+__global__ __launch_bounds__(256) void act_slope_mul_kernel(float* dout, int64_t ldd,
+                                                            const float* out, int64_t ldo,
+                                                            int64_t M, int N, int act) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= M * N) return;
+  const int64_t i = e / N;
+  const int j = (int)(e % N);
+  const float o = out[i * ldo + j];
+  // (forward codes: 1 tanh, 2 relu)
+  dout[i * ldd + j] *= act == 1 ? 1.f - o * o : (act == 2 ? (o > 0.f ? 1.f : 0.f) : 1.f);
+}
+}  // namespace
+
+extern "C" int ga_act_slope_mul_f32(float* dout, int64_t ldd, const float* out,
+                                    int64_t ldo, int64_t M, int N, int act,
+                                    hipStream_t stream) {
+  GA_REQUIRE(dout && out && M >= 0 && N >= 1 && ldd >= N && ldo >= N && act >= 0 &&
+                 act <= 2,
+             "ga_act_slope_mul_f32: bad arguments");
+  if (M == 0 || act == 0) return GA_OK;
+  hipLaunchKernelGGL(act_slope_mul_kernel, dim3((unsigned)ga_ceil_div(M * N, 256)),
+                     dim3(256), 0, stream, dout, ldd, out, ldo, M, N, act);
+  GA_CHECK_LAUNCH("act_slope_mul");
   return GA_OK;
 }
 

@@ -123,7 +123,8 @@ FusedPlan fused_plan(const ga_mlp_desc* d, int64_t M) {
   FusedPlan f;
   const int L = d->n_layers;
   if (L < 2 || L > 8 || M < 1) return f;
-  if (d->hidden_act != 0) return f;  // the fused kernels implement tanh hidden layers
+  // the fused kernels implement tanh hidden layers and a linear output layer
+  if (d->hidden_act != 0 || d->output_act != 0) return f;
   if (g_narrow_step && ga_narrow_step_supported(L, d->dims)) {
     f.ok = f.narrow = true;
     f.tiles = ga_fused_tiles(M);
@@ -414,7 +415,7 @@ int run_minibatch(const ga_update_args* a, int64_t k, ga_stream_t stream,
   // they hold min(S, mb) x 2H floats each, enough from 32 rows up)
   if (g_small_step && !g_fuse_head && !a->comm && a->phase != 1 && a->kind >= 0 && a->kind <= 2 &&
       (a->algo == 0 || a->algo == 1) && a->acts && a->dacts &&
-      workspace_rows(a) >= 32 && a->desc->hidden_act == 0 &&
+      workspace_rows(a) >= 32 && a->desc->hidden_act == 0 && a->desc->output_act == 0 &&
       ga_small_step_supported(L, a->desc->dims, M) &&
       ga_small_step_resident(a->desc->dims[1], 2)) {
     ga_small_step_args s;
@@ -453,7 +454,7 @@ int run_minibatch(const ga_update_args* a, int64_t k, ga_stream_t stream,
   // when its shape allows: no narrow GEMM launch, no round trip of its output
   const int hid_w = L >= 2 ? a->desc->dims[L - 1] : 0;
   const bool fuse_head = g_fuse_head && L >= 2 && (a->kind == 0 || a->kind == 1) &&
-                         ga_head_loss_supported(hid_w, out_w);
+                         a->desc->output_act == 0 && ga_head_loss_supported(hid_w, out_w);
   GA_TRACE(stream, "forward k=%lld M=%lld start=%lld kind=%d", (long long)k, (long long)M,
            (long long)start, a->kind);
   int rc = ga_mlp_forward_f32(a->desc, a->params, a->X, a->ldx, idx, M, a->acts,
@@ -493,6 +494,12 @@ int run_minibatch(const ga_update_args* a, int64_t k, ga_stream_t stream,
                                   a->workspace, stream);
   }
   if (rc) return rc;
+  if (a->desc->output_act) {
+    // output_nonlinearity: d(loss)/d(output) -> d(loss)/d(pre-activation)
+    rc = ga_act_slope_mul_f32(a->dout, a->ldo, a->out, a->ldo, M, out_w,
+                              a->desc->output_act, stream);
+    if (rc) return rc;
+  }
   GA_TRACE(stream, "backward splits=%lld", (long long)splits);
   rc = ga_mlp_backward_f32(a->desc, a->params, a->X, a->ldx, idx, M, a->acts,
                            a->dout, a->ldo, a->dacts, a->slabs, a->n_flat, splits,

@@ -51,9 +51,13 @@ class FlatMLP:
 
     # ga_mlp_desc.hidden_act
     HIDDEN_ACTS = {'tanh': 0, 'relu': 1, 'none': 2}
+    # ga_mlp_desc.output_act
+    OUTPUT_ACTS = {'none': 0, 'tanh': 1, 'relu': 2}
 
-    def __init__(self, in_dim, out_dim, hidden_sizes, device, hidden_act='tanh'):
+    def __init__(self, in_dim, out_dim, hidden_sizes, device, hidden_act='tanh',
+                 output_act='none'):
         self.hidden_act = hidden_act
+        self.output_act = output_act
         self.in_dim, self.out_dim = int(in_dim), int(out_dim)
         self.hidden_sizes = tuple(int(h) for h in hidden_sizes)
         dims = (self.in_dim, ) + self.hidden_sizes + (self.out_dim, )
@@ -82,6 +86,7 @@ class FlatMLP:
         self.adam_steps = 0
         d = _lib.MlpDesc()
         d.hidden_act = self.HIDDEN_ACTS[hidden_act]
+        d.output_act = self.OUTPUT_ACTS[output_act]
         d.n_layers = len(dims) - 1
         for i, v in enumerate(dims):
             d.dims[i] = v
@@ -180,8 +185,9 @@ class FlatMLP:
     def head_fusable(self):
         """Can the last layer be computed inside the loss kernel
         (``ga_head_*_loss_f32``)?"""
-        return (len(self.dims) >= 3 and bool(_lib.load().ga_head_loss_supported(
-            int(self.dims[-2]), int(self.dims[-1]))))
+        return (len(self.dims) >= 3 and self.output_act == 'none'
+                and bool(_lib.load().ga_head_loss_supported(
+                    int(self.dims[-2]), int(self.dims[-1]))))
 
     def forward_hidden(self, X, M, row_idx=None):
         """Hidden layers only; returns ``(H, ldh)`` of the last hidden layer,
@@ -197,9 +203,17 @@ class FlatMLP:
         H = self._acts[off:off + M * ldh].view(M, ldh)
         return H, self.params[self.w_off[L - 1]:], self.params[self.b_off[L - 1]:]
 
-    def backward(self, X, M, dout, row_idx=None):
-        """Slabs <- gradient of everything but the log-std slot."""
+    def backward(self, X, M, dout, row_idx=None, out=None):
+        """Slabs <- gradient of everything but the log-std slot.  ``dout`` is the
+        gradient with respect to the network's OUTPUT (``out``: what the last
+        ``forward`` wrote unless given); an ``output_nonlinearity`` scales it in
+        place by its slope first."""
         ldx = X.stride(0)
+        if self.output_act != 'none':
+            out = self.out_view(M) if out is None else out
+            call('ga_act_slope_mul_f32', dptr(dout), dout.stride(0), dptr(out),
+                 out.stride(0), M, self.out_dim, self.OUTPUT_ACTS[self.output_act],
+                 stream_ptr())
         splits = min(self._splits,
                      int(_lib.load().ga_mlp_backward_splits(
                          C.byref(self._desc), M)))
@@ -223,6 +237,11 @@ class FlatMLP:
              dptr(tangent), dptr(X), X.stride(0), dptr(row_idx), M,
              dptr(self._acts), dptr(self._dacts), dptr(tout), tout.stride(0),
              stream_ptr())
+        if self.output_act != 'none':  # tangent of f(z) = f'(z) tz
+            out = self.out_view(M)
+            call('ga_act_slope_mul_f32', dptr(tout), tout.stride(0), dptr(out),
+                 out.stride(0), M, self.out_dim, self.OUTPUT_ACTS[self.output_act],
+                 stream_ptr())
         return tout
 
     def reduce_grads(self, scale=1.0):

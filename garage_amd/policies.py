@@ -45,9 +45,8 @@ def _hidden_act(hidden_nonlinearity):
 
 def _check_supported(hidden_nonlinearity, output_nonlinearity,
                      std_parameterization, layer_normalization):
-    act = _hidden_act(hidden_nonlinearity)
-    if output_nonlinearity is not None:
-        raise NotImplementedError('output_nonlinearity must be None')
+    """-> (hidden activation, output activation) names for FlatMLP."""
+    act = (_hidden_act(hidden_nonlinearity), _hidden_act(output_nonlinearity))
     if std_parameterization not in ('exp', 'softplus'):
         raise NotImplementedError  # gaussian_mlp_module.py:120-121
     if layer_normalization:
@@ -87,8 +86,11 @@ class _GaussianMLP:
                hidden_b_init, output_w_init, output_b_init, learn_std,
                init_std, min_std, max_std, device, hidden_act='tanh'):
         self.device = device or require_gpu()
+        output_act = 'none'
+        if isinstance(hidden_act, tuple):
+            hidden_act, output_act = hidden_act
         self.net = FlatMLP(in_dim, out_dim, hidden_sizes, self.device,
-                           hidden_act=hidden_act)
+                           hidden_act=hidden_act, output_act=output_act)
         _reference_init(self.net, hidden_w_init, hidden_b_init, output_w_init,
                         output_b_init)
         self._learn_std = bool(learn_std)
@@ -212,7 +214,8 @@ class _GaussianMLP:
         if device.index is not None and device != self.device:
             net = FlatMLP(self.net.in_dim, self.net.out_dim,
                           self.net.hidden_sizes, device,
-                          hidden_act=self.net.hidden_act)
+                          hidden_act=self.net.hidden_act,
+                          output_act=self.net.output_act)
             for k in ('params', 'grads', 'exp_avg', 'exp_avg_sq'):
                 getattr(net, k).copy_(getattr(self.net, k))
             net.adam_steps = self.net.adam_steps
@@ -293,6 +296,7 @@ class _GaussianMLP:
                  if k not in ('net', 'device')}
         state['_hidden_sizes'] = self.net.hidden_sizes
         state['_hidden_act'] = self.net.hidden_act
+        state['_output_act'] = self.net.output_act
         state['_dims'] = (self.net.in_dim, self.net.out_dim)
         for k in ('params', 'exp_avg', 'exp_avg_sq'):
             state['_net_' + k] = getattr(self.net, k).cpu().numpy()
@@ -302,13 +306,15 @@ class _GaussianMLP:
     def __setstate__(self, state):
         hidden = state.pop('_hidden_sizes')
         act = state.pop('_hidden_act', 'tanh')
+        out_act = state.pop('_output_act', 'none')
         in_dim, out_dim = state.pop('_dims')
         bufs = {k: state.pop('_net_' + k)
                 for k in ('params', 'exp_avg', 'exp_avg_sq')}
         steps = state.pop('_net_steps')
         self.__dict__.update(state)
         self.device = require_gpu()
-        self.net = FlatMLP(in_dim, out_dim, hidden, self.device, hidden_act=act)
+        self.net = FlatMLP(in_dim, out_dim, hidden, self.device, hidden_act=act,
+                           output_act=out_act)
         for k, v in bufs.items():
             getattr(self.net, k).copy_(torch.from_numpy(v))
         self.net.adam_steps = steps

@@ -89,7 +89,19 @@ typedef struct {
                          GaussianMLP* default; what a zeroed descriptor means),
                          1 = relu, 2 = none.  The fused / one-launch kernels
                          implement tanh; other networks take the per-layer GEMMs. */
+  int32_t output_act; /* output_nonlinearity of the same module applied to the last
+                         layer (the Gaussian mean / the value): 0 = none (default),
+                         1 = tanh, 2 = relu.  Per-layer kernels only; the caller
+                         scales the loss's d(output) by the slope before the backward
+                         pass (ga_act_slope_mul_f32). */
 } ga_mlp_desc;
+
+/* dout[i, j] *= slope of the activation `act` (1 tanh, 2 relu) at its OUTPUT
+ * out[i, j], j < N: turns the loss's gradient with respect to an output layer
+ * with an output_nonlinearity into the gradient with respect to its pre-activation
+ * (what ga_mlp_backward_f32 takes). */
+int ga_act_slope_mul_f32(float* dout, int64_t ldd, const float* out, int64_t ldo,
+                         int64_t M, int N, int act, ga_stream_t stream);
 
 /* out[M, ldo] = MLP(X[row_idx[i]] or X[i]); acts keeps the hidden outputs. */
 int ga_mlp_forward_f32(const ga_mlp_desc* d, const float* params, const float* X,

@@ -77,6 +77,7 @@ def n_hidden(params, prefix):
 # reference modules, not part of their state_dict: the parameter dicts cannot carry
 # it, so it is set around a computation, per network (None = linear).
 _HIDDEN = [{POLICY_PREFIX: torch.tanh, VALUE_PREFIX: torch.tanh}]
+_OUTPUT = [{POLICY_PREFIX: None, VALUE_PREFIX: None}]
 
 
 @contextlib.contextmanager
@@ -86,6 +87,16 @@ def hidden_nonlinearity(policy=torch.tanh, value=torch.tanh):
         yield
     finally:
         _HIDDEN.pop()
+
+
+@contextlib.contextmanager
+def output_nonlinearity(policy=None, value=None):
+    """``output_nonlinearity`` of the mean / value MLP (mlp_module.py:52-53)."""
+    _OUTPUT.append({POLICY_PREFIX: policy, VALUE_PREFIX: value})
+    try:
+        yield
+    finally:
+        _OUTPUT.pop()
 
 
 # ``std_parameterization`` of the policy likewise ('exp' or 'softplus',
@@ -112,8 +123,9 @@ def mlp_mean(params, prefix, x):
         if act is not None:
             x = act(x)
     base = prefix + '_mean_module._output_layers.0.linear.'
-    return torch.nn.functional.linear(x, params[base + 'weight'],
-                                      params[base + 'bias'])
+    x = torch.nn.functional.linear(x, params[base + 'weight'], params[base + 'bias'])
+    out_act = _OUTPUT[-1].get(prefix)
+    return x if out_act is None else out_act(x)
 
 
 def gaussian_dist(params, prefix, x):

@@ -629,6 +629,12 @@ def gen_policy_options():
         dict(tag='linear', pol=dict(hidden_nonlinearity=None),
              vf=dict(hidden_nonlinearity=None)),
         dict(tag='relu_policy_tanh_vf', pol=dict(hidden_nonlinearity=torch.nn.ReLU)),
+        # output_nonlinearity of the mean / the value (mlp_module.py:52-53)
+        dict(tag='out_tanh', pol=dict(output_nonlinearity=torch.tanh)),
+        dict(tag='out_tanh_vf_relu_hidden',
+             pol=dict(output_nonlinearity=torch.tanh,
+                      hidden_nonlinearity=torch.relu),
+             vf=dict(output_nonlinearity=torch.tanh)),
         # std = log(1 + exp(exp(p))) (gaussian_mlp_module.py:180-181), free and
         # with an active upper clamp on p
         dict(tag='softplus', pol=dict(std_parameterization='softplus',
@@ -649,7 +655,8 @@ def gen_policy_options():
         pol = GaussianMLPPolicy(spec, hidden_sizes=hs, **case['pol'])
         vf = GaussianMLPValueFunction(spec, hidden_sizes=hs, **case.get('vf', {}))
         if ('vf' in case or 'hidden_nonlinearity' in case['pol']
-                or 'std_parameterization' in case['pol']):
+                or 'std_parameterization' in case['pol']
+                or 'output_nonlinearity' in case['pol']):
             # forward outputs of the freshly built networks on fixed inputs
             x = torch.from_numpy(
                 np.random.RandomState(3).randn(6, O).astype(np.float32))

@@ -154,6 +154,11 @@ int ga_small_step(const ga_small_step_args* a, void*) {
   logf("small_step M=%d step=%lld", a->M, (long long)a->step);
   return 0;
 }
+int ga_act_slope_mul_f32(float*, int64_t, const float*, int64_t, int64_t M, int N, int act,
+                         void*) {
+  logf("act_slope_mul M=%lld N=%d act=%d", (long long)M, N, act);
+  return 0;
+}
 int ga_fused_width_ok(int w) { return w == 64 || w == 128 || w == 256; }
 int ga_fused_first_layer_ok(int in_w, int K) {
   return in_w >= 1 && in_w <= 32 && K % 32 == 0 && K * ((in_w + 3) & ~3) <= 5120;

@@ -732,3 +732,51 @@ def test_golden_softplus_std(golden, tag):
                 assert np.allclose(v, g[pre + 'pol:' + k], atol=1e-6), k
             for k, v in vf.items():
                 assert np.allclose(v, g[pre + 'vf:' + k], atol=1e-6), k
+
+
+OUTPUT_CASES = {
+    # tag: (policy hidden, policy output, value hidden, value output)
+    'out_tanh': (torch.tanh, torch.tanh, torch.tanh, None),
+    'out_tanh_vf_relu_hidden': (torch.relu, torch.tanh, torch.tanh, torch.tanh),
+}
+
+
+@pytest.mark.parametrize('tag', sorted(OUTPUT_CASES))
+def test_golden_output_nonlinearity(golden, tag):
+    """``output_nonlinearity`` on the Gaussian mean / the value
+    (``mlp_module.py:52-53``): forward outputs and two real PPO iterations."""
+    from oracle import networks as nets
+    g = golden('policy_options')
+    O, A, P, E, mb = [int(v) for v in g[tag + '_cfg']]
+    ph, po, vh, vo = OUTPUT_CASES[tag]
+    with nets.hidden_nonlinearity(policy=ph, value=vh), \
+            nets.output_nonlinearity(policy=po, value=vo):
+        pol0, vf0 = _params(g, tag + '_pol0:'), _params(g, tag + '_vf0:')
+        x = torch.from_numpy(g[tag + '_fwd_obs'])
+        with torch.no_grad():
+            assert np.allclose(nets.policy_forward(pol0, x)[0].mean.numpy(),
+                               g[tag + '_fwd_mean'], atol=1e-6)
+            assert np.allclose(nets.value_forward(vf0, x).numpy(),
+                               g[tag + '_fwd_value'], atol=1e-6)
+        algo = OraclePPO(pol0, vf0, max_episode_length=P,
+                         max_optimization_epochs=E, minibatch_size=mb,
+                         policy_lr=2.5e-3, vf_lr=2.5e-3)
+        for it in range(2):
+            pre = '%s_it%d_' % (tag, it)
+            lens = g[pre + 'lengths']
+            b = ob.OracleEpisodeBatch(
+                observations=g[pre + 'observations'],
+                last_observations=np.zeros((len(lens), O), np.float32),
+                actions=g[pre + 'actions'], rewards=g[pre + 'rewards'],
+                step_types=g[pre + 'step_types'], lengths=lens,
+                max_episode_length=P)
+            np.random.seed(int(g[pre + 'np_seed']))
+            out = algo.train_once(b)
+            for mine, theirs in LOG_KEYS.items():
+                assert np.isclose(out[mine], float(g[pre + 'log:' + theirs]),
+                                  atol=1e-5, rtol=1e-5), (mine, it)
+            pol, vf = algo.state()
+            for k, v in pol.items():
+                assert np.allclose(v, g[pre + 'pol:' + k], atol=1e-6), k
+            for k, v in vf.items():
+                assert np.allclose(v, g[pre + 'vf:' + k], atol=1e-6), k

@@ -686,6 +686,158 @@ def test_hidden_nonlinearities_match_real_reference(golden, tag):
             assert np.allclose(v.numpy(), g[pre + 'vf:' + k], atol=2e-6), k
 
 
+OUTPUT_CASES = {
+    # tag: (policy kwargs, value-function kwargs)
+    'out_tanh': (dict(output_nonlinearity=torch.tanh), dict()),
+    'out_tanh_vf_relu_hidden': (dict(output_nonlinearity=torch.tanh,
+                                     hidden_nonlinearity=torch.relu),
+                                dict(output_nonlinearity=torch.tanh)),
+}
+
+
+@pytest.mark.parametrize('tag', sorted(OUTPUT_CASES))
+def test_output_nonlinearity_matches_real_reference(golden, tag):
+    """``output_nonlinearity`` on the Gaussian mean / the value
+    (``torch/modules/mlp_module.py:52-53``): forward outputs of the real networks
+    and two real PPO iterations (tests/golden/policy_options.npz); the loss's
+    gradient is scaled by the slope at the output before the backward pass."""
+    from garage_amd.algos import PPO
+    from garage_amd.optimizers import OptimizerWrapper
+    from garage_amd.policies import GaussianMLPPolicy, GaussianMLPValueFunction
+    g = golden('policy_options')
+    O, A, P, E, mb = [int(v) for v in g[tag + '_cfg']]
+    spec = _spec(O, A, P)
+    pkw, vkw = OUTPUT_CASES[tag]
+    pol = GaussianMLPPolicy(spec, hidden_sizes=(8, 8), **pkw)
+    vf = GaussianMLPValueFunction(spec, hidden_sizes=(8, 8), **vkw)
+    pol.load_state_dict(_sd(g, tag + '_pol0:'))
+    vf.load_state_dict(_sd(g, tag + '_vf0:'))
+    x = torch.from_numpy(g[tag + '_fwd_obs'])
+    dist, _ = pol.forward(x)
+    assert np.allclose(dist.mean.cpu().numpy(), g[tag + '_fwd_mean'], atol=2e-6)
+    assert np.allclose(vf.forward(x).cpu().numpy().reshape(-1),
+                       g[tag + '_fwd_value'].reshape(-1), atol=2e-6)
+    algo = PPO(env_spec=spec, policy=pol, value_function=vf, sampler=None,
+               policy_optimizer=OptimizerWrapper(
+                   (torch.optim.Adam, dict(lr=2.5e-3)), pol,
+                   max_optimization_epochs=E, minibatch_size=mb),
+               vf_optimizer=OptimizerWrapper(
+                   (torch.optim.Adam, dict(lr=2.5e-3)), vf,
+                   max_optimization_epochs=E, minibatch_size=mb))
+    for it in range(2):
+        pre = '%s_it%d_' % (tag, it)
+        batch = _host_batch(spec, g, pre, O)
+        np.random.seed(int(g[pre + 'np_seed']))
+        algo._train_once(it, batch)
+        for mine, theirs in LOG_KEYS.items():
+            want = float(g[pre + 'log:' + theirs])
+            assert np.isclose(algo.last_tabular[mine], want, atol=1e-5,
+                              rtol=1e-5), (mine, it, algo.last_tabular[mine],
+                                           want)
+        for k, v in pol.state_dict().items():
+            assert np.allclose(v.numpy(), g[pre + 'pol:' + k], atol=2e-6), k
+        for k, v in vf.state_dict().items():
+            assert np.allclose(v.numpy(), g[pre + 'vf:' + k], atol=2e-6), k
+
+
+def test_output_nonlinearity_python_loop_and_trpo_against_oracle():
+    """The same option through the Python minibatch loop (``engine.backward``
+    scales d(output)) and through TRPO's Fisher-vector product (tangent and seed
+    both pass the output slope): one iteration each against the oracle."""
+    from garage_amd._dtypes import EpisodeBatch, StepType
+    from garage_amd.algos import PPO, TRPO
+    from garage_amd.optimizers import (ConjugateGradientOptimizer,
+                                       OptimizerWrapper)
+    from garage_amd.policies import GaussianMLPPolicy, GaussianMLPValueFunction
+    from oracle import batch as ob
+    from oracle import networks as nets
+    from oracle.ppo import OraclePPO
+    from oracle.trpo import OracleTRPO
+    O, A, P = 7, 3, 16
+    spec = _spec(O, A, P)
+    rng = np.random.RandomState(21)
+    lens = rng.randint(3, P + 1, size=40)
+    lens[::4] = P
+    S = int(lens.sum())
+    st = []
+    for L in lens:
+        t = [1] * L
+        t[0] = 0
+        t[-1] = 3 if L == P else 2
+        st += t
+    obs = rng.randn(S, O).astype(np.float32)
+    acts = (0.5 * rng.randn(S, A)).astype(np.float32)
+    rew = rng.randn(S)
+
+    def batches():
+        b = ob.OracleEpisodeBatch(
+            observations=obs, last_observations=np.zeros((len(lens), O),
+                                                         np.float32),
+            actions=acts, rewards=rew, step_types=np.asarray(st), lengths=lens,
+            max_episode_length=P)
+        e = EpisodeBatch(env_spec=spec, episode_infos={}, observations=obs,
+                         last_observations=np.zeros((len(lens), O), np.float32),
+                         actions=acts, rewards=rew, env_infos={}, agent_infos={},
+                         step_types=np.asarray([StepType(s) for s in st],
+                                               dtype=object),
+                         lengths=lens.astype('l'))
+        return b, e
+
+    for name in ('ppo_python_loop', 'trpo'):
+        torch.manual_seed(31)
+        pol = GaussianMLPPolicy(spec, hidden_sizes=(32, 32),
+                                output_nonlinearity=torch.tanh)
+        vf = GaussianMLPValueFunction(spec, hidden_sizes=(32, 32))
+        b, e = batches()
+        with nets.output_nonlinearity(policy=torch.tanh):
+            if name == 'trpo':
+                oracle = OracleTRPO(OrderedDict(pol.state_dict()),
+                                    OrderedDict(vf.state_dict()),
+                                    max_episode_length=P,
+                                    max_optimization_epochs=2, minibatch_size=128)
+            else:
+                oracle = OraclePPO(OrderedDict(pol.state_dict()),
+                                   OrderedDict(vf.state_dict()),
+                                   max_episode_length=P,
+                                   max_optimization_epochs=2, minibatch_size=128,
+                                   policy_lr=1e-3, vf_lr=1e-3)
+            np.random.seed(6)
+            want = oracle.train_once(b)
+            wpol, _ = oracle.state()
+        if name == 'trpo':
+            algo = TRPO(env_spec=spec, policy=pol, value_function=vf, sampler=None,
+                        policy_optimizer=OptimizerWrapper(
+                            (ConjugateGradientOptimizer,
+                             dict(max_constraint_value=0.01)), pol),
+                        vf_optimizer=OptimizerWrapper(
+                            (torch.optim.Adam, dict(lr=2.5e-4)), vf,
+                            max_optimization_epochs=2, minibatch_size=128))
+        else:
+            algo = PPO(env_spec=spec, policy=pol, value_function=vf, sampler=None,
+                       policy_optimizer=OptimizerWrapper(
+                           (torch.optim.Adam, dict(lr=1e-3)), pol,
+                           max_optimization_epochs=2, minibatch_size=128),
+                       vf_optimizer=OptimizerWrapper(
+                           (torch.optim.Adam, dict(lr=1e-3)), vf,
+                           max_optimization_epochs=2, minibatch_size=128))
+            # a subclass hooking _train_policy forces the Python minibatch loop
+            algo.__class__ = type('Hooked', (PPO, ), {
+                '_train_policy': lambda self, *a: PPO._train_policy(self, *a)})
+            assert not algo._native_update_ok()
+        np.random.seed(6)
+        algo._train_once(0, e)
+        tol = 2e-3 if name == 'trpo' else 2e-5
+        for k in ('policy/LossBefore', 'policy/LossAfter', 'policy/KL'):
+            assert np.isclose(algo.last_tabular[k], want[k], atol=tol,
+                              rtol=1e-3), (name, k, algo.last_tabular[k], want[k])
+        scale = max(1e-3, max(float(np.abs(np.asarray(v)).max())
+                              for v in wpol.values()))
+        for k, v in pol.state_dict().items():
+            assert np.allclose(v.numpy(), np.asarray(wpol[k]),
+                               atol=(2e-3 if name == 'trpo' else 1e-5) * scale), (
+                                   name, k)
+
+
 @pytest.mark.parametrize('act', ['relu', 'none'])
 def test_hidden_nonlinearity_at_c3_shape_against_oracle(act):
     """A relu / linear MLP(256,256) on a 3000-sample batch (the MFMA tile kernels,
