@@ -1,0 +1,63 @@
+"""End to end on the device path: PPO (and the relu / softplus variants, which take
+other kernels) must LEARN the synthetic environment -- its reward is
+``noise + 0.1 * sum_j clip(a_j, -1, 1) * o_j`` (rollout.hip:96-116), so a policy
+that moves each action with the sign of its observation raises the episode return
+from ~0 towards ``0.1 * T * E sum |o_j|``.  Parity tests pin every step against the
+reference; this pins that the steps compose into training
+(``tests/garage/torch/algos/test_ppo.py`` asserts improvement the same way)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+VARIANTS = {
+    # name: (hidden sizes, policy kwargs, minibatch) -> which kernels train it
+    'narrow_step': ((64, 64), dict(), 2048),
+    'fused_first_layer': ((128, 128), dict(), 2048),
+    'small_step_default_minibatch': ((64, 64), dict(), 64),
+    'per_layer_relu_softplus': ((64, 64), dict(
+        hidden_nonlinearity=torch.relu, std_parameterization='softplus',
+        init_std=0.6), 2048),
+}
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize('name', sorted(VARIANTS))
+def test_ppo_learns_the_synthetic_env(name):
+    from garage_amd.algos import PPO
+    from garage_amd.envs import SyntheticVecEnv
+    from garage_amd.optimizers import OptimizerWrapper
+    from garage_amd.policies import GaussianMLPPolicy, GaussianMLPValueFunction
+    from garage_amd.sampler import GpuVecSampler, GpuVecWorker
+    hidden, pkw, mb = VARIANTS[name]
+    n, O, A, T = 256, 8, 4, 32
+    torch.manual_seed(1)
+    np.random.seed(1)
+    env = SyntheticVecEnv(n, O, A, T, seed=2)
+    pol = GaussianMLPPolicy(env.spec, hidden_sizes=hidden, **pkw)
+    vf = GaussianMLPValueFunction(env.spec, hidden_sizes=hidden)
+    sampler = GpuVecSampler(agents=pol, envs=env, max_episode_length=T,
+                            n_workers=1, worker_class=GpuVecWorker,
+                            worker_args=dict(n_envs=n))
+    epochs = 10 if mb > 64 else 2
+    algo = PPO(env_spec=env.spec, policy=pol, value_function=vf, sampler=sampler,
+               policy_optimizer=OptimizerWrapper(
+                   (torch.optim.Adam, dict(lr=2e-3)), pol,
+                   max_optimization_epochs=epochs, minibatch_size=mb,
+                   permutation='device', seed=3),
+               vf_optimizer=OptimizerWrapper(
+                   (torch.optim.Adam, dict(lr=2e-3)), vf,
+                   max_optimization_epochs=epochs, minibatch_size=mb,
+                   permutation='device', seed=4),
+               discount=0.99, gae_lambda=0.95)
+    returns = []
+    for itr in range(25):
+        eps = sampler.obtain_samples(itr, n * T, None)
+        returns.append(float(algo._train_once(itr, eps)))
+    assert np.isfinite(returns).all()
+    first, last = np.mean(returns[:3]), np.mean(returns[-3:])
+    # unit-variance reward noise averages out over 256 episodes of 32 steps; the
+    # shaped term is worth up to ~0.1 * 32 * 4 * E|o| per episode
+    assert abs(first) < 1.0, returns
+    assert last - first > 2.0, returns
