@@ -6,7 +6,7 @@ HIPCC ?= /opt/rocm/bin/hipcc
 ARCH  ?= gfx950
 CSRC  := garage_amd/csrc
 OUT   := garage_amd/_C
-HIPS  := gae_scan gemm skinny losses rollout policy_fused small_step fused_train narrow_step
+HIPS  := gae_scan gemm skinny losses rollout policy_fused small_step fused_train narrow_step lnorm
 CPPS  := errors prof update comm rollout_loop
 OBJS  := $(patsubst %,$(OUT)/%.o,$(HIPS) $(CPPS))
 FLAGS := --offload-arch=$(ARCH) -O3 -fPIC -std=c++17 -Wall -Wno-unused-function $(EXTRA)

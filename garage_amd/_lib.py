@@ -17,7 +17,9 @@ class MlpDesc(C.Structure):
     """``ga_mlp_desc``."""
     _fields_ = [('n_layers', c_i32), ('dims', c_i32 * 9), ('w_off', c_i64 * 8),
                 ('b_off', c_i64 * 8), ('act_off', c_i64 * 8),
-                ('hidden_act', c_i32), ('output_act', c_i32)]
+                ('hidden_act', c_i32), ('output_act', c_i32),
+                ('layer_norm', c_i32), ('pad_', c_i32), ('ln_off', c_i64 * 8),
+                ('lnx_off', c_i64 * 8), ('lns_off', c_i64 * 8)]
 
 
 class SynthEnv(C.Structure):

@@ -389,7 +389,22 @@ struct ga_mlp_desc {
                        // workspace, row stride round4(dims[l + 1]) (hidden layers)
   int32_t hidden_act;  // 0 tanh, 1 relu, 2 none
   int32_t output_act;  // 0 none, 1 tanh, 2 relu (forward codes)
+  int32_t layer_norm;  // 1: LayerNorm in front of every hidden linear layer
+  int32_t pad_;
+  int64_t ln_off[8];   // gamma_l [round4(dims[l])] in params, beta_l right behind it
+  int64_t lnx_off[8];  // normalised input of hidden layer l in the activation
+                       // workspace, row stride round4(dims[l])
+  int64_t lns_off[8];  // (mean, rstd) per row of hidden layer l's input, there too
 };
+
+// lnorm.hip
+int ga_ln_forward(const float* X, int64_t ldx, const int32_t* idx, int64_t M, int D,
+                  const float* gamma, const float* beta, float* Y, int64_t ldy,
+                  float* stats, hipStream_t stream);
+int ga_ln_backward(float* dY, int64_t ldd, const float* X, int64_t ldx, const int32_t* idx,
+                   const float* stats, int64_t M, int D, const float* gamma, int want_dx,
+                   int hact, int rows_per_split, int n_splits, float* dgamma, float* dbeta,
+                   int64_t split_stride, hipStream_t stream);
 
 // The whole-network forward in one launch (policy_fused.hip) for nets whose
 // layers fit its LDS tiles; ga_set_fused_forward(0) forces the per-layer GEMMs.
@@ -462,6 +477,11 @@ static int check_desc(const ga_mlp_desc* d, const char* who) {
              who, d->hidden_act);
   GA_REQUIRE(d->output_act >= 0 && d->output_act <= 2, "%s: output_act %d not in 0..2",
              who, d->output_act);
+  if (d->layer_norm)
+    for (int l = 0; l + 1 < d->n_layers; ++l)
+      GA_REQUIRE(d->ln_off[l] % 4 == 0 && d->lnx_off[l] % 4 == 0 && d->dims[l] <= 1024,
+                 "%s: layer normalisation of layer %d: unaligned offsets or more than "
+                 "1024 inputs", who, l);
   return GA_OK;
 }
 
@@ -483,7 +503,7 @@ extern "C" int ga_mlp_forward_f32(const ga_mlp_desc* d, const float* params,
              "ga_mlp_forward_f32: pointers must be 16-B aligned");
   if (M == 0) return GA_OK;
   if (out && g_fused_forward && d->hidden_act == 0 && d->output_act == 0 &&
-      ga_policy_step_fused_supported(d))
+      !d->layer_norm && ga_policy_step_fused_supported(d))
     return ga_mlp_forward_fused_f32(d, params, X, ldx, row_idx, M, acts, out, ldo,
                                     stream);
   const int L = d->n_layers;
@@ -499,6 +519,17 @@ extern "C" int ga_mlp_forward_f32(const ga_mlp_desc* d, const float* params,
     p.ldb = round4(d->dims[l]);
     const bool last = (l == L - 1);
     if (last && !out) break;
+    if (d->layer_norm && !last) {
+      // LayerNorm(prev) -> Linear -> nonlinearity
+      // (multi_headed_mlp_module.py:77-92): the GEMM reads the normalised rows
+      const int64_t ldn = round4(d->dims[l]);
+      float* xn = acts + d->lnx_off[l];
+      rc = ga_ln_forward(p.A, p.lda, p.a_idx, M, d->dims[l], params + d->ln_off[l],
+                         params + d->ln_off[l] + ldn, xn, ldn, acts + d->lns_off[l],
+                         stream);
+      if (rc) return rc;
+      p.A = xn; p.lda = ldn; p.a_idx = nullptr;
+    }
     p.C = last ? out : acts + d->act_off[l];
     p.c_rs = last ? ldo : round4(d->dims[l + 1]);
     p.c_cs = 1;
@@ -514,7 +545,7 @@ extern "C" int ga_mlp_forward_f32(const ga_mlp_desc* d, const float* params,
       if (rc < 0) return rc;
       if (rc == 0) continue;
     }
-    if (out && l == L - 2 && d->output_act == 0 &&
+    if (out && l == L - 2 && d->output_act == 0 && !d->layer_norm &&
         (g_fuse_head_forward == 2 || (g_fuse_head_forward == 1 && p.N <= 128))) {
       p.head_W = params + d->w_off[L - 1];
       p.head_ldw = round4(d->dims[L - 1]);
@@ -609,9 +640,11 @@ extern "C" int ga_mlp_backward_range_f32(const ga_mlp_desc* d, const float* para
     {
       GemmParams p;
       memset(&p, 0, sizeof(p));
-      const float* in = (l == 0) ? X : acts + d->act_off[l - 1];
-      const int64_t ldin = (l == 0) ? ldx : round4(in_w);
-      const int32_t* in_idx = (l == 0) ? row_idx : nullptr;
+      const bool ln = d->layer_norm && l < L - 1;  // this layer reads normalised rows
+      const float* in = ln ? acts + d->lnx_off[l]
+                           : ((l == 0) ? X : acts + d->act_off[l - 1]);
+      const int64_t ldin = (ln || l > 0) ? round4(in_w) : ldx;
+      const int32_t* in_idx = (l == 0 && !ln) ? row_idx : nullptr;
       p.K = (int)M;
       p.k_per_split = kps;
       p.epi = EPI_PLAIN;
@@ -646,8 +679,8 @@ extern "C" int ga_mlp_backward_range_f32(const ga_mlp_desc* d, const float* para
       } else if (g_skinny && out_w <= 32 && in_w > 32) {
         // head layer: the same pass over the hidden activations also yields the
         // data gradient of the layer below (it needs dz and tanh' of `in` only)
-        const bool with_dz =
-            g_fuse_head_dgrad && l > 0 && in_idx == nullptr && d->hidden_act == 0;
+        const bool with_dz = g_fuse_head_dgrad && l > 0 && in_idx == nullptr &&
+                             d->hidden_act == 0 && !d->layer_norm;
         rc = ga_skinny_wgrad(in, ldin, in_idx, dz, lddz, nullptr, (int)M, in_w, out_w, kps,
                              (int)n_splits, grad_slabs + d->w_off[l], 1, round4(in_w),
                              slab_stride, nullptr, grad_slabs + d->b_off[l],
@@ -669,24 +702,44 @@ extern "C" int ga_mlp_backward_range_f32(const ga_mlp_desc* d, const float* para
       }
     }
     // ---- data gradient for the layer below
-    if (l > 0 && !dgrad_done) {
+    // A normalised layer input (hidden layers with layer_norm) takes the plain
+    // product dz W -- also for the first layer, whose gamma / beta need it -- and
+    // the LayerNorm's backward pass then turns it, in place, into the data
+    // gradient of the layer below.
+    const bool ln_in = d->layer_norm && l < L - 1;
+    if ((l > 0 || ln_in) && !dgrad_done) {
       GemmParams p;
       memset(&p, 0, sizeof(p));
+      float* dst = l > 0 ? dacts + d->act_off[l - 1] : dacts + d->lnx_off[0];
       p.A = dz; p.lda = lddz;
       p.B = params + d->w_off[l]; p.ldb = round4(in_w);
-      p.C = dacts + d->act_off[l - 1]; p.c_rs = round4(in_w); p.c_cs = 1;
+      p.C = dst; p.c_rs = round4(in_w); p.c_cs = 1;
       p.M = (int)M; p.N = in_w; p.K = out_w;
-      p.epi = EPI_MUL_DTANH;
-      p.H = acts + d->act_off[l - 1]; p.ldh = round4(in_w);
-      p.hact = d->hidden_act;
+      if (ln_in) {
+        p.epi = EPI_PLAIN;
+      } else {
+        p.epi = EPI_MUL_DTANH;
+        p.H = acts + d->act_off[l - 1]; p.ldh = round4(in_w);
+        p.hact = d->hidden_act;
+      }
       p.k_per_split = (int)ga_ceil_div(p.K, BK) * BK;
       rc = 1;
-      if (g_skinny && d->hidden_act == 0 && p.K <= 32 && p.N > 32)
+      if (g_skinny && !ln_in && d->hidden_act == 0 && p.K <= 32 && p.N > 32)
         rc = ga_skinny_forward(p.A, p.lda, nullptr, p.B, p.ldb, false, nullptr, 0, p.H,
                                p.ldh, p.C, p.c_rs, p.M, p.N, p.K, stream);
       if (rc < 0) return rc;
       if (rc == 1) {
         rc = launch_gemm<true, false>(p, 1, stream);
+        if (rc) return rc;
+      }
+      if (ln_in) {
+        const int64_t ldn = round4(in_w);
+        rc = ga_ln_backward(dst, ldn, l == 0 ? X : acts + d->act_off[l - 1],
+                            l == 0 ? ldx : ldn, l == 0 ? row_idx : nullptr,
+                            acts + d->lns_off[l], M, in_w, params + d->ln_off[l],
+                            l > 0 ? 1 : 0, d->hidden_act, kps, (int)n_splits,
+                            grad_slabs + d->ln_off[l], grad_slabs + d->ln_off[l] + ldn,
+                            slab_stride, stream);
         if (rc) return rc;
       }
     }
@@ -709,6 +762,8 @@ extern "C" int ga_mlp_jvp_f32(const ga_mlp_desc* d, const float* params,
   int rc = check_desc(d, "ga_mlp_jvp_f32");
   if (rc) return rc;
   GA_REQUIRE(params && tangent && X && tout, "ga_mlp_jvp_f32: null pointer");
+  GA_REQUIRE(!d->layer_norm, "ga_mlp_jvp_f32: layer normalisation is not implemented "
+                             "in the tangent pass (TRPO)");
   GA_REQUIRE(d->n_layers == 1 || (acts && tacts), "ga_mlp_jvp_f32: workspaces needed");
   GA_REQUIRE(M > 0 && M < (1ll << 31), "ga_mlp_jvp_f32: bad M");
   GA_REQUIRE(ldx % 4 == 0 && ldx >= d->dims[0] && ldo >= d->dims[d->n_layers],

@@ -506,6 +506,9 @@ struct ga_mlp_desc_c {
   int64_t act_off[8];
   int32_t hidden_act;  // 0 tanh, 1 relu, 2 none: these kernels implement tanh
   int32_t output_act;  // 0 none, 1 tanh, 2 relu: ... and a linear output layer
+  int32_t layer_norm;  // ... and no layer normalisation
+  int32_t pad_;
+  int64_t ln_off[8], lnx_off[8], lns_off[8];
 };
 
 struct ga_head_args_c {
@@ -524,7 +527,8 @@ struct ga_head_args_c {
 // 1 when ga_policy_step_fused_f32 supports this network shape.
 extern "C" int ga_policy_step_fused_supported(const ga_mlp_desc_c* d) {
   if (!d || d->n_layers < 1 || d->n_layers > 8) return 0;
-  if (d->hidden_act != 0 || d->output_act != 0) return 0;  // tanh, linear output
+  // tanh hidden layers, a linear output layer, no layer normalisation
+  if (d->hidden_act != 0 || d->output_act != 0 || d->layer_norm) return 0;
   for (int l = 0; l < d->n_layers; ++l)
     if (d->dims[l] > HMAX) return 0;  // every layer INPUT lives in an LDS tile
   if (d->dims[d->n_layers] > MAX_OUT) return 0;

@@ -124,7 +124,7 @@ FusedPlan fused_plan(const ga_mlp_desc* d, int64_t M) {
   const int L = d->n_layers;
   if (L < 2 || L > 8 || M < 1) return f;
   // the fused kernels implement tanh hidden layers and a linear output layer
-  if (d->hidden_act != 0 || d->output_act != 0) return f;
+  if (d->hidden_act != 0 || d->output_act != 0 || d->layer_norm) return f;
   if (g_narrow_step && ga_narrow_step_supported(L, d->dims)) {
     f.ok = f.narrow = true;
     f.tiles = ga_fused_tiles(M);
@@ -416,6 +416,7 @@ int run_minibatch(const ga_update_args* a, int64_t k, ga_stream_t stream,
   if (g_small_step && !g_fuse_head && !a->comm && a->phase != 1 && a->kind >= 0 && a->kind <= 2 &&
       (a->algo == 0 || a->algo == 1) && a->acts && a->dacts &&
       workspace_rows(a) >= 32 && a->desc->hidden_act == 0 && a->desc->output_act == 0 &&
+      !a->desc->layer_norm &&
       ga_small_step_supported(L, a->desc->dims, M) &&
       ga_small_step_resident(a->desc->dims[1], 2)) {
     ga_small_step_args s;
@@ -454,7 +455,8 @@ int run_minibatch(const ga_update_args* a, int64_t k, ga_stream_t stream,
   // when its shape allows: no narrow GEMM launch, no round trip of its output
   const int hid_w = L >= 2 ? a->desc->dims[L - 1] : 0;
   const bool fuse_head = g_fuse_head && L >= 2 && (a->kind == 0 || a->kind == 1) &&
-                         a->desc->output_act == 0 && ga_head_loss_supported(hid_w, out_w);
+                         a->desc->output_act == 0 && !a->desc->layer_norm &&
+                         ga_head_loss_supported(hid_w, out_w);
   GA_TRACE(stream, "forward k=%lld M=%lld start=%lld kind=%d", (long long)k, (long long)M,
            (long long)start, a->kind);
   int rc = ga_mlp_forward_f32(a->desc, a->params, a->X, a->ldx, idx, M, a->acts,

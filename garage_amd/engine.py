@@ -55,9 +55,10 @@ class FlatMLP:
     OUTPUT_ACTS = {'none': 0, 'tanh': 1, 'relu': 2}
 
     def __init__(self, in_dim, out_dim, hidden_sizes, device, hidden_act='tanh',
-                 output_act='none'):
+                 output_act='none', layer_norm=False):
         self.hidden_act = hidden_act
         self.output_act = output_act
+        self.layer_norm = bool(layer_norm)
         self.in_dim, self.out_dim = int(in_dim), int(out_dim)
         self.hidden_sizes = tuple(int(h) for h in hidden_sizes)
         dims = (self.in_dim, ) + self.hidden_sizes + (self.out_dim, )
@@ -72,11 +73,28 @@ class FlatMLP:
             off += dims[l + 1] * round4(dims[l])
             self.b_off.append(off)
             off += round4(dims[l + 1])
+        # layer_normalization: gamma_l, beta_l of the LayerNorm in front of hidden
+        # layer l (multi_headed_mlp_module.py:77-81), behind everything else so that
+        # the other offsets do not depend on the option
+        self.ln_off = []
+        if self.layer_norm:
+            for l in range(len(dims) - 2):
+                self.ln_off.append(off)
+                off += 2 * round4(dims[l])
         self.n_flat = off
         self.act_off, aoff = [], 0
         for l in range(len(dims) - 2):
             self.act_off.append(aoff)
             aoff += round4(dims[l + 1])
+        # ... and per row: the normalised input of every hidden layer, (mean, rstd)
+        self.lnx_off, self.lns_off = [], []
+        if self.layer_norm:
+            for l in range(len(dims) - 2):
+                self.lnx_off.append(aoff)
+                aoff += round4(dims[l])
+            for l in range(len(dims) - 2):
+                self.lns_off.append(aoff)
+                aoff += 4
         self.act_width = aoff  # floats of hidden activations per row
         self.ld_out = round4(self.out_dim)
         self.params = torch.zeros(off, dtype=torch.float32, device=device)
@@ -87,6 +105,11 @@ class FlatMLP:
         d = _lib.MlpDesc()
         d.hidden_act = self.HIDDEN_ACTS[hidden_act]
         d.output_act = self.OUTPUT_ACTS[output_act]
+        d.layer_norm = int(self.layer_norm)
+        for l, o in enumerate(self.ln_off):
+            d.ln_off[l] = o
+            n = round4(dims[l])
+            self.params[o:o + dims[l]] = 1.0  # nn.LayerNorm: weight 1, bias 0
         d.n_layers = len(dims) - 1
         for i, v in enumerate(dims):
             d.dims[i] = v
@@ -123,6 +146,11 @@ class FlatMLP:
             b = buf[self.b_off[l]:self.b_off[l] + rows]
             if l < nl - 1:
                 base = '_mean_module._layers.{}.linear.'.format(l)
+                if self.layer_norm:  # parameters() order: the LayerNorm comes first
+                    o, n = self.ln_off[l], round4(cols)
+                    ln = '_mean_module._layers.{}.layer_normalization.'.format(l)
+                    out.append((ln + 'weight', buf[o:o + cols]))
+                    out.append((ln + 'bias', buf[o + n:o + n + cols]))
             else:
                 base = '_mean_module._output_layers.0.linear.'
             out.append((base + 'weight', w))
@@ -147,6 +175,9 @@ class FlatMLP:
                                       dtype=torch.float32, device=dev)
             for l in range(len(self.dims) - 2):
                 self._desc.act_off[l] = self.act_off[l] * cap
+            for l in range(len(self.lnx_off)):
+                self._desc.lnx_off[l] = self.lnx_off[l] * cap
+                self._desc.lns_off[l] = self.lns_off[l] * cap
             self._cap = cap
 
     def train_partials(self, rows):

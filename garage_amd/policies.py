@@ -45,12 +45,11 @@ def _hidden_act(hidden_nonlinearity):
 
 def _check_supported(hidden_nonlinearity, output_nonlinearity,
                      std_parameterization, layer_normalization):
-    """-> (hidden activation, output activation) names for FlatMLP."""
-    act = (_hidden_act(hidden_nonlinearity), _hidden_act(output_nonlinearity))
+    """-> (hidden activation, output activation, layer norm) for FlatMLP."""
+    act = (_hidden_act(hidden_nonlinearity), _hidden_act(output_nonlinearity),
+           bool(layer_normalization))
     if std_parameterization not in ('exp', 'softplus'):
         raise NotImplementedError  # gaussian_mlp_module.py:120-121
-    if layer_normalization:
-        raise NotImplementedError('layer_normalization is not supported')
     return act
 
 
@@ -86,11 +85,12 @@ class _GaussianMLP:
                hidden_b_init, output_w_init, output_b_init, learn_std,
                init_std, min_std, max_std, device, hidden_act='tanh'):
         self.device = device or require_gpu()
-        output_act = 'none'
+        output_act, layer_norm = 'none', False
         if isinstance(hidden_act, tuple):
-            hidden_act, output_act = hidden_act
+            hidden_act, output_act, layer_norm = hidden_act
         self.net = FlatMLP(in_dim, out_dim, hidden_sizes, self.device,
-                           hidden_act=hidden_act, output_act=output_act)
+                           hidden_act=hidden_act, output_act=output_act,
+                           layer_norm=layer_norm)
         _reference_init(self.net, hidden_w_init, hidden_b_init, output_w_init,
                         output_b_init)
         self._learn_std = bool(learn_std)
@@ -215,7 +215,8 @@ class _GaussianMLP:
             net = FlatMLP(self.net.in_dim, self.net.out_dim,
                           self.net.hidden_sizes, device,
                           hidden_act=self.net.hidden_act,
-                          output_act=self.net.output_act)
+                          output_act=self.net.output_act,
+                          layer_norm=self.net.layer_norm)
             for k in ('params', 'grads', 'exp_avg', 'exp_avg_sq'):
                 getattr(net, k).copy_(getattr(self.net, k))
             net.adam_steps = self.net.adam_steps
@@ -297,6 +298,7 @@ class _GaussianMLP:
         state['_hidden_sizes'] = self.net.hidden_sizes
         state['_hidden_act'] = self.net.hidden_act
         state['_output_act'] = self.net.output_act
+        state['_layer_norm'] = self.net.layer_norm
         state['_dims'] = (self.net.in_dim, self.net.out_dim)
         for k in ('params', 'exp_avg', 'exp_avg_sq'):
             state['_net_' + k] = getattr(self.net, k).cpu().numpy()
@@ -307,6 +309,7 @@ class _GaussianMLP:
         hidden = state.pop('_hidden_sizes')
         act = state.pop('_hidden_act', 'tanh')
         out_act = state.pop('_output_act', 'none')
+        layer_norm = state.pop('_layer_norm', False)
         in_dim, out_dim = state.pop('_dims')
         bufs = {k: state.pop('_net_' + k)
                 for k in ('params', 'exp_avg', 'exp_avg_sq')}
@@ -314,7 +317,7 @@ class _GaussianMLP:
         self.__dict__.update(state)
         self.device = require_gpu()
         self.net = FlatMLP(in_dim, out_dim, hidden, self.device, hidden_act=act,
-                           output_act=out_act)
+                           output_act=out_act, layer_norm=layer_norm)
         for k, v in bufs.items():
             getattr(self.net, k).copy_(torch.from_numpy(v))
         self.net.adam_steps = steps

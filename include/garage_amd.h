@@ -94,6 +94,15 @@ typedef struct {
                          1 = tanh, 2 = relu.  Per-layer kernels only; the caller
                          scales the loss's d(output) by the slope before the backward
                          pass (ga_act_slope_mul_f32). */
+  int32_t layer_norm; /* layer_normalization of the same module
+                         (multi_headed_mlp_module.py:77-81): LayerNorm(eps 1e-5,
+                         affine) over the input of every hidden linear layer.
+                         Per-layer kernels only; not in ga_mlp_jvp_f32. */
+  int32_t pad_;
+  int64_t ln_off[8];  /* gamma_l [round4(dims[l])] offset in params; beta_l follows */
+  int64_t lnx_off[8]; /* normalised input of hidden layer l in the activation
+                         workspace (row stride round4(dims[l])) ... */
+  int64_t lns_off[8]; /* ... and its per-row (mean, rstd) pairs */
 } ga_mlp_desc;
 
 /* dout[i, j] *= slope of the activation `act` (1 tanh, 2 relu) at its OUTPUT

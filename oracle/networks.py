@@ -118,6 +118,12 @@ def mlp_mean(params, prefix, x):
     act = _HIDDEN[-1].get(prefix, torch.tanh)
     for i in range(n_hidden(params, prefix)):
         base = '{}_mean_module._layers.{}.linear.'.format(prefix, i)
+        ln = '{}_mean_module._layers.{}.layer_normalization.'.format(prefix, i)
+        if ln + 'weight' in params:  # layer_normalization=True
+            # (multi_headed_mlp_module.py:77-81: nn.LayerNorm(prev_size) first)
+            x = torch.nn.functional.layer_norm(x, (x.shape[-1], ),
+                                               params[ln + 'weight'],
+                                               params[ln + 'bias'], 1e-5)
         x = torch.nn.functional.linear(x, params[base + 'weight'],
                                        params[base + 'bias'])
         if act is not None:

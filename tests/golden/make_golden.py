@@ -635,6 +635,11 @@ def gen_policy_options():
              pol=dict(output_nonlinearity=torch.tanh,
                       hidden_nonlinearity=torch.relu),
              vf=dict(output_nonlinearity=torch.tanh)),
+        # layer_normalization (multi_headed_mlp_module.py:77-81)
+        dict(tag='layer_norm', pol=dict(layer_normalization=True),
+             vf=dict(layer_normalization=True)),
+        dict(tag='layer_norm_relu', pol=dict(layer_normalization=True,
+                                             hidden_nonlinearity=torch.relu)),
         # std = log(1 + exp(exp(p))) (gaussian_mlp_module.py:180-181), free and
         # with an active upper clamp on p
         dict(tag='softplus', pol=dict(std_parameterization='softplus',
@@ -656,7 +661,8 @@ def gen_policy_options():
         vf = GaussianMLPValueFunction(spec, hidden_sizes=hs, **case.get('vf', {}))
         if ('vf' in case or 'hidden_nonlinearity' in case['pol']
                 or 'std_parameterization' in case['pol']
-                or 'output_nonlinearity' in case['pol']):
+                or 'output_nonlinearity' in case['pol']
+                or 'layer_normalization' in case['pol']):
             # forward outputs of the freshly built networks on fixed inputs
             x = torch.from_numpy(
                 np.random.RandomState(3).randn(6, O).astype(np.float32))

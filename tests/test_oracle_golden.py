@@ -780,3 +780,51 @@ def test_golden_output_nonlinearity(golden, tag):
                 assert np.allclose(v, g[pre + 'pol:' + k], atol=1e-6), k
             for k, v in vf.items():
                 assert np.allclose(v, g[pre + 'vf:' + k], atol=1e-6), k
+
+
+LAYER_NORM_CASES = {
+    'layer_norm': (torch.tanh, torch.tanh),
+    'layer_norm_relu': (torch.relu, torch.tanh),
+}
+
+
+@pytest.mark.parametrize('tag', sorted(LAYER_NORM_CASES))
+def test_golden_layer_normalization(golden, tag):
+    """``layer_normalization=True`` (``multi_headed_mlp_module.py:77-81``: a
+    LayerNorm over the input of every hidden linear layer): forward outputs and two
+    real PPO iterations, gamma / beta included."""
+    from oracle import networks as nets
+    g = golden('policy_options')
+    O, A, P, E, mb = [int(v) for v in g[tag + '_cfg']]
+    pa, va = LAYER_NORM_CASES[tag]
+    with nets.hidden_nonlinearity(policy=pa, value=va):
+        pol0, vf0 = _params(g, tag + '_pol0:'), _params(g, tag + '_vf0:')
+        assert any('layer_normalization' in k for k in pol0)
+        x = torch.from_numpy(g[tag + '_fwd_obs'])
+        with torch.no_grad():
+            assert np.allclose(nets.policy_forward(pol0, x)[0].mean.numpy(),
+                               g[tag + '_fwd_mean'], atol=1e-6)
+            assert np.allclose(nets.value_forward(vf0, x).numpy(),
+                               g[tag + '_fwd_value'], atol=1e-6)
+        algo = OraclePPO(pol0, vf0, max_episode_length=P,
+                         max_optimization_epochs=E, minibatch_size=mb,
+                         policy_lr=2.5e-3, vf_lr=2.5e-3)
+        for it in range(2):
+            pre = '%s_it%d_' % (tag, it)
+            lens = g[pre + 'lengths']
+            b = ob.OracleEpisodeBatch(
+                observations=g[pre + 'observations'],
+                last_observations=np.zeros((len(lens), O), np.float32),
+                actions=g[pre + 'actions'], rewards=g[pre + 'rewards'],
+                step_types=g[pre + 'step_types'], lengths=lens,
+                max_episode_length=P)
+            np.random.seed(int(g[pre + 'np_seed']))
+            out = algo.train_once(b)
+            for mine, theirs in LOG_KEYS.items():
+                assert np.isclose(out[mine], float(g[pre + 'log:' + theirs]),
+                                  atol=1e-5, rtol=1e-5), (mine, it)
+            pol, vf = algo.state()
+            for k, v in pol.items():
+                assert np.allclose(v, g[pre + 'pol:' + k], atol=1e-6), k
+            for k, v in vf.items():
+                assert np.allclose(v, g[pre + 'vf:' + k], atol=1e-6), k

@@ -838,6 +838,150 @@ def test_output_nonlinearity_python_loop_and_trpo_against_oracle():
                                    name, k)
 
 
+LAYER_NORM_CASES = {
+    'layer_norm': (dict(layer_normalization=True), dict(layer_normalization=True)),
+    'layer_norm_relu': (dict(layer_normalization=True,
+                             hidden_nonlinearity=torch.relu), dict()),
+}
+
+
+@pytest.mark.parametrize('tag', sorted(LAYER_NORM_CASES))
+def test_layer_normalization_matches_real_reference(golden, tag):
+    """``layer_normalization=True`` (``multi_headed_mlp_module.py:77-81``): the
+    state_dict carries the LayerNorm weights in the reference's order, forward
+    outputs and two real PPO iterations match, gamma / beta included."""
+    from garage_amd.algos import PPO
+    from garage_amd.optimizers import OptimizerWrapper
+    from garage_amd.policies import GaussianMLPPolicy, GaussianMLPValueFunction
+    g = golden('policy_options')
+    O, A, P, E, mb = [int(v) for v in g[tag + '_cfg']]
+    spec = _spec(O, A, P)
+    pkw, vkw = LAYER_NORM_CASES[tag]
+    torch.manual_seed(17)
+    pol = GaussianMLPPolicy(spec, hidden_sizes=(8, 8), **pkw)
+    vf = GaussianMLPValueFunction(spec, hidden_sizes=(8, 8), **vkw)
+    want_keys = [k[len(tag + '_pol0:'):] for k in g.files
+                 if k.startswith(tag + '_pol0:')]
+    assert sorted(pol.state_dict().keys()) == sorted(want_keys)
+    # parameters() order of the reference: LayerNorm before its Linear
+    mine = [n for n, _ in pol.named_parameters()]
+    theirs = [k for k in want_keys if not k.endswith('min_std_param')]
+    assert mine == theirs
+    # freshly built: gamma 1, beta 0, the same Linear init as the reference
+    for k, v in pol.state_dict().items():
+        assert np.allclose(v.numpy(), g[tag + '_pol0:' + k], atol=1e-7), k
+    pol.load_state_dict(_sd(g, tag + '_pol0:'))
+    vf.load_state_dict(_sd(g, tag + '_vf0:'))
+    x = torch.from_numpy(g[tag + '_fwd_obs'])
+    dist, _ = pol.forward(x)
+    assert np.allclose(dist.mean.cpu().numpy(), g[tag + '_fwd_mean'], atol=2e-6)
+    assert np.allclose(vf.forward(x).cpu().numpy().reshape(-1),
+                       g[tag + '_fwd_value'].reshape(-1), atol=2e-6)
+    algo = PPO(env_spec=spec, policy=pol, value_function=vf, sampler=None,
+               policy_optimizer=OptimizerWrapper(
+                   (torch.optim.Adam, dict(lr=2.5e-3)), pol,
+                   max_optimization_epochs=E, minibatch_size=mb),
+               vf_optimizer=OptimizerWrapper(
+                   (torch.optim.Adam, dict(lr=2.5e-3)), vf,
+                   max_optimization_epochs=E, minibatch_size=mb))
+    for it in range(2):
+        pre = '%s_it%d_' % (tag, it)
+        batch = _host_batch(spec, g, pre, O)
+        np.random.seed(int(g[pre + 'np_seed']))
+        algo._train_once(it, batch)
+        for mine_k, theirs_k in LOG_KEYS.items():
+            want = float(g[pre + 'log:' + theirs_k])
+            assert np.isclose(algo.last_tabular[mine_k], want, atol=1e-5,
+                              rtol=1e-5), (mine_k, it, algo.last_tabular[mine_k],
+                                           want)
+        for k, v in pol.state_dict().items():
+            assert np.allclose(v.numpy(), g[pre + 'pol:' + k], atol=2e-6), k
+        for k, v in vf.state_dict().items():
+            assert np.allclose(v.numpy(), g[pre + 'vf:' + k], atol=2e-6), k
+
+
+def test_layer_normalization_at_c3_shape_against_oracle():
+    """LayerNorm rows of 17 and 256 floats, 3000 samples, minibatches, the
+    split-K slab path of gamma / beta: one PPO iteration against the oracle; a
+    pickle round trip keeps the option; TRPO refuses it."""
+    import pickle
+
+    from garage_amd._dtypes import EpisodeBatch, StepType
+    from garage_amd.algos import PPO, TRPO
+    from garage_amd.optimizers import OptimizerWrapper
+    from garage_amd.policies import GaussianMLPPolicy, GaussianMLPValueFunction
+    from oracle import batch as ob
+    from oracle.ppo import OraclePPO
+    O, A, P = 17, 6, 32
+    spec = _spec(O, A, P)
+    torch.manual_seed(9)
+    rng = np.random.RandomState(9)
+    pol = GaussianMLPPolicy(spec, hidden_sizes=(256, 256),
+                            layer_normalization=True)
+    vf = GaussianMLPValueFunction(spec, hidden_sizes=(256, 256),
+                                  layer_normalization=True)
+    # gamma / beta away from their (1, 0) initialisation
+    for net in (pol.net, vf.net):
+        gen = torch.Generator(device='cpu').manual_seed(3)
+        for name, view in net.named_views():
+            if 'layer_normalization' in name:
+                view.add_(0.2 * torch.randn(view.shape, generator=gen).to(
+                    view.device))
+    lens = rng.randint(4, P + 1, size=150)
+    lens[::5] = P
+    S = int(lens.sum())
+    st = []
+    for L in lens:
+        t = [1] * L
+        t[0] = 0
+        t[-1] = 3 if L == P else 2
+        st += t
+    obs = (2.0 * rng.randn(S, O) + 0.5).astype(np.float32)
+    acts = rng.randn(S, A).astype(np.float32)
+    rew = rng.randn(S)
+    E, mb = 2, 700
+    oracle = OraclePPO(OrderedDict(pol.state_dict()), OrderedDict(vf.state_dict()),
+                       max_episode_length=P, max_optimization_epochs=E,
+                       minibatch_size=mb, policy_lr=1e-3, vf_lr=1e-3)
+    b = ob.OracleEpisodeBatch(
+        observations=obs, last_observations=np.zeros((len(lens), O), np.float32),
+        actions=acts, rewards=rew, step_types=np.asarray(st), lengths=lens,
+        max_episode_length=P)
+    np.random.seed(4)
+    want = oracle.train_once(b)
+    wpol, wvf = oracle.state()
+    pol2 = pickle.loads(pickle.dumps(pol))
+    assert pol2.net.layer_norm and sorted(pol2.state_dict()) == sorted(
+        pol.state_dict())
+    algo = PPO(env_spec=spec, policy=pol, value_function=vf, sampler=None,
+               policy_optimizer=OptimizerWrapper(
+                   (torch.optim.Adam, dict(lr=1e-3)), pol,
+                   max_optimization_epochs=E, minibatch_size=mb),
+               vf_optimizer=OptimizerWrapper(
+                   (torch.optim.Adam, dict(lr=1e-3)), vf,
+                   max_optimization_epochs=E, minibatch_size=mb))
+    batch = EpisodeBatch(env_spec=spec, episode_infos={}, observations=obs,
+                         last_observations=np.zeros((len(lens), O), np.float32),
+                         actions=acts, rewards=rew, env_infos={}, agent_infos={},
+                         step_types=np.asarray([StepType(s) for s in st],
+                                               dtype=object),
+                         lengths=lens.astype('l'))
+    np.random.seed(4)
+    algo._train_once(0, batch)
+    for k in ('policy/LossBefore', 'policy/LossAfter', 'policy/KL',
+              'policy/Entropy', 'vf/LossBefore', 'vf/LossAfter'):
+        assert np.isclose(algo.last_tabular[k], want[k], atol=2e-5,
+                          rtol=2e-4), (k, algo.last_tabular[k], want[k])
+    for mine, theirs in ((pol.state_dict(), wpol), (vf.state_dict(), wvf)):
+        for k, v in mine.items():
+            d = np.abs(v.numpy() - np.asarray(theirs[k]))
+            assert d.max() <= 1e-4 and d.mean() <= 2e-6, (k, d.max(), d.mean())
+    with pytest.raises(Exception, match='layer normalisation'):
+        t = TRPO(env_spec=spec, policy=pol2, value_function=vf, sampler=None)
+        np.random.seed(4)
+        t._train_once(0, batch)
+
+
 @pytest.mark.parametrize('act', ['relu', 'none'])
 def test_hidden_nonlinearity_at_c3_shape_against_oracle(act):
     """A relu / linear MLP(256,256) on a 3000-sample batch (the MFMA tile kernels,
