@@ -61,3 +61,50 @@ def test_ppo_learns_the_synthetic_env(name):
     # shaped term is worth up to ~0.1 * 32 * 4 * E|o| per episode
     assert abs(first) < 1.0, returns
     assert last - first > 2.0, returns
+
+
+VPG_VARIANTS = {
+    # the three configurations of tests/garage/torch/algos/test_vpg.py:68-100
+    'no_entropy': dict(positive_adv=True, use_softplus_entropy=True),
+    'max': dict(center_adv=False, stop_entropy_gradient=True, entropy_method='max',
+                policy_ent_coeff=0.01),
+    'regularized': dict(entropy_method='regularized', policy_ent_coeff=0.01),
+}
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize('name', sorted(VPG_VARIANTS))
+def test_vpg_entropy_variants_learn_the_synthetic_env(name):
+    """``test_vpg_no_entropy`` / ``test_vpg_max`` / ``test_vpg_regularized`` of the
+    reference train VPG for 10 epochs and assert a positive return; here the same
+    three configurations on the synthetic env, asserting improvement."""
+    from garage_amd.algos import VPG
+    from garage_amd.envs import SyntheticVecEnv
+    from garage_amd.optimizers import OptimizerWrapper
+    from garage_amd.policies import GaussianMLPPolicy, GaussianMLPValueFunction
+    from garage_amd.sampler import GpuVecSampler, GpuVecWorker
+    n, O, A, T = 256, 8, 4, 32
+    torch.manual_seed(5)
+    np.random.seed(5)
+    env = SyntheticVecEnv(n, O, A, T, seed=6)
+    pol = GaussianMLPPolicy(env.spec, hidden_sizes=(64, 64),
+                            hidden_nonlinearity=torch.tanh,
+                            output_nonlinearity=None)
+    vf = GaussianMLPValueFunction(env.spec)
+    sampler = GpuVecSampler(agents=pol, envs=env, max_episode_length=T,
+                            n_workers=1, worker_class=GpuVecWorker,
+                            worker_args=dict(n_envs=n))
+    algo = VPG(env_spec=env.spec, policy=pol, value_function=vf, sampler=sampler,
+               policy_optimizer=OptimizerWrapper(
+                   (torch.optim.Adam, dict(lr=5e-3)), pol),
+               vf_optimizer=OptimizerWrapper(
+                   (torch.optim.Adam, dict(lr=5e-3)), vf,
+                   max_optimization_epochs=5),
+               discount=0.99, **VPG_VARIANTS[name])
+    returns = []
+    for itr in range(60):
+        eps = sampler.obtain_samples(itr, n * T, None)
+        returns.append(float(algo._train_once(itr, eps)))
+    assert np.isfinite(returns).all()
+    first, last = np.mean(returns[:3]), np.mean(returns[-3:])
+    assert last - first > 1.0, returns
