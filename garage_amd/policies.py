@@ -288,7 +288,13 @@ class _GaussianMLP:
             flat[np.arange(ids.shape[0]), ids] = 1.0
             return pad_rows(flat)
         flat = np.asarray(observations, dtype=np.float32)
+        if flat.ndim == 1 and flat.shape[0] == self.net.in_dim:
+            flat = flat[None]  # a single observation
         flat = flat.reshape(flat.shape[0], -1)
+        if flat.shape[1] != self.net.in_dim:
+            raise ValueError(
+                'observations of width {} given to a network with {} inputs'.format(
+                    flat.shape[1], self.net.in_dim))
         return pad_rows(flat)
 
     # -- pickling (Trainer snapshots cloudpickle the algo, trainer.py:263-293)
@@ -399,6 +405,9 @@ class GaussianMLPPolicy(_GaussianMLP):
         if torch.is_tensor(observations) and observations.dim() > 2:
             lead = observations.shape[:-1]
             observations = observations.reshape(-1, observations.shape[-1])
+        elif np.ndim(observations) == 1 and not is_discrete(
+                self._env_spec.observation_space):
+            lead = ()  # one observation: batch shape () like the reference module
         obs = self._as_device_obs(observations)
         mean = self.mean(obs)[:, :self._action_dim].clone()
         log_std = torch.full_like(mean, self.clamped_log_std())
@@ -565,6 +574,8 @@ class GaussianMLPValueFunction(_GaussianMLP):
         if torch.is_tensor(obs) and obs.dim() > 2:
             lead = obs.shape[:-1]
             obs = obs.reshape(-1, obs.shape[-1])
+        elif np.ndim(obs) == 1:
+            lead = ()  # one observation -> a scalar
         v = self.values(self._as_device_obs(obs))[:, 0].clone()
         return v if lead is None else v.reshape(tuple(lead))
 
