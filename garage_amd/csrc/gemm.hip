@@ -405,6 +405,10 @@ int ga_ln_backward(float* dY, int64_t ldd, const float* X, int64_t ldx, const in
                    const float* stats, int64_t M, int D, const float* gamma, int want_dx,
                    int hact, int rows_per_split, int n_splits, float* dgamma, float* dbeta,
                    int64_t split_stride, hipStream_t stream);
+int ga_ln_jvp(const float* tX, int64_t ldt, const float* X, int64_t ldx, const int32_t* idx,
+              const float* stats, int64_t M, int D, const float* gamma,
+              const float* tgamma, const float* tbeta, float* tY, int64_t ldy,
+              hipStream_t stream);
 
 // The whole-network forward in one launch (policy_fused.hip) for nets whose
 // layers fit its LDS tiles; ga_set_fused_forward(0) forces the per-layer GEMMs.
@@ -762,8 +766,6 @@ extern "C" int ga_mlp_jvp_f32(const ga_mlp_desc* d, const float* params,
   int rc = check_desc(d, "ga_mlp_jvp_f32");
   if (rc) return rc;
   GA_REQUIRE(params && tangent && X && tout, "ga_mlp_jvp_f32: null pointer");
-  GA_REQUIRE(!d->layer_norm, "ga_mlp_jvp_f32: layer normalisation is not implemented "
-                             "in the tangent pass (TRPO)");
   GA_REQUIRE(d->n_layers == 1 || (acts && tacts), "ga_mlp_jvp_f32: workspaces needed");
   GA_REQUIRE(M > 0 && M < (1ll << 31), "ga_mlp_jvp_f32: bad M");
   GA_REQUIRE(ldx % 4 == 0 && ldx >= d->dims[0] && ldo >= d->dims[d->n_layers],
@@ -778,10 +780,26 @@ extern "C" int ga_mlp_jvp_f32(const ga_mlp_desc* d, const float* params,
     float* C = last ? tout : tacts + d->act_off[l];
     const int64_t ldc = last ? ldo : round4(out_w);
     const float* H = last ? nullptr : acts + d->act_off[l];
+    // a normalised layer input: its tangent (through the LayerNorm, from the
+    // tangent of the layer below and of gamma / beta) is a second product even
+    // for the first layer
+    const bool ln = d->layer_norm && !last;
+    const int64_t ldn = round4(in_w);
+    if (ln) {
+      rc = ga_ln_jvp(l > 0 ? tacts + d->act_off[l - 1] : nullptr, ldn,
+                     l > 0 ? acts + d->act_off[l - 1] : X, l > 0 ? ldn : ldx,
+                     l > 0 ? nullptr : row_idx, acts + d->lns_off[l], M, in_w,
+                     params + d->ln_off[l], tangent + d->ln_off[l],
+                     tangent + d->ln_off[l] + ldn, tacts + d->lnx_off[l], ldn, stream);
+      if (rc) return rc;
+    }
+    const bool two = l > 0 || ln;
     // in_l dW_l^T + db_l  (and the tanh' factor when it is the only product)
     GemmParams p;
     memset(&p, 0, sizeof(p));
-    if (l == 0) {
+    if (ln) {
+      p.A = acts + d->lnx_off[l]; p.lda = ldn;
+    } else if (l == 0) {
       p.A = X; p.lda = ldx; p.a_idx = row_idx;
     } else {
       p.A = acts + d->act_off[l - 1]; p.lda = round4(in_w);
@@ -790,15 +808,16 @@ extern "C" int ga_mlp_jvp_f32(const ga_mlp_desc* d, const float* params,
     p.C = C; p.c_rs = ldc; p.c_cs = 1;
     p.M = (int)M; p.N = out_w; p.K = in_w;
     p.epi = EPI_BIAS_ACT; p.bias = tangent + d->b_off[l]; p.act = 0;
-    if (l == 0) { p.H = H; p.ldh = ldc; p.hact = d->hidden_act; }
+    if (!two) { p.H = H; p.ldh = ldc; p.hact = d->hidden_act; }
     p.k_per_split = (int)ga_ceil_div(p.K, BK) * BK;
     rc = launch_gemm<true, true>(p, 1, stream);
     if (rc) return rc;
-    if (l > 0) {
+    if (two) {
       // += tin_l W_l^T, then the tanh' factor
       GemmParams q;
       memset(&q, 0, sizeof(q));
-      q.A = tacts + d->act_off[l - 1]; q.lda = round4(in_w);
+      q.A = ln ? tacts + d->lnx_off[l] : tacts + d->act_off[l - 1];
+      q.lda = round4(in_w);
       q.B = params + d->w_off[l]; q.ldb = round4(in_w);
       q.C = C; q.c_rs = ldc; q.c_cs = 1;
       q.M = (int)M; q.N = out_w; q.K = in_w;

@@ -151,7 +151,72 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdParams p) {
   }
 }
 
+// Tangent of y = LN(x) for the tangents (tx, tgamma, tbeta):
+//   ty = gamma rstd (tx - mean(tx) - xhat mean(tx xhat)) + tgamma xhat + tbeta
+// (tx == null: the rows are inputs of the network and carry no tangent)
+struct LnJvpParams {
+  const float* tX; int64_t ldt;
+  const float* X; int64_t ldx; const int32_t* idx;
+  const float* stats;
+  int64_t M; int D;
+  const float* gamma; const float* tgamma; const float* tbeta;
+  float* tY; int64_t ldy;
+};
+
+__global__ __launch_bounds__(256) void ln_jvp_kernel(LnJvpParams p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+  if (row >= p.M) return;
+  const int64_t src = p.idx ? (int64_t)p.idx[row] : row;
+  const float* x = p.X + src * p.ldx;
+  const float mean = p.stats[2 * row], rstd = p.stats[2 * row + 1];
+  float xh[LN_PER_LANE], tx[LN_PER_LANE];
+  float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < LN_PER_LANE; ++k) {
+    const int j = lane + 64 * k;
+    const bool ok = j < p.D;
+    xh[k] = ok ? (x[j] - mean) * rstd : 0.f;
+    tx[k] = (ok && p.tX) ? p.tX[row * p.ldt + j] : 0.f;
+    c1 += tx[k];
+    c2 += tx[k] * xh[k];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    c1 += __shfl_xor(c1, o, 64);
+    c2 += __shfl_xor(c2, o, 64);
+  }
+  c1 /= (float)p.D;
+  c2 /= (float)p.D;
+  float* ty = p.tY + row * p.ldy;
+#pragma unroll
+  for (int k = 0; k < LN_PER_LANE; ++k) {
+    const int j = lane + 64 * k;
+    if (j < p.D)
+      ty[j] = p.gamma[j] * rstd * (tx[k] - c1 - xh[k] * c2) + p.tgamma[j] * xh[k] +
+              p.tbeta[j];
+    else if (j < (int)p.ldy)
+      ty[j] = 0.f;
+  }
+}
+
 }  // namespace
+
+int ga_ln_jvp(const float* tX, int64_t ldt, const float* X, int64_t ldx, const int32_t* idx,
+              const float* stats, int64_t M, int D, const float* gamma,
+              const float* tgamma, const float* tbeta, float* tY, int64_t ldy,
+              hipStream_t stream) {
+  GA_REQUIRE(X && stats && gamma && tgamma && tbeta && tY && M >= 1 && D >= 1 &&
+                 D <= LN_MAXW && ldy >= D && ldy <= LN_MAXW,
+             "layer normalisation tangent: bad arguments");
+  LnJvpParams p;
+  p.tX = tX; p.ldt = ldt; p.X = X; p.ldx = ldx; p.idx = idx; p.stats = stats; p.M = M;
+  p.D = D; p.gamma = gamma; p.tgamma = tgamma; p.tbeta = tbeta; p.tY = tY; p.ldy = ldy;
+  hipLaunchKernelGGL(ln_jvp_kernel, dim3((unsigned)ga_ceil_div(M, 4)), dim3(256), 0, stream,
+                     p);
+  GA_CHECK_LAUNCH("ln_jvp");
+  return GA_OK;
+}
 
 // Internal entry points (gemm.hip calls them from the per-layer forward / backward).
 int ga_ln_forward(const float* X, int64_t ldx, const int32_t* idx, int64_t M, int D,

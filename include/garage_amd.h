@@ -97,7 +97,7 @@ typedef struct {
   int32_t layer_norm; /* layer_normalization of the same module
                          (multi_headed_mlp_module.py:77-81): LayerNorm(eps 1e-5,
                          affine) over the input of every hidden linear layer.
-                         Per-layer kernels only; not in ga_mlp_jvp_f32. */
+                         Per-layer kernels only. */
   int32_t pad_;
   int64_t ln_off[8];  /* gamma_l [round4(dims[l])] offset in params; beta_l follows */
   int64_t lnx_off[8]; /* normalised input of hidden layer l in the activation

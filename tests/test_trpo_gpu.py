@@ -169,10 +169,13 @@ def test_trpo_per_iterate_pins_against_real_reference(golden, tag):
                           rtol=1e-4), (k, kl)
 
 
-def test_fisher_vector_product_matches_double_backward():
+@pytest.mark.parametrize('options', ['default', 'layer_norm', 'relu_out_tanh'])
+def test_fisher_vector_product_matches_double_backward(options):
     """``A v`` (tangent forward, Gaussian metric, backward) against the
     reference's Hessian-vector product by double backward (oracle) on the same
-    parameters and observations."""
+    parameters and observations -- also through a LayerNorm in front of every
+    hidden layer (its tangent pass, ``ln_jvp_kernel``) and through relu hidden
+    layers with a tanh on the mean."""
     from garage_amd._dtypes import Box, EnvSpec  # noqa: F401
     from garage_amd.algos import TRPO
     from garage_amd.policies import GaussianMLPPolicy, GaussianMLPValueFunction
@@ -181,9 +184,23 @@ def test_fisher_vector_product_matches_double_backward():
     O, A, P, M = 11, 3, 16, 700
     spec = _spec(O, A, P)
     torch.manual_seed(3)
-    pol = GaussianMLPPolicy(spec, hidden_sizes=(64, 32))
+    import contextlib
+    pkw = {'default': {}, 'layer_norm': dict(layer_normalization=True),
+           'relu_out_tanh': dict(hidden_nonlinearity=torch.relu,
+                                 output_nonlinearity=torch.tanh)}[options]
+    pol = GaussianMLPPolicy(spec, hidden_sizes=(64, 32), **pkw)
+    if options == 'layer_norm':  # gamma / beta away from (1, 0)
+        gen = torch.Generator(device='cpu').manual_seed(2)
+        for name, view in pol.net.named_views():
+            if 'layer_normalization' in name:
+                view.add_(0.3 * torch.randn(view.shape, generator=gen).to(
+                    view.device))
     vf = GaussianMLPValueFunction(spec, hidden_sizes=(8, ))
     algo = TRPO(env_spec=spec, policy=pol, value_function=vf, sampler=None)
+    oracle_ctx = contextlib.ExitStack()
+    if options == 'relu_out_tanh':
+        oracle_ctx.enter_context(nets.hidden_nonlinearity(policy=torch.relu))
+        oracle_ctx.enter_context(nets.output_nonlinearity(policy=torch.tanh))
     rng = np.random.RandomState(0)
     obs = rng.randn(M, O).astype(np.float32)
     from garage_amd.engine import pad_rows
@@ -215,10 +232,11 @@ def test_fisher_vector_product_matches_double_backward():
         d_new = nets.gaussian_dist(params, nets.POLICY_PREFIX, x)
         return torch.distributions.kl.kl_divergence(d_old, d_new).mean()
 
-    f_Ax = build_hessian_vector_product(f_constraint,
-                                        [params[k] for k in keys], 1e-5)
-    v_ref = torch.from_numpy(_flat_no_pad(net, vec))
-    want = f_Ax(v_ref).detach().numpy()
+    with oracle_ctx:
+        f_Ax = build_hessian_vector_product(f_constraint,
+                                            [params[k] for k in keys], 1e-5)
+        v_ref = torch.from_numpy(_flat_no_pad(net, vec))
+        want = f_Ax(v_ref).detach().numpy()
     assert np.allclose(got, want, atol=2e-5 * max(1.0, np.abs(want).max()),
                        rtol=1e-4)
 
