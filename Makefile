@@ -13,7 +13,7 @@ FLAGS := --offload-arch=$(ARCH) -O3 -fPIC -std=c++17 -Wall -Wno-unused-function 
 
 all: $(OUT)/libgarage_amd.so
 
-$(OUT)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/prof.h $(CSRC)/small_step.h $(CSRC)/gemm_core.h $(CSRC)/loss_rows.h $(CSRC)/fused_train.h
+$(OUT)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/prof.h $(CSRC)/small_step.h $(CSRC)/gemm_core.h $(CSRC)/loss_rows.h $(CSRC)/fused_train.h $(CSRC)/rollout_dev.h
 	@mkdir -p $(OUT)
 	$(HIPCC) $(FLAGS) -c $< -o $@
 

@@ -189,6 +189,12 @@ SIGNATURES = {
                                               C.POINTER(RecordArgs),
                                               C.POINTER(NormArgs), ptr, c_i64,
                                               ptr, ptr]),
+    'ga_policy_env_step_fused_f32': (c_int, [C.POINTER(MlpDesc), ptr,
+                                             C.POINTER(HeadArgs),
+                                             C.POINTER(SynthEnv),
+                                             C.POINTER(RecordArgs),
+                                             C.POINTER(NormArgs), ptr]),
+    'ga_set_fused_env_step': (c_int, [c_int]),
     'ga_rollout_synth_steps': (c_int, [C.POINTER(MlpDesc), ptr,
                                        C.POINTER(HeadArgs),
                                        C.POINTER(SynthEnv),

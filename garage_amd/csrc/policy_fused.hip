@@ -20,6 +20,8 @@
 // per-layer path.
 #include "common.h"
 
+#include "rollout_dev.h"
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -87,6 +89,12 @@ struct FusedParams {
   float* act_buf;
   float* head_buf;
   int64_t ldh;
+  // env_step: the synthetic env's step, the NormalizedEnv statistics, the
+  // bookkeeping and the reset of finished envs follow in the same launch, each env by
+  // the thread that sampled its action (rollout_dev.h: the code of
+  // synth_step_record_kernel)
+  int env_step;
+  ga_rollout::EnvStepArgs es;
 };
 
 // Stage W[:, k0 : k0 + 32] of a [N][ldw] weight matrix: registers -> LDS.
@@ -260,6 +268,7 @@ __global__ __launch_bounds__(256) void policy_step_fused_kernel(FusedParams p) {
   __syncthreads();
 
   // ---- action head: one thread per env
+  int ended_len = 0;
   if (tid < ROWS) {
     const int64_t env = row0 + tid;
     if (env < p.n) {
@@ -321,8 +330,12 @@ __global__ __launch_bounds__(256) void policy_step_fused_kernel(FusedParams p) {
         p.action[env * p.lda] = (float)pick;
         p.act_buf[cell * p.lda] = (float)pick;
       }
+      if (p.env_step) ended_len = ga_rollout::env_step_one(p.es, env);
     }
   }
+  // (episode counts of the step: a wave-aggregated integer atomic; the envs of a
+  // workgroup all sit in wave 0)
+  if (p.env_step && wave == 0) ga_rollout::record_counts(p.es.p, ended_len);
 }
 
 // ---- the same network, training forward ---------------------------------------
@@ -537,8 +550,37 @@ extern "C" int ga_policy_step_fused_supported(const ga_mlp_desc_c* d) {
 
 // `head` of args is ignored (the means / scores stay on chip); everything else
 // as in ga_policy_head_sample.
+static int policy_step_launch(const ga_mlp_desc_c* d, const float* params,
+                              const ga_head_args_c* a, const ga_rollout::EnvStepArgs* es,
+                              hipStream_t stream);
+
 extern "C" int ga_policy_step_fused_f32(const ga_mlp_desc_c* d, const float* params,
                                         const ga_head_args_c* a, hipStream_t stream) {
+  return policy_step_launch(d, params, a, nullptr, stream);
+}
+
+// The same launch followed, per env, by the synthetic env's step + NormalizedEnv
+// statistics + bookkeeping + reset (what ga_synth_env_step_record_norm does as its
+// own launch): one launch per rollout step.  `a->action` is what the env is stepped
+// with.
+extern "C" int ga_policy_env_step_fused_f32(const ga_mlp_desc_c* d, const float* params,
+                                            const ga_head_args_c* a,
+                                            const ga_synth_env* env,
+                                            const ga_record_args* rec,
+                                            const ga_norm_args* norm,
+                                            hipStream_t stream) {
+  GA_REQUIRE(a, "ga_policy_env_step_fused_f32: null pointer");
+  ga_rollout::EnvStepArgs es;
+  int rc = ga_build_env_step(env, rec, norm, a->action, a->lda, a->obs,
+                             "ga_policy_env_step_fused_f32", &es);
+  if (rc) return rc;
+  GA_REQUIRE(es.e.n == a->n, "ga_policy_env_step_fused_f32: env count mismatch");
+  return policy_step_launch(d, params, a, &es, stream);
+}
+
+static int policy_step_launch(const ga_mlp_desc_c* d, const float* params,
+                              const ga_head_args_c* a, const ga_rollout::EnvStepArgs* es,
+                              hipStream_t stream) {
   GA_REQUIRE(d && params && a, "ga_policy_step_fused_f32: null pointer");
   GA_REQUIRE(ga_policy_step_fused_supported(d),
              "ga_policy_step_fused_f32: unsupported network shape");
@@ -561,6 +603,9 @@ extern "C" int ga_policy_step_fused_f32(const ga_mlp_desc_c* d, const float* par
   p.ldo = a->ldo; p.col = a->col; p.Tcap = a->Tcap; p.action = a->action;
   p.lda = a->lda; p.obs_buf = a->obs_buf; p.act_buf = a->act_buf;
   p.head_buf = a->head_buf; p.ldh = a->ldh;
+  p.env_step = es != nullptr;
+  if (es) p.es = *es;
+  else memset(&p.es, 0, sizeof(p.es));
   hipLaunchKernelGGL(policy_step_fused_kernel,
                      dim3((unsigned)ga_ceil_div(a->n, ROWS)), dim3(256), 0, stream, p);
   GA_CHECK_LAUNCH("policy_step_fused");

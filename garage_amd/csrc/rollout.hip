@@ -8,80 +8,10 @@
 // thread owns one env (its row tails are 16-B friendly: widths are padded to 4).
 #include "common.h"
 
+#include "rollout_dev.h"
+
 namespace {
-
-// ---- Philox4x32-10 (Random123; Salmon et al. SC'11) --------------------------
-struct U4 { uint32_t x, y, z, w; };
-
-__device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2,
-                                            uint32_t c3, uint32_t k0, uint32_t k1) {
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
-    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-    const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
-    const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
-    const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
-    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
-    k0 += 0x9E3779B9u;
-    k1 += 0xBB67AE85u;
-  }
-  return U4{c0, c1, c2, c3};
-}
-
-// uint32 -> fp32 uniform on [-sqrt3, sqrt3): every step exact or singly rounded,
-// so the CPU twin (oracle/envs.py) reproduces it bit for bit.
-__device__ __forceinline__ float u32_unit_variance(uint32_t u) {
-  const float f = __fmul_rn((float)(u >> 8), 1.1920928955078125e-07f);  // 2^-23
-  return __fmul_rn(__fsub_rn(f, 1.0f), 1.7320508f);
-}
-__device__ __forceinline__ float u32_unit_interval(uint32_t u) {
-  return ((float)(u >> 8) + 0.5f) * 5.9604644775390625e-08f;  // (0,1)
-}
-
-constexpr uint32_t STREAM_OBS = 0, STREAM_REWARD = 1, STREAM_LENGTH = 2;
-constexpr uint32_t STREAM_ACTION = 3;
-
-// ---- synthetic environment ---------------------------------------------------
-struct SynthEnv {
-  int64_t n;
-  int64_t env_id0;       // global id of env 0 of this shard
-  int obs_dim, act_dim, discrete;
-  int min_len, max_len;
-  uint32_t k0, k1;       // seed
-  int32_t* episode;      // [n] episode counter (-1 before the first reset)
-  int32_t* t;            // [n] steps taken in the current episode
-  int32_t* len;          // [n] length of the current episode
-};
-
-__device__ __forceinline__ void synth_obs(const SynthEnv& e, uint32_t env,
-                                          uint32_t episode, uint32_t t, float* out) {
-  for (int b = 0; b * 4 < e.obs_dim; ++b) {
-    const U4 r = philox4x32_10(env, episode, t, (STREAM_OBS << 16) | (uint32_t)b,
-                               e.k0, e.k1);
-    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
-    for (int j = 0; j < 4 && b * 4 + j < e.obs_dim; ++j)
-      out[b * 4 + j] = u32_unit_variance(w[j]);
-  }
-}
-
-__device__ __forceinline__ int synth_len(const SynthEnv& e, uint32_t env,
-                                         uint32_t episode) {
-  if (e.min_len >= e.max_len) return e.max_len;
-  const U4 r = philox4x32_10(env, episode, 0, STREAM_LENGTH << 16, e.k0, e.k1);
-  return e.min_len + (int)(r.x % (uint32_t)(e.max_len - e.min_len + 1));
-}
-
-// reset envs where mask != 0 (mask == null: all); writes the first observation.
-__device__ __forceinline__ void synth_reset_one(const SynthEnv& e, int64_t i,
-                                                float* obs, int64_t ldo) {
-  const uint32_t env = (uint32_t)(e.env_id0 + i);
-  const int ep = e.episode[i] + 1;
-  e.episode[i] = ep;
-  e.t[i] = 0;
-  e.len[i] = synth_len(e, env, (uint32_t)ep);
-  synth_obs(e, env, (uint32_t)ep, 0u, obs + i * ldo);
-}
+using namespace ga_rollout;
 
 __global__ __launch_bounds__(256) void synth_reset_kernel(SynthEnv e,
                                                           const uint8_t* mask,
@@ -92,80 +22,12 @@ __global__ __launch_bounds__(256) void synth_reset_kernel(SynthEnv e,
   synth_reset_one(e, i, obs, ldo);
 }
 
-// one env step: reward, step type and the (true) next observation.
-__device__ __forceinline__ void synth_step_one(
-    const SynthEnv& e, int64_t i, const float* actions, int64_t lda, const float* obs,
-    float* next_obs, int64_t ldo, float* reward, uint8_t* step_type) {
-  const uint32_t env = (uint32_t)(e.env_id0 + i);
-  const uint32_t ep = (uint32_t)e.episode[i];
-  const int t = e.t[i];
-  const U4 r = philox4x32_10(env, ep, (uint32_t)t, STREAM_REWARD << 16, e.k0, e.k1);
-  const float noise = u32_unit_variance(r.x);
-  const float* o = obs + i * ldo;
-  const float* a = actions + i * lda;
-  float shaped = 0.f;
-  if (e.discrete) {
-    shaped = o[((int)a[0]) % e.obs_dim];
-  } else {
-    const int m = min(e.act_dim, e.obs_dim);
-    for (int j = 0; j < m; ++j) {
-      const float aj = fminf(fmaxf(a[j], -1.f), 1.f);
-      shaped = __fadd_rn(shaped, __fmul_rn(aj, o[j]));  // no fma: matches numpy
-    }
-  }
-  reward[i] = __fadd_rn(noise, __fmul_rn(0.1f, shaped));
-  const int tn = t + 1;
-  e.t[i] = tn;
-  synth_obs(e, env, ep, (uint32_t)tn, next_obs + i * ldo);
-  // StepType.get_step_type (_dtypes.py:42-68): TIMEOUT wins over done
-  uint8_t st;
-  if (tn >= e.max_len) st = 3;
-  else if (tn >= e.len[i]) st = 2;
-  else if (tn == 1) st = 0;
-  else st = 1;
-  step_type[i] = st;
-}
-
 __global__ __launch_bounds__(256) void synth_step_kernel(
     SynthEnv e, const float* actions, int64_t lda, const float* obs, float* next_obs,
     int64_t ldo, float* reward, uint8_t* step_type) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= e.n) return;
   synth_step_one(e, i, actions, lda, obs, next_obs, ldo, reward, step_type);
-}
-
-// ---- NormalizedEnv observation / reward path -----------------------------------
-// envs/normalized_env.py:118-132,134-164: per-env exponential moving mean and
-// variance (float64 state, alpha = 0.001 by default); the mean is updated first,
-// the variance uses the NEW mean, and the value is normalised with the updated
-// statistics.  One thread per env; rows with mask == 0 are left untouched.
-__device__ __forceinline__ void obs_normalize_one(const float* src, float* dst,
-                                                  double* m, double* v, int obs_dim,
-                                                  double alpha) {
-  for (int j = 0; j < obs_dim; ++j) {
-    const double x = (double)src[j];
-    const double mn = (1.0 - alpha) * m[j] + alpha * x;
-    const double d = x - mn;
-    const double vn = (1.0 - alpha) * v[j] + alpha * (d * d);
-    m[j] = mn;
-    v[j] = vn;
-    dst[j] = (float)((x - mn) / (sqrt(vn) + 1e-8));
-  }
-}
-
-__device__ __forceinline__ float reward_normalize_one(float reward, double* mean,
-                                                      double* var, double alpha,
-                                                      double scale, int normalize) {
-  double r = (double)reward;
-  if (normalize) {  // normalized_env.py:126-132,153-164
-    const double mn = (1.0 - alpha) * *mean + alpha * r;
-    const double d = r - mn;
-    const double vn = (1.0 - alpha) * *var + alpha * (d * d);
-    *mean = mn;
-    *var = vn;
-    r = r / (sqrt(vn) + 1e-8);
-  }
-  return (float)(r * scale);
 }
 
 // src == dst normalises in place; otherwise the raw rows stay untouched (the
@@ -303,110 +165,19 @@ __global__ __launch_bounds__(256) void categorical_head_kernel(HeadParams p) {
   for (int j = 0; j < p.obs_dim; ++j) ob[j] = o[j];
 }
 
-// ---- per-step bookkeeping (VecWorker.step_episode, vec_worker.py:176-204) ------
-struct RecordParams {
-  int64_t n, col, Tcap;
-  int max_episode_length;
-  const float* reward;       // [n]
-  const uint8_t* step_type;  // [n]
-  const float* next_obs;     // [n, ldo]
-  int64_t ldo;
-  int obs_dim;
-  int32_t* ep_t;             // [n] steps so far in the running episode
-  float* rew_buf;            // [n, Tcap]
-  uint8_t* st_buf;           // [n, Tcap]
-  uint16_t* tail_buf;        // [n, Tcap] episode length at its last step, else 0
-  float* lastobs_buf;        // [n, Tcap, ldo] written at episode ends only
-  uint8_t* done;             // [n] 1 where the env must be reset
-  int32_t* step_eps;         // [Tcap] episodes finished at this step
-  int32_t* step_samples;     // [Tcap] their total length
-  int terminal_only;         // 1: only TERMINAL (not TIMEOUT) ends an episode
-};
-
-// bookkeeping of env i; returns the length of the episode that ended (else 0)
-__device__ __forceinline__ int record_one(const RecordParams& p, int64_t i) {
-  int ended_len = 0;
-  {
-    const int64_t cell = i * p.Tcap + p.col;
-    const int t = p.ep_t[i] + 1;
-    const uint8_t st = p.step_type[i];
-    // VecWorker ends an episode on any last step (vec_worker.py:198);
-    // FragmentWorker only on TERMINAL (fragment_worker.py:114-115)
-    const bool ended = (t >= p.max_episode_length) ||
-                       (p.terminal_only ? (st == 2) : (st >= 2));
-    p.rew_buf[cell] = p.reward[i];
-    p.st_buf[cell] = st;
-    p.tail_buf[cell] = ended ? (uint16_t)t : (uint16_t)0;
-    p.done[i] = ended ? 1 : 0;
-    p.ep_t[i] = ended ? 0 : t;
-    if (ended) {
-      ended_len = t;
-      const float* o = p.next_obs + i * p.ldo;
-      float* lo = p.lastobs_buf + cell * p.ldo;
-      for (int j = 0; j < p.obs_dim; ++j) lo[j] = o[j];
-    }
-  }
-  return ended_len;
-}
-
-// per-step completion counts: wave-aggregated integer atomics (deterministic:
-// integer adds commute)
-__device__ __forceinline__ void record_counts(const RecordParams& p, int ended_len) {
-  const uint64_t ballot = __ballot(ended_len > 0);
-  int sum = ended_len;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o, 64);
-  if ((threadIdx.x & 63) == 0 && ballot) {
-    atomicAdd(&p.step_eps[p.col], (int)__popcll(ballot));
-    atomicAdd(&p.step_samples[p.col], sum);
-  }
-}
-
 __global__ __launch_bounds__(256) void record_step_kernel(RecordParams p) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   record_counts(p, i < p.n ? record_one(p, i) : 0);
 }
-
-struct NormParams {
-  int norm_obs, norm_reward, scale_reward;
-  double* obs_mean;   // [n, obs_dim]
-  double* obs_var;
-  double obs_alpha;
-  double* rew_mean;   // [n]
-  double* rew_var;
-  double rew_alpha, rew_scale;
-};
 
 // env step -> (NormalizedEnv statistics + normalisation) -> bookkeeping -> reset
 // of the envs that finished, one thread per env and one launch (every stage only
 // touches env i's own state).  `raw_obs` / `raw_next` are the env's own
 // observations; p.next_obs is what the policy sees next and what is recorded as
 // the terminal observation -- the same buffer as raw_next without normalisation.
-__global__ __launch_bounds__(256) void synth_step_record_kernel(
-    SynthEnv e, RecordParams p, NormParams nm, const float* actions, int64_t lda,
-    const float* raw_obs, float* raw_next, float* seen_next, float* reward,
-    uint8_t* step_type) {
+__global__ __launch_bounds__(256) void synth_step_record_kernel(EnvStepArgs a) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  int ended_len = 0;
-  if (i < e.n) {
-    synth_step_one(e, i, actions, lda, raw_obs, raw_next, p.ldo, reward, step_type);
-    if (nm.norm_obs)  // normalized_env.py:134-151: statistics first, then the value
-      obs_normalize_one(raw_next + i * p.ldo, seen_next + i * p.ldo,
-                        nm.obs_mean + i * p.obs_dim, nm.obs_var + i * p.obs_dim,
-                        p.obs_dim, nm.obs_alpha);
-    if (nm.norm_reward || nm.scale_reward)
-      reward[i] = reward_normalize_one(reward[i], nm.rew_mean + i, nm.rew_var + i,
-                                       nm.rew_alpha, nm.rew_scale, nm.norm_reward);
-    ended_len = record_one(p, i);
-    if (ended_len > 0) {
-      synth_reset_one(e, i, raw_next, p.ldo);
-      if (nm.norm_obs)
-        obs_normalize_one(raw_next + i * p.ldo, seen_next + i * p.ldo,
-                          nm.obs_mean + i * p.obs_dim, nm.obs_var + i * p.obs_dim,
-                          p.obs_dim, nm.obs_alpha);
-    }
-  }
-  record_counts(p, ended_len);
+  record_counts(a.p, i < a.e.n ? env_step_one(a, i) : 0);
 }
 
 // ---- ragged -> packed ------------------------------------------------------------
@@ -667,25 +438,25 @@ struct ga_norm_args {
   float* raw_next_obs;   // ... and where its next observations go
 };
 
-extern "C" int ga_synth_env_step_record_norm(const ga_synth_env* env,
-                                             const ga_record_args* a,
-                                             const ga_norm_args* norm,
-                                             const float* actions, int64_t lda,
-                                             const float* obs, hipStream_t stream) {
-  int rc = check_env(env, "ga_synth_env_step_record");
+// Validation + conversion of the C-ABI arguments of one env step (also used by the
+// fused policy + env step of policy_fused.hip)
+int ga_build_env_step(const ga_synth_env* env, const ga_record_args* a,
+                      const ga_norm_args* norm, const float* actions, int64_t lda,
+                      const float* obs, const char* who, ga_rollout::EnvStepArgs* out) {
+  int rc = check_env(env, who);
   if (rc) return rc;
   GA_REQUIRE(a && a->reward && a->step_type && a->next_obs && a->ep_t && a->rew_buf &&
                  a->st_buf && a->tail_buf && a->lastobs_buf && a->done &&
                  a->step_eps && a->step_samples && actions && obs,
-             "ga_synth_env_step_record: null pointer");
+             "%s: null pointer", who);
   GA_REQUIRE(a->n == env->n && a->col >= 0 && a->col < a->Tcap,
-             "ga_synth_env_step_record: col %lld out of range (Tcap %lld)",
-             (long long)a->col, (long long)a->Tcap);
+             "%s: col %lld out of range (Tcap %lld)", who, (long long)a->col,
+             (long long)a->Tcap);
   GA_REQUIRE(a->max_episode_length >= 1 && a->max_episode_length <= 65535,
-             "ga_synth_env_step_record: max_episode_length must be in 1..65535");
+             "%s: max_episode_length must be in 1..65535", who);
   GA_REQUIRE(a->ldo >= env->obs_dim && a->obs_dim == env->obs_dim &&
                  lda >= (env->discrete ? 1 : env->act_dim),
-             "ga_synth_env_step_record: leading dimensions too small");
+             "%s: leading dimensions too small", who);
   RecordParams p;
   p.n = a->n; p.col = a->col; p.Tcap = a->Tcap;
   p.max_episode_length = a->max_episode_length; p.reward = a->reward;
@@ -708,18 +479,32 @@ extern "C" int ga_synth_env_step_record_norm(const ga_synth_env* env,
     nm.rew_scale = norm->reward_scale;
     GA_REQUIRE(!nm.norm_obs || (nm.obs_mean && nm.obs_var && norm->raw_obs &&
                                 norm->raw_next_obs),
-               "ga_synth_env_step_record_norm: observation statistics / raw buffers");
-    GA_REQUIRE(!nm.norm_reward || (nm.rew_mean && nm.rew_var),
-               "ga_synth_env_step_record_norm: reward statistics");
+               "%s: observation statistics / raw buffers", who);
+    GA_REQUIRE(!nm.norm_reward || (nm.rew_mean && nm.rew_var), "%s: reward statistics",
+               who);
     if (nm.norm_obs) {
       raw_obs = norm->raw_obs;
       raw_next = norm->raw_next_obs;
     }
   }
+  out->e = to_dev(env); out->p = p; out->nm = nm;
+  out->actions = actions; out->lda = lda; out->raw_obs = raw_obs; out->raw_next = raw_next;
+  out->seen_next = (float*)a->next_obs; out->reward = (float*)a->reward;
+  out->step_type = (uint8_t*)a->step_type;
+  return GA_OK;
+}
+
+extern "C" int ga_synth_env_step_record_norm(const ga_synth_env* env,
+                                             const ga_record_args* a,
+                                             const ga_norm_args* norm,
+                                             const float* actions, int64_t lda,
+                                             const float* obs, hipStream_t stream) {
+  EnvStepArgs args;
+  int rc = ga_build_env_step(env, a, norm, actions, lda, obs, "ga_synth_env_step_record",
+                             &args);
+  if (rc) return rc;
   hipLaunchKernelGGL(synth_step_record_kernel, dim3((unsigned)ga_ceil_div(a->n, 256)),
-                     dim3(256), 0, stream, to_dev(env), p, nm, actions, lda, raw_obs,
-                     raw_next, (float*)a->next_obs, (float*)a->reward,
-                     (uint8_t*)a->step_type);
+                     dim3(256), 0, stream, args);
   GA_CHECK_LAUNCH("synth_step_record");
   return GA_OK;
 }

@@ -6,10 +6,27 @@
 // Python/ctypes overhead per launch (~12 us) exceeds the device time of a step.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/garage_amd.h"
 
 void ga_set_error(const char* fmt, ...);
+
+// 1 (default): policy step and env step of a rollout step in ONE launch
+// (ga_policy_env_step_fused_f32) unless the actions are rescaled in between;
+// 0, or GARAGE_AMD_FUSED_ENV_STEP=0 in the environment: two launches
+static int g_fused_env_step = -1;
+extern "C" int ga_set_fused_env_step(int on) {
+  g_fused_env_step = on != 0;
+  return 0;
+}
+static int fused_env_step_on() {
+  if (g_fused_env_step < 0) {
+    const char* e = getenv("GARAGE_AMD_FUSED_ENV_STEP");
+    g_fused_env_step = (e && e[0] == '0') ? 0 : 1;
+  }
+  return g_fused_env_step;
+}
 
 extern "C" int ga_rollout_synth_steps(const ga_mlp_desc* desc, const float* params,
                                       const ga_head_args* head,
@@ -53,15 +70,25 @@ extern "C" int ga_rollout_synth_steps(const ga_mlp_desc* desc, const float* para
     h.col = head->col + s;
     h.step = head->step + (uint32_t)s;
     h.obs = cur;
-    int rc = ga_policy_step_fused_f32(desc, params, &h, stream);
-    if (rc) return rc;
-    // env step -> bookkeeping -> reset of the finished envs: one launch
     r.col = h.col;
     r.next_obs = nxt;
     if (norm) {
       nm.raw_obs = raw_cur;
       nm.raw_next_obs = raw_nxt;
     }
+    int rc;
+    if (fused_env_step_on() && !(norm && nm.act_low)) {
+      // policy step, env step, bookkeeping and reset of the finished envs: one launch
+      rc = ga_policy_env_step_fused_f32(desc, params, &h, env, &r, norm ? &nm : nullptr,
+                                        stream);
+      if (rc) return rc;
+      float* t = cur; cur = nxt; nxt = t;
+      t = raw_cur; raw_cur = raw_nxt; raw_nxt = t;
+      continue;
+    }
+    rc = ga_policy_step_fused_f32(desc, params, &h, stream);
+    if (rc) return rc;
+    // env step -> bookkeeping -> reset of the finished envs: one launch
     const float* env_action = h.action;
     if (norm && nm.act_low) {
       // NormalizedEnv.step: the wrapped env sees the rescaled, clipped action; the

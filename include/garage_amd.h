@@ -438,6 +438,17 @@ int ga_synth_env_step_record_norm(const ga_synth_env* env, const ga_record_args*
                                   const ga_norm_args* norm, const float* actions,
                                   int64_t lda, const float* obs, ga_stream_t stream);
 
+/* ga_policy_step_fused_f32 followed, per env and in the same launch, by what
+ * ga_synth_env_step_record_norm does (env step with `head->action`, NormalizedEnv
+ * statistics, bookkeeping, reset of the finished envs): one launch per rollout
+ * step of the synthetic env. */
+int ga_policy_env_step_fused_f32(const ga_mlp_desc* d, const float* params,
+                                 const ga_head_args* head, const ga_synth_env* env,
+                                 const ga_record_args* rec, const ga_norm_args* norm,
+                                 ga_stream_t stream);
+/* 1 (default): ga_rollout_synth_steps takes that launch (unless actions are
+ * rescaled between policy and env); 0: policy step and env step as two launches. */
+int ga_set_fused_env_step(int on);
 /* n_steps consecutive vectorised steps (fused policy step, synthetic env step,
  * bookkeeping, reset of finished envs) starting at head->col / head->step,
  * alternating the observation buffers obs_a (current) / obs_b; after an odd

@@ -229,6 +229,13 @@ int ga_policy_step_fused_f32(const ga_mlp_desc*, const float*, const ga_head_arg
   logf("policy_step col=%lld step=%u obs=%p", (long long)h->col, h->step, (void*)h->obs);
   return 0;
 }
+int ga_policy_env_step_fused_f32(const ga_mlp_desc*, const float*, const ga_head_args* h,
+                                 const ga_synth_env*, const ga_record_args* r,
+                                 const ga_norm_args* nm, ga_stream_t) {
+  logf("policy_env_step col=%lld step=%u obs=%p next=%p norm=%d", (long long)h->col,
+       h->step, (void*)h->obs, (void*)r->next_obs, nm != nullptr);
+  return 0;
+}
 int ga_synth_env_step_record_norm(const ga_synth_env*, const ga_record_args* r,
                                   const ga_norm_args* nm, const float* act, int64_t,
                                   const float* obs, ga_stream_t) {
@@ -468,10 +475,20 @@ int main() {
     Net pol(17, 64, 64, 6);
     CHECK(ga_rollout_synth_steps(&pol.d, pol.params.data(), &h, &env, &rec, A, B, nullptr,
                                  nullptr, nullptr, 3, nullptr) == 0);
-    CHECK(count("policy_step") == 3 && count("env_step") == 3);
+    // (one launch per step by default)
+    CHECK(count("policy_env_step") == 3 && count("policy_step ") == 0);
     char want[128];
+    snprintf(want, sizeof(want), "policy_env_step col=4 step=101 obs=%p next=%p",
+             (void*)B, (void*)A);
+    CHECK(count(want) == 1);
+    ga_set_fused_env_step(0);
+    g_log.clear();
+    CHECK(ga_rollout_synth_steps(&pol.d, pol.params.data(), &h, &env, &rec, A, B, nullptr,
+                                 nullptr, nullptr, 3, nullptr) == 0);
+    CHECK(count("policy_step") == 3 && count("env_step col") == 3);
     snprintf(want, sizeof(want), "env_step col=4 obs=%p next=%p", (void*)B, (void*)A);
     CHECK(count(want) == 1);
+    ga_set_fused_env_step(1);
     CHECK(ga_rollout_synth_steps(&pol.d, pol.params.data(), &h, &env, &rec, A, B, nullptr,
                                  nullptr, nullptr, 14, nullptr) != 0);  // past Tcap
   }
