@@ -44,7 +44,7 @@ def _make_shard(rank, n_eps=N_EPS):
 
 
 def _rank_main(rank, world, port, q, init_pol, init_vf, algo_name='ppo',
-               backend='gloo', minibatch=None, n_eps=None):
+               backend='gloo', minibatch=None, n_eps=None, hidden=(16, 16)):
     try:
         os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank),
                           WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
@@ -67,8 +67,8 @@ def _rank_main(rank, world, port, q, init_pol, init_vf, algo_name='ppo',
             comm = Comm()
         spec = EnvSpec(Box(-np.inf, np.inf, (O, )), Box(-np.inf, np.inf, (A, )),
                        max_episode_length=P)
-        pol = GaussianMLPPolicy(spec, hidden_sizes=(16, 16))
-        vf = GaussianMLPValueFunction(spec, hidden_sizes=(16, 16))
+        pol = GaussianMLPPolicy(spec, hidden_sizes=hidden)
+        vf = GaussianMLPValueFunction(spec, hidden_sizes=hidden)
         if rank == 0:  # rank 0's parameters must win (broadcast in shard_algo)
             pol.load_state_dict(init_pol)
             vf.load_state_dict(init_vf)
@@ -266,7 +266,7 @@ class _TwinComm:
         pass
 
 
-def _twin_algo(native, seed=0):
+def _twin_algo(native, seed=0, hidden=(16, 16), minibatch=16):
     """PPO whose gradient exchange goes through the C++ epoch loop's all-reduce
     hook (``native``) or through the Python minibatch loop's ``grad_hook``."""
     import ctypes as C
@@ -279,13 +279,13 @@ def _twin_algo(native, seed=0):
     spec = EnvSpec(Box(-np.inf, np.inf, (O, )), Box(-np.inf, np.inf, (A, )),
                    max_episode_length=P)
     torch.manual_seed(seed)
-    pol = GaussianMLPPolicy(spec, hidden_sizes=(16, 16))
-    vf = GaussianMLPValueFunction(spec, hidden_sizes=(16, 16))
+    pol = GaussianMLPPolicy(spec, hidden_sizes=hidden)
+    vf = GaussianMLPValueFunction(spec, hidden_sizes=hidden)
     opt = (torch.optim.Adam, dict(lr=1e-3))
     algo = PPO(env_spec=spec, policy=pol, value_function=vf, sampler=None,
-               policy_optimizer=OptimizerWrapper(opt, pol, 2, 16,
+               policy_optimizer=OptimizerWrapper(opt, pol, 2, minibatch,
                                                  permutation='device', seed=5),
-               vf_optimizer=OptimizerWrapper(opt, vf, 2, 16,
+               vf_optimizer=OptimizerWrapper(opt, vf, 2, minibatch,
                                              permutation='device', seed=6))
     comm = _TwinComm()
     algo._comm = comm
@@ -340,6 +340,51 @@ def test_native_dp_branch_equals_python_loop_with_a_twin_rank(overlap):
     assert torch.equal(outs[0][0], outs[1][0])
     assert torch.equal(outs[0][1], outs[1][1])
     assert outs[0][2] == outs[1][2]
+
+
+@pytest.mark.parametrize('overlap', [True, False])
+@pytest.mark.parametrize('hidden', [(64, 64), (128, 128), (256, 256), (96, 256)])
+def test_native_dp_branch_of_the_fused_step_kernels_with_a_twin_rank(hidden, overlap):
+    """What the multi-GPU bench runs: the FUSED optimizer-step kernels (one-launch
+    narrow step at 2 x 64; first layer + last hidden layer + head + loss, data
+    gradient + first-layer weight gradient, region reduction WITHOUT Adam at
+    128 / 256; (96, 256): the first layer as its own launch) -> all-reduce hook ->
+    Adam, inside the C++ epoch loops on one or two streams, against the Python
+    minibatch loop with the same exchange (``phase = 1`` + ``grad_hook`` +
+    ``adam_step``): same kernels, same bits.  The fused kernels are really taken
+    (switching them off changes the bits)."""
+    from garage_amd import _lib
+    from garage_amd._dtypes import EpisodeBatch, StepType
+    lib = _lib.load()
+    d = _make_shard(0, 60)
+    st = np.asarray([StepType(int(s)) for s in d['step_types']], dtype=object)
+
+    def run(native, fused=True):
+        spec, pol, vf, algo, keep = _twin_algo(native, hidden=hidden,
+                                               minibatch=100)
+        algo.overlap_updates = overlap
+        batch = EpisodeBatch(env_spec=spec, episode_infos={},
+                             observations=d['observations'],
+                             last_observations=d['last_observations'],
+                             actions=d['actions'], rewards=d['rewards'],
+                             env_infos={}, agent_infos={}, step_types=st,
+                             lengths=d['lengths'])
+        assert algo._native_update_ok() == native
+        try:
+            lib.ga_set_fused_train(1 if fused else 0)
+            algo._train_once(0, batch)
+        finally:
+            lib.ga_set_fused_train(1)
+        del keep
+        return (pol.net.params.clone(), vf.net.params.clone(),
+                dict(algo.last_tabular), (pol.net.adam_steps, vf.net.adam_steps))
+
+    native, python, unfused = run(True), run(False), run(True, fused=False)
+    assert torch.equal(native[0], python[0]) and torch.equal(native[1], python[1])
+    assert native[2] == python[2] and native[3] == python[3]
+    assert native[3][0] > 2  # several minibatches per pass
+    assert not torch.equal(native[0], unfused[0])
+    assert float((native[0] - unfused[0]).abs().max()) < 5e-4
 
 
 @pytest.mark.timeout(300)
@@ -470,3 +515,71 @@ def test_one_rank_nccl_group_takes_the_rccl_branch_of_the_epoch_loop():
     for k in ('policy/LossBefore', 'policy/LossAfter', 'policy/KL',
               'vf/LossBefore', 'vf/LossAfter'):
         assert np.isclose(got['tab'][k], want[k], atol=2e-5, rtol=2e-5), k
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize('hidden', [(64, 64), (256, 256)])
+def test_one_rank_rccl_through_the_fused_step_kernels(hidden):
+    """The bench's multi-GPU configuration as far as one GPU allows: a real ``nccl``
+    (= RCCL) process group of one rank, the library-owned communicators, the fused
+    optimizer-step kernels with minibatches on two streams, one real
+    ``ncclAllReduce`` per optimizer step and network.  A one-rank sum is the
+    identity, so the iteration must equal the same iteration without any process
+    group."""
+    from garage_amd._dtypes import Box, EnvSpec, EpisodeBatch, StepType
+    from garage_amd.algos import PPO
+    from garage_amd.optimizers import OptimizerWrapper
+    from garage_amd.policies import GaussianMLPPolicy, GaussianMLPValueFunction
+    from oracle import networks as nets
+    rng = np.random.RandomState(1)
+    init_pol = nets.init_gaussian_mlp(rng, nets.POLICY_PREFIX, O, A, hidden,
+                                      min_std=1e-6)
+    init_vf = nets.init_gaussian_mlp(rng, nets.VALUE_PREFIX, O, 1, hidden)
+    n_eps = (60, )
+    # data parallel runs split a pass EVENLY into K minibatches (every rank must
+    # take the same number of steps); a minibatch size that divides the sample
+    # count makes that the same split as the single-process one
+    S = int(_make_shard(0, n_eps[0])['lengths'].sum())
+    mb = next(S // k for k in (4, 3, 5, 6, 2, 1) if S % k == 0)
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    proc = ctx.Process(target=_rank_main,
+                       args=(0, 1, port, q, init_pol, init_vf, 'ppo', 'nccl', mb,
+                             n_eps, hidden))
+    proc.start()
+    rank, status, got = q.get(timeout=240)
+    proc.join(30)
+    assert status == 'ok', status
+    assert got['native_comm'] and got['native_loop']
+    # the same iteration in this process, no process group
+    spec = EnvSpec(Box(-np.inf, np.inf, (O, )), Box(-np.inf, np.inf, (A, )),
+                   max_episode_length=P)
+    pol = GaussianMLPPolicy(spec, hidden_sizes=hidden)
+    vf = GaussianMLPValueFunction(spec, hidden_sizes=hidden)
+    pol.load_state_dict(init_pol)
+    vf.load_state_dict(init_vf)
+    opt = (torch.optim.Adam, dict(lr=1e-3))
+    algo = PPO(env_spec=spec, policy=pol, value_function=vf, sampler=None,
+               policy_optimizer=OptimizerWrapper(opt, pol, 3, mb),
+               vf_optimizer=OptimizerWrapper(opt, vf, 3, mb))
+    d = _make_shard(0, n_eps[0])
+    np.random.seed(50)
+    batch = EpisodeBatch(env_spec=spec, episode_infos={},
+                         observations=d['observations'],
+                         last_observations=d['last_observations'],
+                         actions=d['actions'], rewards=d['rewards'], env_infos={},
+                         agent_infos={},
+                         step_types=np.asarray([StepType(int(s))
+                                                for s in d['step_types']],
+                                               dtype=object),
+                         lengths=d['lengths'])
+    algo._train_once(0, batch)
+    assert got['adam_steps'] == (pol.net.adam_steps, vf.net.adam_steps)
+    assert got['adam_steps'][0] == 3 * (S // mb)
+    for k, v in pol.state_dict().items():
+        assert np.allclose(got[k], v.numpy(), atol=1e-6), k
+    for k, v in vf.state_dict().items():
+        assert np.allclose(got['vf:' + k], v.numpy(), atol=1e-6), k
+    for k, v in algo.last_tabular.items():
+        assert np.isclose(got['tab'][k], v, atol=1e-6, rtol=1e-6), k
