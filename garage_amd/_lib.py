@@ -114,6 +114,7 @@ SIGNATURES = {
     'ga_small_step_launches': (c_i64, []),
     'ga_small_step_debug': (c_int, [ptr]),
     'ga_narrow_step_debug': (c_int, [ptr]),
+    'ga_policy_step_debug': (c_int, [ptr]),
     'ga_fused_fwd_debug': (c_int, [ptr]),
     'ga_fused_fwd_debug_skew': (c_int, [ptr, c_int]),
     'ga_fused_dgrad_debug': (c_int, [ptr, c_int, c_int]),
@@ -193,7 +194,7 @@ SIGNATURES = {
                                              C.POINTER(HeadArgs),
                                              C.POINTER(SynthEnv),
                                              C.POINTER(RecordArgs),
-                                             C.POINTER(NormArgs), ptr]),
+                                             C.POINTER(NormArgs), c_i64, ptr]),
     'ga_set_fused_env_step': (c_int, [c_int]),
     'ga_rollout_synth_steps': (c_int, [C.POINTER(MlpDesc), ptr,
                                        C.POINTER(HeadArgs),

@@ -95,7 +95,17 @@ struct FusedParams {
   // synth_step_record_kernel)
   int env_step;
   ga_rollout::EnvStepArgs es;
+  // n_steps > 1 (needs env_step): the workgroup takes its envs through n_steps
+  // consecutive rollout steps in this one launch -- nothing couples the envs of
+  // different workgroups within a rollout -- alternating between the two
+  // observation buffers (obs / es.seen_next and, with observation normalisation,
+  // es.raw_obs / es.raw_next)
+  int n_steps;
+  long long* dbg;  // developer hook: phase timestamps of workgroup 0
 };
+
+#define PS_STAMP(i) \
+  if (p.dbg && blockIdx.x == 0 && threadIdx.x == 0) p.dbg[i] = wall_clock64()
 
 // Stage W[:, k0 : k0 + 32] of a [N][ldw] weight matrix: registers -> LDS.
 struct WeightStage {
@@ -130,6 +140,32 @@ struct WeightStage {
   }
 };
 
+// NG groups of 8 k of a hidden layer whose B operands sit in registers.
+template <int NG>
+__device__ __forceinline__ void resident_layer(const float* __restrict__ A,
+                                               const float (&wreg)[2][HMAX / 2],
+                                               f32x16 (&acc)[2]) {
+#pragma unroll
+  for (int G = 0; G < NG; ++G) {
+    const float4 av = *reinterpret_cast<const float4*>(A + 8 * G);
+    const float a4[4] = {av.x, av.y, av.z, av.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q], wreg[j][4 * G + q], acc[j],
+                                                      0, 0, 0);
+  }
+}
+
+// RES (a whole rollout in one launch, observations no wider than one k chunk, one
+// or two hidden layers): the weights stay on the CU for all the steps -- the first
+// layer's chunk in wst[0], the output layer's rows in wst[1], and the second hidden
+// layer's [N][K] matrix in REGISTERS (each lane holds the 2 x 128 B operands its
+// MFMAs consume: 256 of the 512 registers a wave has at one wave per SIMD), so that
+// layer runs without a barrier or a weight fetch.  Same k order per accumulator as
+// the streamed loop: bit-identical.
+template <bool RES>
 __global__ __launch_bounds__(256) void policy_step_fused_kernel(FusedParams p) {
   __shared__ __attribute__((aligned(16))) float act[2][ROWS * LDACT];
   __shared__ __attribute__((aligned(16))) float wst[2][HMAX * LDW];
@@ -139,9 +175,71 @@ __global__ __launch_bounds__(256) void policy_step_fused_kernel(FusedParams p) {
   const int half = lane >> 5, l31 = lane & 31;
   const int64_t row0 = (int64_t)blockIdx.x * ROWS;
   const int L = p.n_layers;
+  float wreg[2][HMAX / 2];
+  if constexpr (RES) {
+    // (the register-resident layer multiplies whole tiles: no stale columns)
+    for (int e = tid; e < ROWS * LDACT; e += 256) act[0][e] = act[1][e] = 0.f;
+    {
+      const int K = p.dims[0], N = p.dims[1];
+      WeightStage ws;
+      ws.load(p.params + p.w_off[0], (K + 3) & ~3, N, K, 0);
+      ws.store(wst[0], N, K, 0);
+    }
+    if (L == 3) {
+      const int K = p.dims[1], N = p.dims[2];
+      const int ldw = (K + 3) & ~3;
+      const float* W = p.params + p.w_off[1];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int ncol = wave * 64 + 32 * j + l31;
+#pragma unroll
+        for (int G = 0; G < HMAX / 8; ++G) {
+          const int k = 8 * G + 4 * half;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (ncol < N && k < K) {
+            v = *reinterpret_cast<const float4*>(W + (int64_t)ncol * ldw + k);
+            if (k + 1 >= K) v.y = 0.f;
+            if (k + 2 >= K) v.z = 0.f;
+            if (k + 3 >= K) v.w = 0.f;
+          }
+          wreg[j][4 * G + 0] = v.x; wreg[j][4 * G + 1] = v.y;
+          wreg[j][4 * G + 2] = v.z; wreg[j][4 * G + 3] = v.w;
+        }
+      }
+    }
+    {
+      const int K = p.dims[L - 1], N = p.dims[L];
+      const int ldw = (K + 3) & ~3;
+      const float* W = p.params + p.w_off[L - 1];
+      for (int e = tid; e < N * (ldw / 4); e += 256)
+        reinterpret_cast<float4*>(wst[1])[e] = reinterpret_cast<const float4*>(W)[e];
+    }
+    __syncthreads();
+  }
+  for (int sidx = 0; sidx < p.n_steps; ++sidx) {
+  // this step's column, Philox counter and observation buffers (they swap roles
+  // every step)
+  const int64_t col = p.col + sidx;
+  const uint32_t step = p.step + (uint32_t)sidx;
+  const bool odd = sidx & 1;
+  const float* obs = odd ? p.es.seen_next : p.obs;
+  ga_rollout::EnvStepArgs es = p.es;
+  if (p.env_step) {
+    es.p.col = col;
+    es.seen_next = odd ? const_cast<float*>(p.obs) : p.es.seen_next;
+    es.p.next_obs = es.seen_next;
+    if (p.es.raw_next != p.es.seen_next) {  // NormalizedEnv: the env's own rows
+      es.raw_obs = odd ? p.es.raw_next : p.es.raw_obs;
+      es.raw_next = odd ? const_cast<float*>(p.es.raw_obs) : p.es.raw_next;
+    } else {
+      es.raw_obs = obs;
+      es.raw_next = es.seen_next;
+    }
+  }
 
   // ---- observations -> act[0] (zero padded to a multiple of the k chunk) and
   //      into the rollout buffer (the list append of vec_worker.py:188)
+  PS_STAMP(0);
   const int in_w = p.dims[0];
   const int in_pad = (in_w + KC - 1) / KC * KC;
   for (int e = tid; e < ROWS * in_pad; e += 256) {
@@ -149,12 +247,13 @@ __global__ __launch_bounds__(256) void policy_step_fused_kernel(FusedParams p) {
     const int64_t env = row0 + r;
     float v = 0.f;
     if (env < p.n && c < in_w) {
-      v = p.obs[env * p.ldo + c];
-      p.obs_buf[(env * p.Tcap + p.col) * p.ldo + c] = v;
+      v = obs[env * p.ldo + c];
+      p.obs_buf[(env * p.Tcap + col) * p.ldo + c] = v;
     }
     act[0][r * LDACT + c] = v;
   }
   __syncthreads();
+  PS_STAMP(1);
 
   // ---- hidden layers on the matrix cores
   int cur = 0;
@@ -171,6 +270,38 @@ __global__ __launch_bounds__(256) void policy_step_fused_kernel(FusedParams p) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    if constexpr (RES) {
+      if (wave_on) {
+        const float* A = act[cur] + l31 * LDACT;
+        if (l == 0) {
+          const float* B = wst[0];
+#pragma unroll
+          for (int g = 0; g < KC / 8; ++g) {
+            const float4 av = *reinterpret_cast<const float4*>(A + 8 * g + 4 * half);
+            const float a4[4] = {av.x, av.y, av.z, av.w};
+            float b4[2][4];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const float4 bv = *reinterpret_cast<const float4*>(
+                  B + (n0 + 32 * j + l31) * LDW + 8 * g + 4 * half);
+              b4[j][0] = bv.x; b4[j][1] = bv.y; b4[j][2] = bv.z; b4[j][3] = bv.w;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+              for (int j = 0; j < 2; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q], b4[j][q], acc[j],
+                                                              0, 0, 0);
+          }
+        } else {
+          // (straight-line per depth: a branch per k group would make the compiler
+          // move the accumulators at every join; the tiles are zero beyond K)
+          if (K <= 64) resident_layer<8>(A + 4 * half, wreg, acc);
+          else if (K <= 128) resident_layer<16>(A + 4 * half, wreg, acc);
+          else resident_layer<32>(A + 4 * half, wreg, acc);
+        }
+      }
+    } else {
     WeightStage ws;
     ws.load(W, ldw, N, K, 0);
     ws.store(wst[0], N, K, 0);
@@ -203,6 +334,8 @@ __global__ __launch_bounds__(256) void policy_step_fused_kernel(FusedParams p) {
       if (more) ws.store(wst[(s + 1) & 1], N, K, (s + 1) * KC);
       __syncthreads();
     }
+    }  // streamed weights
+    (void)nk;
     // bias + tanh -> the other activation tile (zero padded to the k chunk)
     float* out = act[cur ^ 1];
     const int n_pad = (N + KC - 1) / KC * KC;
@@ -221,6 +354,7 @@ __global__ __launch_bounds__(256) void policy_step_fused_kernel(FusedParams p) {
     }
     __syncthreads();
     cur ^= 1;
+    PS_STAMP(2 + l);
   }
 
   // ---- narrow output layer: its weights go to LDS once; 8 lanes per row hold
@@ -230,9 +364,10 @@ __global__ __launch_bounds__(256) void policy_step_fused_kernel(FusedParams p) {
     const int ldw = (K + 3) & ~3;
     const float* W = p.params + p.w_off[L - 1];
     const float* bias = p.params + p.b_off[L - 1];
-    float* wo = wst[0];  // [N][ldw]: N <= 32, ldw <= 256 -> fits one stage
-    for (int e = tid; e < N * (ldw / 4); e += 256)
-      reinterpret_cast<float4*>(wo)[e] = reinterpret_cast<const float4*>(W)[e];
+    float* wo = wst[RES ? 1 : 0];  // [N][ldw]: N <= 32, ldw <= 256 -> fits one stage
+    if constexpr (!RES)
+      for (int e = tid; e < N * (ldw / 4); e += 256)
+        reinterpret_cast<float4*>(wo)[e] = reinterpret_cast<const float4*>(W)[e];
     const int r = tid >> 3, part = tid & 7;
     const float* a = act[cur] + r * LDACT;
     float4 xr[HMAX / 32];
@@ -266,6 +401,7 @@ __global__ __launch_bounds__(256) void policy_step_fused_kernel(FusedParams p) {
     }
   }
   __syncthreads();
+  PS_STAMP(10);
 
   // ---- action head: one thread per env
   int ended_len = 0;
@@ -273,7 +409,7 @@ __global__ __launch_bounds__(256) void policy_step_fused_kernel(FusedParams p) {
     const int64_t env = row0 + tid;
     if (env < p.n) {
       const int N = p.dims[L];
-      const int64_t cell = env * p.Tcap + p.col;
+      const int64_t cell = env * p.Tcap + col;
       const float* h = head[tid];
       if (p.head_buf) {
         // agent_info: Gaussian mean (probabilities are written below)
@@ -290,7 +426,7 @@ __global__ __launch_bounds__(256) void policy_step_fused_kernel(FusedParams p) {
             for (int j = 0; j < 4 && b * 4 + j < N; ++j)
               z[j] = p.noise[env * p.ldn + b * 4 + j];
           } else {
-            const U4 rr = philox4x32_10((uint32_t)(p.env_id0 + env), p.step,
+            const U4 rr = philox4x32_10((uint32_t)(p.env_id0 + env), step,
                                         (uint32_t)b, 3u << 16, p.k0, p.k1);
             box_muller(rr.x, rr.y, &z[0], &z[1]);
             box_muller(rr.z, rr.w, &z[2], &z[3]);
@@ -313,7 +449,7 @@ __global__ __launch_bounds__(256) void policy_step_fused_kernel(FusedParams p) {
         if (p.noise) {
           u = p.noise[env * p.ldn];
         } else {
-          const U4 rr = philox4x32_10((uint32_t)(p.env_id0 + env), p.step, 0u,
+          const U4 rr = philox4x32_10((uint32_t)(p.env_id0 + env), step, 0u,
                                       3u << 16, p.k0, p.k1);
           u = unit_interval(rr.x);
         }
@@ -330,12 +466,17 @@ __global__ __launch_bounds__(256) void policy_step_fused_kernel(FusedParams p) {
         p.action[env * p.lda] = (float)pick;
         p.act_buf[cell * p.lda] = (float)pick;
       }
-      if (p.env_step) ended_len = ga_rollout::env_step_one(p.es, env);
+      if (p.env_step) ended_len = ga_rollout::env_step_one(es, env);
     }
   }
   // (episode counts of the step: a wave-aggregated integer atomic; the envs of a
   // workgroup all sit in wave 0)
-  if (p.env_step && wave == 0) ga_rollout::record_counts(p.es.p, ended_len);
+  if (p.env_step && wave == 0) ga_rollout::record_counts(es.p, ended_len);
+  PS_STAMP(11);
+  // the next step reads what the env threads just wrote (same workgroup: one CU,
+  // one L1) and reuses the LDS tiles
+  if (sidx + 1 < p.n_steps) __syncthreads();
+  }  // steps
 }
 
 // ---- the same network, training forward ---------------------------------------
@@ -552,35 +693,61 @@ extern "C" int ga_policy_step_fused_supported(const ga_mlp_desc_c* d) {
 // as in ga_policy_head_sample.
 static int policy_step_launch(const ga_mlp_desc_c* d, const float* params,
                               const ga_head_args_c* a, const ga_rollout::EnvStepArgs* es,
-                              hipStream_t stream);
+                              int64_t n_steps, hipStream_t stream);
+
+static bool g_ps_no_resident = getenv("GARAGE_AMD_ROLLOUT_RESIDENT") &&
+                               atoi(getenv("GARAGE_AMD_ROLLOUT_RESIDENT")) == 0;
+static long long* g_ps_dbg = nullptr;
+// developer hook: phase timestamps (100 MHz wall clock) of workgroup 0 of the most
+// recent fused rollout step -- first call arms it, second call reads 16 values back
+// (0 start, 1 observations staged, 2 + l hidden layer l done, 10 output layer,
+// 11 sampled + env stepped)
+extern "C" int ga_policy_step_debug(long long* host_out16) {
+  if (!g_ps_dbg) {
+    if (hipMalloc(&g_ps_dbg, 16 * sizeof(long long)) != hipSuccess) return -1;
+    (void)hipMemset(g_ps_dbg, 0, 16 * sizeof(long long));
+    return 1;
+  }
+  (void)hipDeviceSynchronize();
+  return hipMemcpy(host_out16, g_ps_dbg, 16 * sizeof(long long), hipMemcpyDeviceToHost) ==
+                 hipSuccess ? 0 : -1;
+}
 
 extern "C" int ga_policy_step_fused_f32(const ga_mlp_desc_c* d, const float* params,
                                         const ga_head_args_c* a, hipStream_t stream) {
-  return policy_step_launch(d, params, a, nullptr, stream);
+  return policy_step_launch(d, params, a, nullptr, 1, stream);
 }
 
 // The same launch followed, per env, by the synthetic env's step + NormalizedEnv
 // statistics + bookkeeping + reset (what ga_synth_env_step_record_norm does as its
-// own launch): one launch per rollout step.  `a->action` is what the env is stepped
-// with.
+// own launch), for n_steps consecutive rollout steps: every workgroup takes its 32
+// envs through all of them (nothing couples envs within a rollout), alternating
+// between `a->obs` and `rec->next_obs` (and the raw pair of `norm`).  `a->action` is
+// what the env is stepped with.
 extern "C" int ga_policy_env_step_fused_f32(const ga_mlp_desc_c* d, const float* params,
                                             const ga_head_args_c* a,
                                             const ga_synth_env* env,
                                             const ga_record_args* rec,
-                                            const ga_norm_args* norm,
+                                            const ga_norm_args* norm, int64_t n_steps,
                                             hipStream_t stream) {
-  GA_REQUIRE(a, "ga_policy_env_step_fused_f32: null pointer");
+  GA_REQUIRE(a && rec, "ga_policy_env_step_fused_f32: null pointer");
+  GA_REQUIRE(n_steps >= 1 && a->col + n_steps <= a->Tcap,
+             "ga_policy_env_step_fused_f32: steps exceed the rollout buffer");
+  GA_REQUIRE(!a->noise || n_steps == 1,
+             "ga_policy_env_step_fused_f32: teacher-forced noise is per step");
   ga_rollout::EnvStepArgs es;
   int rc = ga_build_env_step(env, rec, norm, a->action, a->lda, a->obs,
                              "ga_policy_env_step_fused_f32", &es);
   if (rc) return rc;
   GA_REQUIRE(es.e.n == a->n, "ga_policy_env_step_fused_f32: env count mismatch");
-  return policy_step_launch(d, params, a, &es, stream);
+  GA_REQUIRE(es.p.col == a->col && es.p.col + n_steps <= es.p.Tcap,
+             "ga_policy_env_step_fused_f32: record columns do not match the policy's");
+  return policy_step_launch(d, params, a, &es, n_steps, stream);
 }
 
 static int policy_step_launch(const ga_mlp_desc_c* d, const float* params,
                               const ga_head_args_c* a, const ga_rollout::EnvStepArgs* es,
-                              hipStream_t stream) {
+                              int64_t n_steps, hipStream_t stream) {
   GA_REQUIRE(d && params && a, "ga_policy_step_fused_f32: null pointer");
   GA_REQUIRE(ga_policy_step_fused_supported(d),
              "ga_policy_step_fused_f32: unsupported network shape");
@@ -603,11 +770,19 @@ static int policy_step_launch(const ga_mlp_desc_c* d, const float* params,
   p.ldo = a->ldo; p.col = a->col; p.Tcap = a->Tcap; p.action = a->action;
   p.lda = a->lda; p.obs_buf = a->obs_buf; p.act_buf = a->act_buf;
   p.head_buf = a->head_buf; p.ldh = a->ldh;
+  p.dbg = g_ps_dbg;
   p.env_step = es != nullptr;
+  p.n_steps = (int)n_steps;
   if (es) p.es = *es;
   else memset(&p.es, 0, sizeof(p.es));
-  hipLaunchKernelGGL(policy_step_fused_kernel,
-                     dim3((unsigned)ga_ceil_div(a->n, ROWS)), dim3(256), 0, stream, p);
+  const dim3 grid((unsigned)ga_ceil_div(a->n, ROWS));
+  // a whole rollout in one launch keeps the weights on the CU (see the kernel)
+  const bool resident = n_steps > 1 && d->dims[0] <= KC &&
+                        (d->n_layers == 2 || d->n_layers == 3) && !g_ps_no_resident;
+  if (resident)
+    hipLaunchKernelGGL(policy_step_fused_kernel<true>, grid, dim3(256), 0, stream, p);
+  else
+    hipLaunchKernelGGL(policy_step_fused_kernel<false>, grid, dim3(256), 0, stream, p);
   GA_CHECK_LAUNCH("policy_step_fused");
   return GA_OK;
 }

@@ -66,6 +66,19 @@ extern "C" int ga_rollout_synth_steps(const ga_mlp_desc* desc, const float* para
   ga_record_args r = *rec;
   ga_norm_args nm;
   if (norm) nm = *norm;
+  if (fused_env_step_on() && !(norm && nm.act_low) && !head->noise && n_steps >= 1) {
+    // every rollout step -- policy, env, bookkeeping, reset of the finished envs --
+    // in ONE launch for all n_steps: a workgroup owns its envs for the whole rollout
+    r.col = h.col;
+    r.next_obs = nxt;
+    h.obs = cur;
+    if (norm) {
+      nm.raw_obs = raw_cur;
+      nm.raw_next_obs = raw_nxt;
+    }
+    return ga_policy_env_step_fused_f32(desc, params, &h, env, &r, norm ? &nm : nullptr,
+                                        n_steps, stream);
+  }
   for (int64_t s = 0; s < n_steps; ++s) {
     h.col = head->col + s;
     h.step = head->step + (uint32_t)s;
@@ -77,15 +90,6 @@ extern "C" int ga_rollout_synth_steps(const ga_mlp_desc* desc, const float* para
       nm.raw_next_obs = raw_nxt;
     }
     int rc;
-    if (fused_env_step_on() && !(norm && nm.act_low)) {
-      // policy step, env step, bookkeeping and reset of the finished envs: one launch
-      rc = ga_policy_env_step_fused_f32(desc, params, &h, env, &r, norm ? &nm : nullptr,
-                                        stream);
-      if (rc) return rc;
-      float* t = cur; cur = nxt; nxt = t;
-      t = raw_cur; raw_cur = raw_nxt; raw_nxt = t;
-      continue;
-    }
     rc = ga_policy_step_fused_f32(desc, params, &h, stream);
     if (rc) return rc;
     // env step -> bookkeeping -> reset of the finished envs: one launch

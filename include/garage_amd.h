@@ -174,6 +174,8 @@ int64_t ga_small_step_launches(void); /* launches so far (tests, diagnostics) */
 int ga_small_step_debug(long long* host_out16);
 /* the same for the one-launch step of 2 x 32 / 2 x 64 networks (narrow_step.hip) */
 int ga_narrow_step_debug(long long* host_out16);
+/* ... for the fused rollout step (policy_fused.hip) */
+int ga_policy_step_debug(long long* host_out16);
 /* ... and for the fused last-hidden-layer + head + loss kernel (fused_train.hip) */
 int ga_fused_fwd_debug(long long* host_out16);
 /* (start, end of the k-loop, end) of the first n <= 4096 workgroups of that launch */
@@ -440,12 +442,16 @@ int ga_synth_env_step_record_norm(const ga_synth_env* env, const ga_record_args*
 
 /* ga_policy_step_fused_f32 followed, per env and in the same launch, by what
  * ga_synth_env_step_record_norm does (env step with `head->action`, NormalizedEnv
- * statistics, bookkeeping, reset of the finished envs): one launch per rollout
- * step of the synthetic env. */
+ * statistics, bookkeeping, reset of the finished envs), for n_steps consecutive
+ * rollout steps of the synthetic env in ONE launch: a workgroup takes its 32 envs
+ * through all of them (envs do not interact within a rollout), alternating between
+ * the buffers head->obs / rec->next_obs (norm: raw_obs / raw_next_obs); columns
+ * head->col .. head->col + n_steps - 1, Philox counters head->step + s.  Device
+ * noise only (head->noise must be null for n_steps > 1). */
 int ga_policy_env_step_fused_f32(const ga_mlp_desc* d, const float* params,
                                  const ga_head_args* head, const ga_synth_env* env,
                                  const ga_record_args* rec, const ga_norm_args* norm,
-                                 ga_stream_t stream);
+                                 int64_t n_steps, ga_stream_t stream);
 /* 1 (default): ga_rollout_synth_steps takes that launch (unless actions are
  * rescaled between policy and env); 0: policy step and env step as two launches. */
 int ga_set_fused_env_step(int on);

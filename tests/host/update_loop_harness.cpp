@@ -231,9 +231,10 @@ int ga_policy_step_fused_f32(const ga_mlp_desc*, const float*, const ga_head_arg
 }
 int ga_policy_env_step_fused_f32(const ga_mlp_desc*, const float*, const ga_head_args* h,
                                  const ga_synth_env*, const ga_record_args* r,
-                                 const ga_norm_args* nm, ga_stream_t) {
-  logf("policy_env_step col=%lld step=%u obs=%p next=%p norm=%d", (long long)h->col,
-       h->step, (void*)h->obs, (void*)r->next_obs, nm != nullptr);
+                                 const ga_norm_args* nm, int64_t n_steps, ga_stream_t) {
+  logf("policy_env_step col=%lld step=%u obs=%p next=%p norm=%d steps=%lld",
+       (long long)h->col, h->step, (void*)h->obs, (void*)r->next_obs, nm != nullptr,
+       (long long)n_steps);
   return 0;
 }
 int ga_synth_env_step_record_norm(const ga_synth_env*, const ga_record_args* r,
@@ -475,11 +476,12 @@ int main() {
     Net pol(17, 64, 64, 6);
     CHECK(ga_rollout_synth_steps(&pol.d, pol.params.data(), &h, &env, &rec, A, B, nullptr,
                                  nullptr, nullptr, 3, nullptr) == 0);
-    // (one launch per step by default)
-    CHECK(count("policy_env_step") == 3 && count("policy_step ") == 0);
-    char want[128];
-    snprintf(want, sizeof(want), "policy_env_step col=4 step=101 obs=%p next=%p",
-             (void*)B, (void*)A);
+    // (ONE launch for all the steps by default)
+    CHECK(count("policy_env_step") == 1 && count("policy_step ") == 0);
+    char want[160];
+    snprintf(want, sizeof(want),
+             "policy_env_step col=3 step=100 obs=%p next=%p norm=0 steps=3", (void*)A,
+             (void*)B);
     CHECK(count(want) == 1);
     ga_set_fused_env_step(0);
     g_log.clear();
