@@ -105,7 +105,8 @@ struct FusedParams {
 };
 
 #define PS_STAMP(i) \
-  if (p.dbg && blockIdx.x == 0 && threadIdx.x == 0) p.dbg[i] = wall_clock64()
+  if (p.dbg && blockIdx.x == 0 && threadIdx.x == 0 && sidx == p.n_steps / 2) \
+    p.dbg[(i) + (RES ? 16 : 0)] = wall_clock64()
 
 // Stage W[:, k0 : k0 + 32] of a [N][ldw] weight matrix: registers -> LDS.
 struct WeightStage {
@@ -139,6 +140,19 @@ struct WeightStage {
     }
   }
 };
+
+// Butterfly sum over 8 consecutive lanes (xor 1, 2, 4) on DPP lane permutes: after
+// the first two stages a quad holds one value, so the mirrored half row supplies
+// what lane ^ 4 holds -- the same additions, in the same order, as three shuffles.
+__device__ __forceinline__ float sum8(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(
+           __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(
+           __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(
+           __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  return v;
+}
 
 // NG groups of 8 k of a hidden layer whose B operands sit in registers.
 template <int NG>
@@ -176,7 +190,18 @@ __global__ __launch_bounds__(256) void policy_step_fused_kernel(FusedParams p) {
   const int64_t row0 = (int64_t)blockIdx.x * ROWS;
   const int L = p.n_layers;
   float wreg[2][HMAX / 2];
+  float bias_r[2][2] = {{0.f, 0.f}, {0.f, 0.f}};  // RES: hidden biases of this lane's columns
+  __shared__ float obias[MAX_OUT];
   if constexpr (RES) {
+    for (int l = 0; l < L - 1; ++l)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int ncol = wave * 64 + 32 * j + l31;
+        const float b = ncol < p.dims[l + 1] ? p.params[p.b_off[l] + ncol] : 0.f;
+        if (l == 0) bias_r[0][j] = b;
+        else bias_r[1][j] = b;
+      }
+    if (tid < p.dims[L]) obias[tid] = p.params[p.b_off[L - 1] + tid];
     // (the register-resident layer multiplies whole tiles: no stale columns)
     for (int e = tid; e < ROWS * LDACT; e += 256) act[0][e] = act[1][e] = 0.f;
     {
@@ -343,12 +368,19 @@ __global__ __launch_bounds__(256) void policy_step_fused_kernel(FusedParams p) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int ncol = n0 + 32 * j + l31;
-        const float bv = ncol < N ? bias[ncol] : 0.f;
+        const float bv = RES ? (l == 0 ? bias_r[0][j] : bias_r[1][j])
+                             : (ncol < N ? bias[ncol] : 0.f);
+        // (straight-line: tanh of every element, then one guarded run of stores)
+        float v[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
-          const float v = ncol < N ? tanh_fast(acc[j][r] + bv) : 0.f;
-          if (ncol < n_pad) out[m * LDACT + ncol] = v;
+          const float t = tanh_fast(acc[j][r] + bv);
+          v[r] = ncol < N ? t : 0.f;
+        }
+        if (ncol < n_pad) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            out[((r & 3) + 8 * (r >> 2) + 4 * half) * LDACT + ncol] = v[r];
         }
       }
     }
@@ -370,34 +402,36 @@ __global__ __launch_bounds__(256) void policy_step_fused_kernel(FusedParams p) {
         reinterpret_cast<float4*>(wo)[e] = reinterpret_cast<const float4*>(W)[e];
     const int r = tid >> 3, part = tid & 7;
     const float* a = act[cur] + r * LDACT;
+    // (branch free: out-of-range slices read slice 0 and are selected away, so the
+    // LDS reads of a row go out together instead of one latency after another)
     float4 xr[HMAX / 32];
 #pragma unroll
     for (int i = 0; i < HMAX / 32; ++i) {
       const int k = part * 4 + 32 * i;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (k < K) {
-        v = *reinterpret_cast<const float4*>(a + k);
-        if (k + 1 >= K) v.y = 0.f;
-        if (k + 2 >= K) v.z = 0.f;
-        if (k + 3 >= K) v.w = 0.f;
-      }
+      float4 v = *reinterpret_cast<const float4*>(a + (k < K ? k : 0));
+      v.x = k < K ? v.x : 0.f;
+      v.y = k + 1 < K ? v.y : 0.f;
+      v.z = k + 2 < K ? v.z : 0.f;
+      v.w = k + 3 < K ? v.w : 0.f;
       xr[i] = v;
     }
     __syncthreads();
     for (int o = 0; o < N; ++o) {
       const float* w = wo + o * ldw + part * 4;
+      float4 wv[HMAX / 32];
+#pragma unroll
+      for (int i = 0; i < HMAX / 32; ++i)
+        wv[i] = *reinterpret_cast<const float4*>(
+            w + (part * 4 + 32 * i < ldw ? 32 * i : 0));
       float sum = 0.f;
 #pragma unroll
       for (int i = 0; i < HMAX / 32; ++i) {
-        if (part * 4 + 32 * i < ldw) {
-          const float4 wv = *reinterpret_cast<const float4*>(w + 32 * i);
-          sum += xr[i].x * wv.x + xr[i].y * wv.y + xr[i].z * wv.z + xr[i].w * wv.w;
-        }
+        const float t = sum + (xr[i].x * wv[i].x + xr[i].y * wv[i].y +
+                               xr[i].z * wv[i].z + xr[i].w * wv[i].w);
+        sum = part * 4 + 32 * i < ldw ? t : sum;
       }
-      sum += __shfl_xor(sum, 1, 64);
-      sum += __shfl_xor(sum, 2, 64);
-      sum += __shfl_xor(sum, 4, 64);
-      if (part == 0) head[r][o] = sum + bias[o];
+      sum = sum8(sum);
+      if (part == 0) head[r][o] = sum + (RES ? obias[o] : bias[o]);
     }
   }
   __syncthreads();
@@ -699,17 +733,17 @@ static bool g_ps_no_resident = getenv("GARAGE_AMD_ROLLOUT_RESIDENT") &&
                                atoi(getenv("GARAGE_AMD_ROLLOUT_RESIDENT")) == 0;
 static long long* g_ps_dbg = nullptr;
 // developer hook: phase timestamps (100 MHz wall clock) of workgroup 0 of the most
-// recent fused rollout step -- first call arms it, second call reads 16 values back
+// recent fused rollout step -- first call arms it, second call reads 32 values back
 // (0 start, 1 observations staged, 2 + l hidden layer l done, 10 output layer,
-// 11 sampled + env stepped)
-extern "C" int ga_policy_step_debug(long long* host_out16) {
+// 11 sampled + env stepped; + 16: the same of the resident-weights kernel; the middle step of the launch)
+extern "C" int ga_policy_step_debug(long long* host_out32) {
   if (!g_ps_dbg) {
-    if (hipMalloc(&g_ps_dbg, 16 * sizeof(long long)) != hipSuccess) return -1;
-    (void)hipMemset(g_ps_dbg, 0, 16 * sizeof(long long));
+    if (hipMalloc(&g_ps_dbg, 32 * sizeof(long long)) != hipSuccess) return -1;
+    (void)hipMemset(g_ps_dbg, 0, 32 * sizeof(long long));
     return 1;
   }
   (void)hipDeviceSynchronize();
-  return hipMemcpy(host_out16, g_ps_dbg, 16 * sizeof(long long), hipMemcpyDeviceToHost) ==
+  return hipMemcpy(host_out32, g_ps_dbg, 32 * sizeof(long long), hipMemcpyDeviceToHost) ==
                  hipSuccess ? 0 : -1;
 }
 

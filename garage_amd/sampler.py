@@ -430,19 +430,19 @@ class GpuVecWorker:
         col = 0
         # the target cannot be reached before step ceil(num_samples / n): those
         # steps need no host check and are enqueued natively when possible
-        first_check = -(-int(num_samples) // n)
-        if self._native_steps(b, 0, first_check - 1):
-            col = first_check - 1
+        first_check = min(-(-int(num_samples) // n), b['Tcap'])
+        if self._native_steps(b, 0, first_check):
+            col = first_check
         while True:
-            self._step(b, col)
-            col += 1
-            if col * n >= num_samples:  # cannot be reached any earlier
+            if col > 0 and col * n >= num_samples:  # cannot be reached any earlier
                 done_samples = int(b['step_samples'][:col].sum().item())
                 if done_samples >= num_samples:
                     break
             if col >= b['Tcap']:
                 raise RuntimeError('rollout buffer exhausted: an environment '
                                    'ran past max_episode_length')
+            self._step(b, col)
+            col += 1
         return self._pack(b, col)
 
     def _pack(self, b, n_steps, first_step=0):

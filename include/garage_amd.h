@@ -175,7 +175,7 @@ int ga_small_step_debug(long long* host_out16);
 /* the same for the one-launch step of 2 x 32 / 2 x 64 networks (narrow_step.hip) */
 int ga_narrow_step_debug(long long* host_out16);
 /* ... for the fused rollout step (policy_fused.hip) */
-int ga_policy_step_debug(long long* host_out16);
+int ga_policy_step_debug(long long* host_out32);
 /* ... and for the fused last-hidden-layer + head + loss kernel (fused_train.hip) */
 int ga_fused_fwd_debug(long long* host_out16);
 /* (start, end of the k-loop, end) of the first n <= 4096 workgroups of that launch */
