@@ -277,6 +277,10 @@ __global__ __launch_bounds__(256) void policy_step_fused_kernel(FusedParams p) {
     }
     act[0][r * LDACT + c] = v;
   }
+  // the env threads fetch what their env's step will read now, behind the network
+  ga_rollout::EnvPre pre;
+  if (p.env_step && tid < ROWS && row0 + tid < p.n)
+    pre = ga_rollout::env_prefetch(es, row0 + tid);
   __syncthreads();
   PS_STAMP(1);
 
@@ -445,6 +449,7 @@ __global__ __launch_bounds__(256) void policy_step_fused_kernel(FusedParams p) {
       const int N = p.dims[L];
       const int64_t cell = env * p.Tcap + col;
       const float* h = head[tid];
+      float* act_row = head[tid];  // the sampled action replaces the mean / scores
       if (p.head_buf) {
         // agent_info: Gaussian mean (probabilities are written below)
         if (p.kind == 0)
@@ -469,6 +474,7 @@ __global__ __launch_bounds__(256) void policy_step_fused_kernel(FusedParams p) {
             const float a = h[b * 4 + j] + sd * z[j];
             p.action[env * p.lda + b * 4 + j] = a;
             p.act_buf[cell * p.lda + b * 4 + j] = a;
+            act_row[b * 4 + j] = a;
           }
         }
       } else {
@@ -499,8 +505,9 @@ __global__ __launch_bounds__(256) void policy_step_fused_kernel(FusedParams p) {
         }
         p.action[env * p.lda] = (float)pick;
         p.act_buf[cell * p.lda] = (float)pick;
+        act_row[0] = (float)pick;
       }
-      if (p.env_step) ended_len = ga_rollout::env_step_one(es, env);
+      if (p.env_step) ended_len = ga_rollout::env_step_one(es, env, pre, act_row);
     }
   }
   // (episode counts of the step: a wave-aggregated integer atomic; the envs of a

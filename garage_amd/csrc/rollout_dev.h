@@ -26,11 +26,18 @@ static __device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uin
   return U4{c0, c1, c2, c3};
 }
 
+// The env's arithmetic is numpy's: every product and sum rounded on its own.  The
+// __fmul_rn / __fadd_rn intrinsics are plain operators in this toolchain and may
+// be contracted into FMAs with their neighbours, so the functions below switch
+// contraction off for their own statements instead.
+//
 // uint32 -> fp32 uniform on [-sqrt3, sqrt3): every step exact or singly rounded,
 // so the CPU twin (oracle/envs.py) reproduces it bit for bit.
 static __device__ __forceinline__ float u32_unit_variance(uint32_t u) {
-  const float f = __fmul_rn((float)(u >> 8), 1.1920928955078125e-07f);  // 2^-23
-  return __fmul_rn(__fsub_rn(f, 1.0f), 1.7320508f);
+#pragma clang fp contract(off)
+  const float f = (float)(u >> 8) * 1.1920928955078125e-07f;  // 2^-23
+  const float c = f - 1.0f;
+  return c * 1.7320508f;
 }
 static __device__ __forceinline__ float u32_unit_interval(uint32_t u) {
   return ((float)(u >> 8) + 0.5f) * 5.9604644775390625e-08f;  // (0,1)
@@ -80,37 +87,85 @@ static __device__ __forceinline__ void synth_reset_one(const SynthEnv& e, int64_
   synth_obs(e, env, (uint32_t)ep, 0u, obs + i * ldo);
 }
 
-// one env step: reward, step type and the (true) next observation.
-static __device__ __forceinline__ void synth_step_one(
-    const SynthEnv& e, int64_t i, const float* actions, int64_t lda, const float* obs,
-    float* next_obs, int64_t ldo, float* reward, uint8_t* step_type) {
+// What a step of env i reads of the env's and the worker's state: loaded up front,
+// so that no load waits behind the step's own stores (the memory counter retires in
+// order).  `o` holds the observation entries the reward looks at when they are few.
+constexpr int PRE_OBS = 8;
+struct EnvPre {
+  int ep, t, len, ep_t;
+  float o[PRE_OBS];
+  bool has_o;
+};
+static __device__ __forceinline__ int synth_reward_width(const SynthEnv& e) {
+  return e.discrete ? e.obs_dim : min(e.act_dim, e.obs_dim);
+}
+
+// one env step: reward, step type and the (true) next observation.  `a` is the
+// env's action row (any address space), `o` its observation row.
+static __device__ __forceinline__ void synth_step_core(
+    const SynthEnv& e, int64_t i, const EnvPre& s, const float* a, const float* o,
+    float* next_row, float* reward, uint8_t* step_type) {
+#pragma clang fp contract(off)
   const uint32_t env = (uint32_t)(e.env_id0 + i);
-  const uint32_t ep = (uint32_t)e.episode[i];
-  const int t = e.t[i];
+  const uint32_t ep = (uint32_t)s.ep;
+  const int t = s.t;
   const U4 r = philox4x32_10(env, ep, (uint32_t)t, STREAM_REWARD << 16, e.k0, e.k1);
   const float noise = u32_unit_variance(r.x);
-  const float* o = obs + i * ldo;
-  const float* a = actions + i * lda;
   float shaped = 0.f;
   if (e.discrete) {
-    shaped = o[((int)a[0]) % e.obs_dim];
+    const int k = ((int)a[0]) % e.obs_dim;
+    if (s.has_o) {
+#pragma unroll
+      for (int j = 0; j < PRE_OBS; ++j) shaped = j == k ? s.o[j] : shaped;
+    } else {
+      shaped = o[k];
+    }
   } else {
     const int m = min(e.act_dim, e.obs_dim);
-    for (int j = 0; j < m; ++j) {
-      const float aj = fminf(fmaxf(a[j], -1.f), 1.f);
-      shaped = __fadd_rn(shaped, __fmul_rn(aj, o[j]));  // no fma: matches numpy
+    if (s.has_o) {
+#pragma unroll
+      for (int j = 0; j < PRE_OBS; ++j)
+        if (j < m) {
+          const float aj = fminf(fmaxf(a[j], -1.f), 1.f);
+          const float prod = aj * s.o[j];
+          shaped = shaped + prod;
+        }
+    } else {
+      for (int j = 0; j < m; ++j) {
+        const float aj = fminf(fmaxf(a[j], -1.f), 1.f);
+        const float prod = aj * o[j];
+        shaped = shaped + prod;
+      }
     }
   }
-  reward[i] = __fadd_rn(noise, __fmul_rn(0.1f, shaped));
+  const float tenth = 0.1f * shaped;
+  *reward = noise + tenth;
   const int tn = t + 1;
   e.t[i] = tn;
-  synth_obs(e, env, ep, (uint32_t)tn, next_obs + i * ldo);
+  synth_obs(e, env, ep, (uint32_t)tn, next_row);
   // StepType.get_step_type (_dtypes.py:42-68): TIMEOUT wins over done
   uint8_t st;
   if (tn >= e.max_len) st = 3;
-  else if (tn >= e.len[i]) st = 2;
+  else if (tn >= s.len) st = 2;
   else if (tn == 1) st = 0;
   else st = 1;
+  *step_type = st;
+}
+
+static __device__ __forceinline__ void synth_step_one(
+    const SynthEnv& e, int64_t i, const float* actions, int64_t lda, const float* obs,
+    float* next_obs, int64_t ldo, float* reward, uint8_t* step_type) {
+  EnvPre s;
+  s.ep = e.episode[i];
+  s.t = e.t[i];
+  s.len = e.len[i];
+  s.ep_t = 0;
+  s.has_o = false;
+  float rew;
+  uint8_t st;
+  synth_step_core(e, i, s, actions + i * lda, obs + i * ldo, next_obs + i * ldo, &rew,
+                  &st);
+  reward[i] = rew;
   step_type[i] = st;
 }
 
@@ -122,6 +177,7 @@ static __device__ __forceinline__ void synth_step_one(
 static __device__ __forceinline__ void obs_normalize_one(const float* src, float* dst,
                                                   double* m, double* v, int obs_dim,
                                                   double alpha) {
+#pragma clang fp contract(off)
   for (int j = 0; j < obs_dim; ++j) {
     const double x = (double)src[j];
     const double mn = (1.0 - alpha) * m[j] + alpha * x;
@@ -136,6 +192,7 @@ static __device__ __forceinline__ void obs_normalize_one(const float* src, float
 static __device__ __forceinline__ float reward_normalize_one(float reward, double* mean,
                                                       double* var, double alpha,
                                                       double scale, int normalize) {
+#pragma clang fp contract(off)
   double r = (double)reward;
   if (normalize) {  // normalized_env.py:126-132,153-164
     const double mn = (1.0 - alpha) * *mean + alpha * r;
@@ -169,17 +226,17 @@ struct RecordParams {
 };
 
 // bookkeeping of env i; returns the length of the episode that ended (else 0)
-static __device__ __forceinline__ int record_one(const RecordParams& p, int64_t i) {
+static __device__ __forceinline__ int record_core(const RecordParams& p, int64_t i,
+                                                  int ep_t, float reward, uint8_t st) {
   int ended_len = 0;
   {
     const int64_t cell = i * p.Tcap + p.col;
-    const int t = p.ep_t[i] + 1;
-    const uint8_t st = p.step_type[i];
+    const int t = ep_t + 1;
     // VecWorker ends an episode on any last step (vec_worker.py:198);
     // FragmentWorker only on TERMINAL (fragment_worker.py:114-115)
     const bool ended = (t >= p.max_episode_length) ||
                        (p.terminal_only ? (st == 2) : (st >= 2));
-    p.rew_buf[cell] = p.reward[i];
+    p.rew_buf[cell] = reward;
     p.st_buf[cell] = st;
     p.tail_buf[cell] = ended ? (uint16_t)t : (uint16_t)0;
     p.done[i] = ended ? 1 : 0;
@@ -192,6 +249,10 @@ static __device__ __forceinline__ int record_one(const RecordParams& p, int64_t 
     }
   }
   return ended_len;
+}
+
+static __device__ __forceinline__ int record_one(const RecordParams& p, int64_t i) {
+  return record_core(p, i, p.ep_t[i], p.reward[i], p.step_type[i]);
 }
 
 // per-step completion counts: wave-aggregated integer atomics (deterministic:
@@ -231,20 +292,42 @@ struct EnvStepArgs {
   float* reward; uint8_t* step_type;
 };
 
-static __device__ __forceinline__ int env_step_one(const EnvStepArgs& a, int64_t i) {
+static __device__ __forceinline__ EnvPre env_prefetch(const EnvStepArgs& a, int64_t i) {
+  EnvPre s;
+  s.ep = a.e.episode[i];
+  s.t = a.e.t[i];
+  s.len = a.e.len[i];
+  s.ep_t = a.p.ep_t[i];
+  const int m = synth_reward_width(a.e);
+  s.has_o = m <= PRE_OBS;
+  const float* o = a.raw_obs + i * a.p.ldo;
+#pragma unroll
+  for (int j = 0; j < PRE_OBS; ++j) s.o[j] = (s.has_o && j < m) ? o[j] : 0.f;
+  return s;
+}
+
+// `s`: env_prefetch(a, i), taken before anything of this step was stored;
+// `act_row`: the env's action (a.actions + i * a.lda, or a copy on chip).
+static __device__ __forceinline__ int env_step_one(const EnvStepArgs& a, int64_t i,
+                                                   const EnvPre& s,
+                                                   const float* act_row) {
   const SynthEnv& e = a.e;
   const RecordParams& p = a.p;
   const NormParams& nm = a.nm;
-  synth_step_one(e, i, a.actions, a.lda, a.raw_obs, a.raw_next, p.ldo, a.reward,
-                 a.step_type);
+  float rew;
+  uint8_t st;
+  synth_step_core(e, i, s, act_row, a.raw_obs + i * p.ldo, a.raw_next + i * p.ldo, &rew,
+                  &st);
+  a.step_type[i] = st;
   if (nm.norm_obs)  // normalized_env.py:134-151: statistics first, then the value
     obs_normalize_one(a.raw_next + i * p.ldo, a.seen_next + i * p.ldo,
                       nm.obs_mean + i * p.obs_dim, nm.obs_var + i * p.obs_dim, p.obs_dim,
                       nm.obs_alpha);
   if (nm.norm_reward || nm.scale_reward)
-    a.reward[i] = reward_normalize_one(a.reward[i], nm.rew_mean + i, nm.rew_var + i,
-                                       nm.rew_alpha, nm.rew_scale, nm.norm_reward);
-  const int ended_len = record_one(p, i);
+    rew = reward_normalize_one(rew, nm.rew_mean + i, nm.rew_var + i, nm.rew_alpha,
+                               nm.rew_scale, nm.norm_reward);
+  a.reward[i] = rew;
+  const int ended_len = record_core(p, i, s.ep_t, rew, st);
   if (ended_len > 0) {
     synth_reset_one(e, i, a.raw_next, p.ldo);
     if (nm.norm_obs)
@@ -253,6 +336,9 @@ static __device__ __forceinline__ int env_step_one(const EnvStepArgs& a, int64_t
                         p.obs_dim, nm.obs_alpha);
   }
   return ended_len;
+}
+static __device__ __forceinline__ int env_step_one(const EnvStepArgs& a, int64_t i) {
+  return env_step_one(a, i, env_prefetch(a, i), a.actions + i * a.lda);
 }
 
 }  // namespace ga_rollout
