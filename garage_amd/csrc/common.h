@@ -60,6 +60,22 @@ __device__ __forceinline__ void ga_xcd_group(int id, int n_groups, int n_members
   }
 }
 
+// tanh(x) = 1 - 2 / (exp(2x) + 1) on the hardware exp / rcp units, the ONE tanh of
+// every kernel (forward, rollout and training paths must agree): v_exp, v_rcp and
+// one Newton step on the reciprocal (8 VALU instructions; an IEEE division in its
+// place costs 11 more, and the activation epilogues are VALU bound).  Absolute error
+// <= ~2e-7 over the whole range; the exponent is capped so that exp stays finite
+// (2 / (e^80 + 1) is 0 in fp32: the result is exactly 1 from x = 40 on), -1 at the
+// other end, NaN in -> NaN out.
+__device__ __forceinline__ float ga_tanh(float x) {
+  const float t = 2.f * x;
+  const float e = __expf(t > 80.f ? 80.f : t);  // (not fminf: a NaN must get through)
+  const float d = e + 1.f;
+  float r = __builtin_amdgcn_rcpf(d);
+  r = fmaf(fmaf(-d, r, 1.f), r, r);
+  return fmaf(-2.f, r, 1.f);
+}
+
 // The scalar std parameter of GaussianMLPBaseModule.forward
 // (torch/modules/gaussian_mlp_module.py:165-181): clamp to [log min_std,
 // log max_std], then 'exp' -> log std = p, or 'softplus' -> std =

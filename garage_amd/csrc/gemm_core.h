@@ -22,8 +22,7 @@ enum Epilogue { EPI_BIAS_ACT = 0, EPI_MUL_DTANH = 1, EPI_PLAIN = 2 };
 // instructions instead of libm's ~30 (64 of these per lane per output tile).
 // Absolute error <= ~1.5e-7 over the whole range, saturates cleanly at +-1.
 __device__ __forceinline__ float tanh_fast(float x) {
-  const float e = __expf(2.f * x);
-  return 1.f - 2.f * __frcp_rn(e + 1.f);
+  return ga_tanh(x);  // common.h
 }
 
 // Hidden activations.  Forward code (GemmParams::act): 0 none, 1 tanh, 2 relu.

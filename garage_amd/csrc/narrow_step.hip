@@ -36,8 +36,7 @@ constexpr int NS_HN = 8;
 typedef float ns_f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ float ns_tanh(float x) {
-  const float e = __expf(2.f * x);
-  return 1.f - 2.f * __frcp_rn(e + 1.f);
+  return ga_tanh(x);  // common.h
 }
 
 struct NarrowParams {

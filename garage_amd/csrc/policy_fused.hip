@@ -63,8 +63,7 @@ __device__ __forceinline__ void box_muller(uint32_t u0, uint32_t u1, float* z0,
   *z1 = rad * s;
 }
 __device__ __forceinline__ float tanh_fast(float x) {
-  const float e = __expf(2.f * x);
-  return 1.f - 2.f * __frcp_rn(e + 1.f);
+  return ga_tanh(x);  // common.h
 }
 
 struct FusedParams {

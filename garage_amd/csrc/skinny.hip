@@ -24,8 +24,7 @@
 namespace {
 
 __device__ __forceinline__ float tanh_fast(float x) {
-  const float e = __expf(2.f * x);
-  return 1.f - 2.f * __frcp_rn(e + 1.f);
+  return ga_tanh(x);  // common.h
 }
 
 // ---------------------------------------------------------------------------

@@ -69,8 +69,7 @@ struct SmallStepParams {
 };
 
 __device__ __forceinline__ float ss_tanh(float x) {
-  const float e = __expf(2.f * x);
-  return 1.f - 2.f * __frcp_rn(e + 1.f);
+  return ga_tanh(x);  // common.h
 }
 
 // torch.optim.Adam, one element (losses.hip: adam_update)
