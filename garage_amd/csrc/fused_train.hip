@@ -166,6 +166,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N,
 
   FT_STAMP(0);
   FT_MARK(0);
+  // this lane's output columns' biases (used when the accumulators are staged)
+  float bcol[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) bcol[j] = p.g.bias[wn0 + 32 * j + (lane & 31)];
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -365,29 +369,21 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N,
   }
 
 
-  // ---- E1: accumulators -> staged rows [64][BN + 4]
+  // ---- E1 + E2: H = tanh(accumulators + bias) -> staged rows [64][BN + 4], kept in
+  //      the stage only (the activation is applied on the way in: one LDS round
+  //      trip and one barrier less than staging first)
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+    for (int j = 0; j < TN; ++j) {
+      const float b = bcol[j];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int rr = wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        stage[rr * LDC + wn0 + 32 * j + (lane & 31)] = acc[i][j][r];
+        stage[rr * LDC + wn0 + 32 * j + (lane & 31)] = tanh_fast(acc[i][j][r] + b);
       }
-  __syncthreads();
+    }
   FT_STAMP(3);
-  // ---- E2: H = tanh(. + bias), kept in the stage only
-#pragma unroll
-  for (int q = 0; q < FT_ROWS * (BN / 4) / NT; ++q) {
-    const int e = tid + NT * q;
-    const int rr = e / (BN / 4), c4 = e % (BN / 4);
-    float4 v = *reinterpret_cast<const float4*>(stage + rr * LDC + 4 * c4);
-    const float4 b = *reinterpret_cast<const float4*>(p.g.bias + 4 * c4);
-    v.x = tanh_fast(v.x + b.x); v.y = tanh_fast(v.y + b.y);
-    v.z = tanh_fast(v.z + b.z); v.w = tanh_fast(v.w + b.w);
-    *reinterpret_cast<float4*>(stage + rr * LDC + 4 * c4) = v;
-  }
   __syncthreads();
   FT_STAMP(4);
   // ---- E3: head outputs of the 64 rows (lane = row, wave = a column segment whose
@@ -489,7 +485,21 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N,
   }
   __syncthreads();
   FT_STAMP(6);
-  // ---- E5: dZ = (dout W_head) (1 - H^2) -> global (the only [M x BN] store)
+  // E5 and E6 both read only the staged H and dout: the second half of the grid takes
+  // them in the other order, so that the dZ stores of the whole grid (33 MB, every
+  // workgroup of the single generation reaching them within a microsecond of the
+  // others) spread over twice the window, and the two workgroups of a CU do not
+  // contend for the same unit at the same time
+  auto phase_dz = [&]() {
+  // ---- E5: dZ = (dout W_head) (1 - H^2) -> global (the only [M x BN] store).  A
+  //      thread's column quad is the same for all its rows: its W_head values are
+  //      read once; rows of W_head and entries of dout beyond A are zero, so all HN
+  //      terms are taken without a branch (and without a wait inside one)
+  static_assert(NT % (BN / 4) == 0, "one column quad per thread");
+  float4 w8[HN];
+#pragma unroll
+  for (int j = 0; j < HN; ++j)
+    w8[j] = *reinterpret_cast<const float4*>(aux + j * BN + 4 * (tid % (BN / 4)));
 #pragma unroll
   for (int q = 0; q < FT_ROWS * (BN / 4) / NT; ++q) {
     const int e = tid + NT * q;
@@ -501,18 +511,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N,
     float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int j = 0; j < HN; ++j) {
-      if (j < L.A) {
-        const float4 w = *reinterpret_cast<const float4*>(aux + j * BN + 4 * c4);
-        z.x = fmaf(dd[j], w.x, z.x); z.y = fmaf(dd[j], w.y, z.y);
-        z.z = fmaf(dd[j], w.z, z.z); z.w = fmaf(dd[j], w.w, z.w);
-      }
+      z.x = fmaf(dd[j], w8[j].x, z.x); z.y = fmaf(dd[j], w8[j].y, z.y);
+      z.z = fmaf(dd[j], w8[j].z, z.z); z.w = fmaf(dd[j], w8[j].w, z.w);
     }
     z.x *= (1.f - h.x * h.x); z.y *= (1.f - h.y * h.y);
     z.z *= (1.f - h.z * h.z); z.w *= (1.f - h.w * h.w);
     if (m0 + rr < M)
       *reinterpret_cast<float4*>(p.dZ + (int64_t)(m0 + rr) * p.lddz + 4 * c4) = z;
   }
-  FT_STAMP(7);
+  };
+  auto phase_head_grad = [&]() {
   // ---- E6: this workgroup's share of dW_head[j][c] = sum_r dout[r][j] H[r][c]
   //      (rows beyond M carry dout = 0) and of db_head
   {
@@ -534,6 +542,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N,
       for (int r = 0; r < FT_ROWS; ++r) b += doutl[r * HN + tid];
       hp[HN * BN + tid] = b;
     }
+  }
+  };
+  if (blockIdx.x >= (gridDim.x + 1) / 2) {
+    phase_head_grad();
+    FT_STAMP(7);
+    phase_dz();
+  } else {
+    phase_dz();
+    FT_STAMP(7);
+    phase_head_grad();
   }
   FT_STAMP(8);
   FT_MARK(2);
