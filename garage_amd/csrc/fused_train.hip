@@ -637,6 +637,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N,
   FT_STAMP(1);
   FT_MARK(1);
 
+  // H1 of this thread's quads: in flight while the accumulators are staged
+  float4 hq[FT_ROWS * (BN / 4) / NT];
+#pragma unroll
+  for (int q = 0; q < FT_ROWS * (BN / 4) / NT; ++q) {
+    const int e = tid + NT * q;
+    const int rr = e / (BN / 4), c4 = e % (BN / 4);
+    const int m = min(m0 + rr, M - 1);
+    hq[q] = *reinterpret_cast<const float4*>(p.H + (int64_t)m * p.ldh + 4 * c4);
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -668,8 +677,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N,
   for (int q = 0; q < FT_ROWS * (BN / 4) / NT; ++q) {
     const int e = tid + NT * q;
     const int rr = e / (BN / 4), c4 = e % (BN / 4);
-    const int m = min(m0 + rr, M - 1);
-    const float4 h = *reinterpret_cast<const float4*>(p.H + (int64_t)m * p.ldh + 4 * c4);
+    const float4 h = hq[q];
     float4 v = *reinterpret_cast<const float4*>(stage + rr * LDC + 4 * c4);
     v.x *= (1.f - h.x * h.x); v.y *= (1.f - h.y * h.y);
     v.z *= (1.f - h.z * h.z); v.w *= (1.f - h.w * h.w);
