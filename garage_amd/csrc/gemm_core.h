@@ -18,9 +18,8 @@ constexpr int PAD = 4;
 
 enum Epilogue { EPI_BIAS_ACT = 0, EPI_MUL_DTANH = 1, EPI_PLAIN = 2 };
 
-// tanh(x) = 1 - 2 / (exp(2x) + 1) on the hardware exp / rcp units: 5 VALU
-// instructions instead of libm's ~30 (64 of these per lane per output tile).
-// Absolute error <= ~1.5e-7 over the whole range, saturates cleanly at +-1.
+// tanh on the hardware exp / rcp units (common.h: the one definition every kernel
+// shares; 64 of these per lane per output tile).
 __device__ __forceinline__ float tanh_fast(float x) {
   return ga_tanh(x);  // common.h
 }

@@ -15,8 +15,8 @@ assert lib.ga_fused_fwd_debug(buf) == 1
 algo._train_once(1, eps)
 assert lib.ga_fused_fwd_debug(buf) == 0
 t = np.array(list(buf), dtype=np.int64)[:9]
-names = ['prologue (W1, X, first tiles)', 'k-loop', 'E1 stage accumulators',
-         'E2 bias + tanh', 'E3 head', 'E4 loss rows', 'E5 dZ store',
+names = ['prologue (W1, X, first tiles)', 'k-loop', 'E1 tanh(acc + bias) -> stage',
+         'E2 barrier', 'E3 head', 'E4 loss rows', 'E5 dZ store (E6 in the 2nd grid half)',
          'E6 head grad shares']
 for n, d in zip(names, np.diff(t)):
     print('%-30s %6.2f us' % (n, d / 100.0))
