@@ -7,17 +7,18 @@
 //   torch/modules/gaussian_mlp_module.py:158-192, multi_headed_mlp_module.py:136-151)
 // and the per-env appends of observations / actions / agent_info.
 //
-// One workgroup (4 waves) owns 32 envs for the whole network: the activations
-// of those 32 rows never leave the CU (two [32][H+4] fp32 tiles in LDS, ping /
-// pong between layers), the weights stream from L2 through a double-buffered
-// [N][32+4] LDS stage in 32-wide k chunks (16-B loads, branch free), hidden
-// layers run on v_mfma_f32_32x32x2_f32 with the same k <-> slot map as the
-// update GEMMs (so means agree with the unfused path to rounding), the narrow
-// output layer is an 8-lane VALU dot product, and the head (Gaussian: mean +
-// std * noise; categorical: inverse CDF) writes the action and the rollout
-// buffers.  At n = 4096 that is 128 workgroups and one ~10 us launch instead of
-// four launches (~65 us).  Hidden widths up to 256 (C2, C3); wider nets use the
-// per-layer path.
+// One workgroup (4 waves) owns 16 envs for the whole network (n = 4096: 256
+// workgroups, one per CU): the activations of those rows never leave the CU (two
+// [16][H+4] fp32 tiles in LDS, ping / pong between layers), the weights stream from
+// L2 through a double-buffered [N][32+4] LDS stage in 32-wide k chunks (16-B loads,
+// branch free), hidden layers run on v_mfma_f32_16x16x4_f32 (wave w owns the
+// 16-column tiles w, w + 4, ...; means agree with the per-layer path to rounding),
+// the narrow output layer is a 16-lane VALU dot product, and the head (Gaussian:
+// mean + std * noise; categorical: inverse CDF) writes the action and the rollout
+// buffers.  Hidden widths up to 256 (C2, C3); wider nets use the per-layer path.
+// With the synthetic env the thread that sampled an env's action also steps it, and
+// a whole rollout is ONE launch with the weights resident on the CU (see the
+// kernel).
 #include "common.h"
 
 #include "rollout_dev.h"
@@ -25,8 +26,9 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int ROWS = 32;          // envs per workgroup
+constexpr int ROWS = 16;          // envs per workgroup (one 16 x 16 MFMA tile of rows)
 constexpr int HMAX = 256;         // widest supported layer
 constexpr int LDACT = HMAX + 4;   // activation tile row stride (floats)
 constexpr int KC = 32;            // k chunk
@@ -140,41 +142,87 @@ struct WeightStage {
   }
 };
 
-// Butterfly sum over 8 consecutive lanes (xor 1, 2, 4) on DPP lane permutes: after
-// the first two stages a quad holds one value, so the mirrored half row supplies
-// what lane ^ 4 holds -- the same additions, in the same order, as three shuffles.
-__device__ __forceinline__ float sum8(float v) {
+// Butterfly sum over 16 consecutive lanes (xor 1, 2, 4, 8) on DPP lane permutes:
+// after the first two stages a quad holds one value, after the third a half row, so
+// the mirrored (half) row supplies what lane ^ 4 / lane ^ 8 holds -- the same
+// additions, in the same order, as four shuffles.
+__device__ __forceinline__ float sum16(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(
            __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
   v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(
            __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
   v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(
            __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(
+           __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
   return v;
 }
 
-// NG groups of 8 k of a hidden layer whose B operands sit in registers.
-template <int NG>
+// The hidden layers run on v_mfma_f32_16x16x4_f32 (lane l: A[row l % 16][slot l / 16],
+// B[slot l / 16][col l % 16], D[row 4 (l / 16) + reg][col l % 16]); wave w owns the
+// 16-column tiles w, w + 4, w + 8, w + 12 of a layer's outputs.  Within a 16-deep
+// group MFMA q gives slot kq the element k = 16 G + 4 kq + q, so A and B fragments
+// are one 16-B read per lane and group.
+constexpr int TPW = HMAX / 64;  // tiles per wave
+
+// One 32-deep chunk with the B fragments in a staged [N][LDW] chunk.
+//   A: act + (l % 16) * LDACT + 32 * chunk + 4 * (l / 16)
+//   B: stage + (16 * wave + l % 16) * LDW + 4 * (l / 16)
+template <int NT>
+__device__ __forceinline__ void staged_chunk(const float* __restrict__ A,
+                                             const float* __restrict__ B,
+                                             f32x4 (&acc)[TPW]) {
+#pragma unroll
+  for (int G = 0; G < KC / 16; ++G) {
+    const float4 av = *reinterpret_cast<const float4*>(A + 16 * G);
+    const float a4[4] = {av.x, av.y, av.z, av.w};
+    float b4[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const float4 bv = *reinterpret_cast<const float4*>(B + 64 * t * LDW + 16 * G);
+      b4[t][0] = bv.x; b4[t][1] = bv.y; b4[t][2] = bv.z; b4[t][3] = bv.w;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[q], b4[t][q], acc[t], 0, 0, 0);
+  }
+}
+
+// NG groups of 16 k of a hidden layer whose B operands sit in registers
+// (wreg[t][4 G + q] = W[16 (wave + 4 t) + l % 16][16 G + 4 (l / 16) + q]).
+template <int NG, int NT>
 __device__ __forceinline__ void resident_layer(const float* __restrict__ A,
-                                               const float (&wreg)[2][HMAX / 2],
-                                               f32x16 (&acc)[2]) {
+                                               const float (&wreg)[TPW][HMAX / 4],
+                                               f32x4 (&acc)[TPW]) {
 #pragma unroll
   for (int G = 0; G < NG; ++G) {
-    const float4 av = *reinterpret_cast<const float4*>(A + 8 * G);
+    const float4 av = *reinterpret_cast<const float4*>(A + 16 * G);
     const float a4[4] = {av.x, av.y, av.z, av.w};
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q], wreg[j][4 * G + q], acc[j],
+      for (int t = 0; t < NT; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[q], wreg[t][4 * G + q], acc[t],
                                                       0, 0, 0);
   }
+}
+template <int NT>
+__device__ __forceinline__ void resident_layer_k(const float* __restrict__ A, int K,
+                                                 const float (&wreg)[TPW][HMAX / 4],
+                                                 f32x4 (&acc)[TPW]) {
+  // (straight-line per depth: a branch per k group would make the compiler move the
+  // accumulators at every join; the tiles are zero beyond K)
+  if (K <= 64) resident_layer<4, NT>(A, wreg, acc);
+  else if (K <= 128) resident_layer<8, NT>(A, wreg, acc);
+  else resident_layer<16, NT>(A, wreg, acc);
 }
 
 // RES (a whole rollout in one launch, observations no wider than one k chunk, one
 // or two hidden layers): the weights stay on the CU for all the steps -- the first
 // layer's chunk in wst[0], the output layer's rows in wst[1], and the second hidden
-// layer's [N][K] matrix in REGISTERS (each lane holds the 2 x 128 B operands its
+// layer's [N][K] matrix in REGISTERS (each lane holds the 4 x 64 B operands its
 // MFMAs consume: 256 of the 512 registers a wave has at one wave per SIMD), so that
 // layer runs without a barrier or a weight fetch.  Same k order per accumulator as
 // the streamed loop: bit-identical.
@@ -185,20 +233,22 @@ __global__ __launch_bounds__(256) void policy_step_fused_kernel(FusedParams p) {
   __shared__ float head[ROWS][MAX_OUT];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int half = lane >> 5, l31 = lane & 31;
+  const int r16 = lane & 15, kq = lane >> 4;
   const int64_t row0 = (int64_t)blockIdx.x * ROWS;
   const int L = p.n_layers;
-  float wreg[2][HMAX / 2];
-  float bias_r[2][2] = {{0.f, 0.f}, {0.f, 0.f}};  // RES: hidden biases of this lane's columns
+  float wreg[TPW][HMAX / 4];
+  float bias_r[2][TPW];  // RES: hidden biases of this lane's columns
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) bias_r[0][t] = bias_r[1][t] = 0.f;
   __shared__ float obias[MAX_OUT];
   if constexpr (RES) {
     for (int l = 0; l < L - 1; ++l)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int ncol = wave * 64 + 32 * j + l31;
+      for (int t = 0; t < TPW; ++t) {
+        const int ncol = 16 * (wave + 4 * t) + r16;
         const float b = ncol < p.dims[l + 1] ? p.params[p.b_off[l] + ncol] : 0.f;
-        if (l == 0) bias_r[0][j] = b;
-        else bias_r[1][j] = b;
+        if (l == 0) bias_r[0][t] = b;
+        else bias_r[1][t] = b;
       }
     if (tid < p.dims[L]) obias[tid] = p.params[p.b_off[L - 1] + tid];
     // (the register-resident layer multiplies whole tiles: no stale columns)
@@ -214,11 +264,11 @@ __global__ __launch_bounds__(256) void policy_step_fused_kernel(FusedParams p) {
       const int ldw = (K + 3) & ~3;
       const float* W = p.params + p.w_off[1];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int ncol = wave * 64 + 32 * j + l31;
+      for (int t = 0; t < TPW; ++t) {
+        const int ncol = 16 * (wave + 4 * t) + r16;
 #pragma unroll
-        for (int G = 0; G < HMAX / 8; ++G) {
-          const int k = 8 * G + 4 * half;
+        for (int G = 0; G < HMAX / 16; ++G) {
+          const int k = 16 * G + 4 * kq;
           float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
           if (ncol < N && k < K) {
             v = *reinterpret_cast<const float4*>(W + (int64_t)ncol * ldw + k);
@@ -226,8 +276,8 @@ __global__ __launch_bounds__(256) void policy_step_fused_kernel(FusedParams p) {
             if (k + 2 >= K) v.z = 0.f;
             if (k + 3 >= K) v.w = 0.f;
           }
-          wreg[j][4 * G + 0] = v.x; wreg[j][4 * G + 1] = v.y;
-          wreg[j][4 * G + 2] = v.z; wreg[j][4 * G + 3] = v.w;
+          wreg[t][4 * G + 0] = v.x; wreg[t][4 * G + 1] = v.y;
+          wreg[t][4 * G + 2] = v.z; wreg[t][4 * G + 3] = v.w;
         }
       }
     }
@@ -291,42 +341,25 @@ __global__ __launch_bounds__(256) void policy_step_fused_kernel(FusedParams p) {
     const float* W = p.params + p.w_off[l];
     const float* bias = p.params + p.b_off[l];
     const int nk = (K + KC - 1) / KC;
-    const int n0 = wave * 64;  // this wave's 64 output columns
-    const bool wave_on = n0 < N;
-    f32x16 acc[2];
+    const int n_pad = (N + KC - 1) / KC * KC;
+    // this wave's tiles: columns 16 (wave + 4 t); a narrow layer is one tile per wave
+    const bool wave_on = 16 * wave < n_pad;
+    const bool one_tile = n_pad <= 64;
+    f32x4 acc[TPW];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int t = 0; t < TPW; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+      for (int r = 0; r < 4; ++r) acc[t][r] = 0.f;
+    const float* Arow = act[cur] + r16 * LDACT + 4 * kq;
     if constexpr (RES) {
       if (wave_on) {
-        const float* A = act[cur] + l31 * LDACT;
         if (l == 0) {
-          const float* B = wst[0];
-#pragma unroll
-          for (int g = 0; g < KC / 8; ++g) {
-            const float4 av = *reinterpret_cast<const float4*>(A + 8 * g + 4 * half);
-            const float a4[4] = {av.x, av.y, av.z, av.w};
-            float b4[2][4];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-              const float4 bv = *reinterpret_cast<const float4*>(
-                  B + (n0 + 32 * j + l31) * LDW + 8 * g + 4 * half);
-              b4[j][0] = bv.x; b4[j][1] = bv.y; b4[j][2] = bv.z; b4[j][3] = bv.w;
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-              for (int j = 0; j < 2; ++j)
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q], b4[j][q], acc[j],
-                                                              0, 0, 0);
-          }
+          const float* B = wst[0] + (16 * wave + r16) * LDW + 4 * kq;
+          if (one_tile) staged_chunk<1>(Arow, B, acc);
+          else staged_chunk<TPW>(Arow, B, acc);
         } else {
-          // (straight-line per depth: a branch per k group would make the compiler
-          // move the accumulators at every join; the tiles are zero beyond K)
-          if (K <= 64) resident_layer<8>(A + 4 * half, wreg, acc);
-          else if (K <= 128) resident_layer<16>(A + 4 * half, wreg, acc);
-          else resident_layer<32>(A + 4 * half, wreg, acc);
+          if (one_tile) resident_layer_k<1>(Arow, K, wreg, acc);
+          else resident_layer_k<TPW>(Arow, K, wreg, acc);
         }
       }
     } else {
@@ -338,26 +371,9 @@ __global__ __launch_bounds__(256) void policy_step_fused_kernel(FusedParams p) {
       const bool more = s + 1 < nk;
       if (more) ws.load(W, ldw, N, K, (s + 1) * KC);
       if (wave_on) {
-        const float* A = act[cur] + l31 * LDACT + s * KC;
-        const float* B = wst[s & 1];
-#pragma unroll
-        for (int g = 0; g < KC / 8; ++g) {
-          const float4 av = *reinterpret_cast<const float4*>(A + 8 * g + 4 * half);
-          const float a4[4] = {av.x, av.y, av.z, av.w};
-          float b4[2][4];
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const float4 bv = *reinterpret_cast<const float4*>(
-                B + (n0 + 32 * j + l31) * LDW + 8 * g + 4 * half);
-            b4[j][0] = bv.x; b4[j][1] = bv.y; b4[j][2] = bv.z; b4[j][3] = bv.w;
-          }
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-              acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q], b4[j][q], acc[j],
-                                                            0, 0, 0);
-        }
+        const float* B = wst[s & 1] + (16 * wave + r16) * LDW + 4 * kq;
+        if (one_tile) staged_chunk<1>(Arow + s * KC, B, acc);
+        else staged_chunk<TPW>(Arow + s * KC, B, acc);
       }
       if (more) ws.store(wst[(s + 1) & 1], N, K, (s + 1) * KC);
       __syncthreads();
@@ -366,24 +382,24 @@ __global__ __launch_bounds__(256) void policy_step_fused_kernel(FusedParams p) {
     (void)nk;
     // bias + tanh -> the other activation tile (zero padded to the k chunk)
     float* out = act[cur ^ 1];
-    const int n_pad = (N + KC - 1) / KC * KC;
     if (wave_on) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int ncol = n0 + 32 * j + l31;
-        const float bv = RES ? (l == 0 ? bias_r[0][j] : bias_r[1][j])
-                             : (ncol < N ? bias[ncol] : 0.f);
-        // (straight-line: tanh of every element, then one guarded run of stores)
-        float v[16];
+      for (int t = 0; t < TPW; ++t) {
+        if (t == 0 || !one_tile) {
+          const int ncol = 16 * (wave + 4 * t) + r16;
+          const float bv = RES ? (l == 0 ? bias_r[0][t] : bias_r[1][t])
+                               : (ncol < N ? bias[ncol] : 0.f);
+          // (straight-line: tanh of every element, then one guarded run of stores)
+          float v[4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float t = tanh_fast(acc[j][r] + bv);
-          v[r] = ncol < N ? t : 0.f;
-        }
-        if (ncol < n_pad) {
+          for (int r = 0; r < 4; ++r) {
+            const float th = tanh_fast(acc[t][r] + bv);
+            v[r] = ncol < N ? th : 0.f;
+          }
+          if (ncol < n_pad) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
-            out[((r & 3) + 8 * (r >> 2) + 4 * half) * LDACT + ncol] = v[r];
+            for (int r = 0; r < 4; ++r) out[(4 * kq + r) * LDACT + ncol] = v[r];
+          }
         }
       }
     }
@@ -392,7 +408,7 @@ __global__ __launch_bounds__(256) void policy_step_fused_kernel(FusedParams p) {
     PS_STAMP(2 + l);
   }
 
-  // ---- narrow output layer: its weights go to LDS once; 8 lanes per row hold
+  // ---- narrow output layer: its weights go to LDS once; 16 lanes per row hold
   //      their k slice of the row in registers and dot it with every output
   {
     const int K = p.dims[L - 1], N = p.dims[L];
@@ -403,14 +419,14 @@ __global__ __launch_bounds__(256) void policy_step_fused_kernel(FusedParams p) {
     if constexpr (!RES)
       for (int e = tid; e < N * (ldw / 4); e += 256)
         reinterpret_cast<float4*>(wo)[e] = reinterpret_cast<const float4*>(W)[e];
-    const int r = tid >> 3, part = tid & 7;
+    const int r = tid >> 4, part = tid & 15;
     const float* a = act[cur] + r * LDACT;
     // (branch free: out-of-range slices read slice 0 and are selected away, so the
     // LDS reads of a row go out together instead of one latency after another)
-    float4 xr[HMAX / 32];
+    float4 xr[HMAX / 64];
 #pragma unroll
-    for (int i = 0; i < HMAX / 32; ++i) {
-      const int k = part * 4 + 32 * i;
+    for (int i = 0; i < HMAX / 64; ++i) {
+      const int k = part * 4 + 64 * i;
       float4 v = *reinterpret_cast<const float4*>(a + (k < K ? k : 0));
       v.x = k < K ? v.x : 0.f;
       v.y = k + 1 < K ? v.y : 0.f;
@@ -421,19 +437,19 @@ __global__ __launch_bounds__(256) void policy_step_fused_kernel(FusedParams p) {
     __syncthreads();
     for (int o = 0; o < N; ++o) {
       const float* w = wo + o * ldw + part * 4;
-      float4 wv[HMAX / 32];
+      float4 wv[HMAX / 64];
 #pragma unroll
-      for (int i = 0; i < HMAX / 32; ++i)
+      for (int i = 0; i < HMAX / 64; ++i)
         wv[i] = *reinterpret_cast<const float4*>(
-            w + (part * 4 + 32 * i < ldw ? 32 * i : 0));
+            w + (part * 4 + 64 * i < ldw ? 64 * i : 0));
       float sum = 0.f;
 #pragma unroll
-      for (int i = 0; i < HMAX / 32; ++i) {
+      for (int i = 0; i < HMAX / 64; ++i) {
         const float t = sum + (xr[i].x * wv[i].x + xr[i].y * wv[i].y +
                                xr[i].z * wv[i].z + xr[i].w * wv[i].w);
-        sum = part * 4 + 32 * i < ldw ? t : sum;
+        sum = part * 4 + 64 * i < ldw ? t : sum;
       }
-      sum = sum8(sum);
+      sum = sum16(sum);
       if (part == 0) head[r][o] = sum + (RES ? obias[o] : bias[o]);
     }
   }

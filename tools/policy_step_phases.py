@@ -18,7 +18,7 @@ marks = [(0, 'start'), (1, 'observations staged')] + [
     (2 + l, 'hidden layer %d' % l) for l in range(L - 1)] + [
     (10, 'output layer'), (11, 'sampling + env step')]
 for base, what in ((0, 'one step per launch (weights streamed from L2)'),
-                   (16, 'last step of a whole-rollout launch (weights resident)')):
+                   (16, 'middle step of a whole-rollout launch (weights resident)')):
     if t[base + 11] == 0:
         continue
     print(what)
