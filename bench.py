@@ -154,8 +154,9 @@ KIND_NAMES = [
     'fwd_head_loss_kernel<256,1,8,false> (last hidden layer + head + loss + seed)',
     'dgrad_wgrad0_kernel<256,1,8> (data grad + first-layer weight grad)',
     'narrow_train_kernel<64> (forward + loss + backward of a 2 x 64 net)',
+    'mlp_eval_forward_kernel<256,1,8> (whole MLP, outputs only: full-batch passes)',
 ]
-GEMM_KINDS = (0, 1, 2, 3, 4, 5, 9, 10, 11)  # MFMA kernels: work = flops
+GEMM_KINDS = (0, 1, 2, 3, 4, 5, 9, 10, 11, 12)  # MFMA kernels: work = flops
 
 
 TRAFFIC_FILE = 'profiles/r02_traffic.json'

@@ -104,6 +104,8 @@ SIGNATURES = {
     'ga_mlp_forward_fused_f32': (c_int, [C.POINTER(MlpDesc), ptr, ptr, c_i64,
                                          ptr, c_i64, ptr, ptr, c_i64, ptr]),
     'ga_set_fused_forward': (c_int, [c_int]),
+    'ga_mlp_forward_eval_supported': (c_int, [C.POINTER(MlpDesc)]),
+    'ga_set_eval_forward': (c_int, [c_int]),
     'ga_set_skinny_kernels': (c_int, [c_int]),
     'ga_set_fused_head_dgrad': (c_int, [c_int]),
     'ga_set_fused_head_forward': (c_int, [c_int]),

@@ -170,7 +170,8 @@ class VPG:
                      and ent_out is None and getattr(self, 'fuse_head', False)
                      and net.head_fusable())
             if head is None and not fused:
-                head = net.forward(obs, M, row_idx=idx)
+                # (outputs only unless a backward pass follows)
+                head = net.forward(obs, M, row_idx=idx, keep_acts=want_grad)
             dout = net.dout_view(M) if want_grad else None
             loss = torch.empty(1, dtype=torch.float32, device=net.device)
             algo = self._algo_id if old_ll is not None else 1
@@ -232,7 +233,8 @@ class VPG:
                  dptr(reduction_workspace(net.device)), stream_ptr())
             return loss, v, dout
         if v is None:
-            v = net.forward(batch.obs_dev, M, row_idx=idx)
+            v = net.forward(batch.obs_dev, M, row_idx=idx,
+                            keep_acts=want_grad)
         call('ga_gaussian_nll_loss_f32', dptr(v), v.stride(0), dptr(returns),
              dptr(idx), dptr(net.params[0:1]), M, dptr(dout), dptr(loss),
              dptr(net._slabs) if want_grad else None, net.n_flat,
@@ -296,7 +298,7 @@ class VPG:
         # baselines on every valid step and on the all-zero observation the
         # reference feeds through the padding (vpg.py:147,155-156; Q2)
         values = torch.empty(S, 1, dtype=torch.float32, device=dev)
-        vf.net.forward(batch.obs_dev, S, out=values)
+        vf.net.forward(batch.obs_dev, S, out=values, keep_acts=False)
         v0 = float(vf.net.forward(zero_obs, 1)[0, 0].item())
 
         bonus, bonus_steps = 0.0, None

@@ -49,6 +49,13 @@ int ga_fused_fwd_head_loss(const float* A, int64_t lda, const int32_t* a_idx,
                            const float* head_bias, const ga_fused_loss_args* loss,
                            float* dZ, int64_t lddz, float* hpart, double* lpart,
                            const ga_fused_first_layer* first, hipStream_t stream);
+// The whole MLP (two hidden tanh layers of the shapes above, <= 8 linear outputs) for
+// its OUTPUTS only: out[m] = MLP(X[idx ? idx[m] : m]); no activation reaches memory.
+int ga_fused_eval_supported(int n_layers, const int* dims);
+int ga_fused_eval_forward(const float* X, int64_t ldx, const int32_t* idx, int64_t M,
+                          const int* dims, const float* W1, const float* b1,
+                          const float* W2, const float* b2, const float* Wh,
+                          const float* bh, float* out, int64_t ldo, hipStream_t stream);
 // data gradient into the first hidden layer + first-layer weight / bias gradient
 // shares; wpart: [tiles][width * round4(in_w) + width] floats
 int ga_fused_dgrad_wgrad0(const float* dZ2, int64_t lddz, const float* W2, int64_t ldw,

@@ -73,6 +73,8 @@ struct FwdLossParams {
   int l1_in;
   float* l1_H;           // [M][l1_ldh]: H1 is written once, for the backward pass
   int64_t l1_ldh;
+  float* eval_out;       // EVAL: the head outputs [M][eval_ldo], nothing else is kept
+  int64_t eval_ldo;
   long long* dbg;        // developer hook: phase timestamps of one workgroup
 };
 
@@ -126,10 +128,13 @@ __device__ __forceinline__ void ft_kstep(const float* As, const float* Bs,
 
 // (two 512-thread workgroups per CU need <= 128 registers: the second bound is waves
 // per SIMD)
-template <int BN, int WAVES_M, int WAVES_N, bool L1 = false>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N,
-                             WAVES_M * WAVES_N == 8 ? 4 : 2) void fwd_head_loss_kernel(
-    FwdLossParams p) {
+// EVAL (with L1): the whole MLP for its outputs only -- no H1 spill, and after the
+// head outputs (E3) the rows go to p.eval_out and the workgroup is done
+// (mlp_eval_forward_kernel: the full-batch passes around an update, baselines /
+// old log-likelihoods / LossBefore / LossAfter / KL, need no activation in memory).
+template <int BN, int WAVES_M, int WAVES_N, bool L1, bool EVAL>
+__device__ __forceinline__ void fwd_head_loss_body(const FwdLossParams& p) {
+  static_assert(L1 || !EVAL, "the evaluation forward computes the first layer itself");
   constexpr int NT = 64 * WAVES_M * WAVES_N;
   constexpr int WM = FT_ROWS / WAVES_M, WN = BN / WAVES_N;
   constexpr int TM = WM / 32, TN = WN / 32;
@@ -286,7 +291,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N,
 #pragma unroll
         for (int g = 0; g < 4; ++g) bc[j][g] = bn[j][g];
       if (more) fetch_b(s + 1);
-      spill(s);
+      if constexpr (!EVAL) spill(s);
       if (more) produce(s + 1);
       FT_TICK(c_store, tk);
       const float* As = As2(s);
@@ -345,7 +350,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N,
 #pragma unroll
   for (int j = 0; j < 8; ++j) act[j] = 0.f;
   const bool live = m0 + lane < M;
-  if (wave == 0) {
+  if (!EVAL && wave == 0) {
     const int m = min(m0 + lane, M - 1);
     const int64_t src = L.idx ? (int64_t)L.idx[m] : (int64_t)m;
     if (L.kind == 1) {
@@ -438,8 +443,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N,
         for (int w = 0; w < PL; ++w) s += aux[w * 64 * HN + o];
       }
       outl[o] = s;
+      if constexpr (EVAL) {
+        const int row = o / HN;
+        if (j < L.A && m0 + row < M)
+          p.eval_out[(int64_t)(m0 + row) * p.eval_ldo + j] = s;
+      }
     }
   }
+  if constexpr (EVAL) return;
   __syncthreads();
   FT_STAMP(5);
   // ---- E4: wave 0: the loss rows (d(loss)/d(head output) -> doutl, batch-sum
@@ -555,6 +566,20 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N,
   }
   FT_STAMP(8);
   FT_MARK(2);
+}
+
+template <int BN, int WAVES_M, int WAVES_N, bool L1 = false>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N,
+                             WAVES_M * WAVES_N == 8 ? 4 : 2) void fwd_head_loss_kernel(
+    FwdLossParams p) {
+  fwd_head_loss_body<BN, WAVES_M, WAVES_N, L1, false>(p);
+}
+
+template <int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N,
+                             WAVES_M * WAVES_N == 8 ? 4 : 2) void mlp_eval_forward_kernel(
+    FwdLossParams p) {
+  fwd_head_loss_body<BN, WAVES_M, WAVES_N, true, true>(p);
 }
 
 // ---------------------------------------------------------------------------
@@ -1025,6 +1050,49 @@ extern "C" int ga_fused_fwd_head_loss(const float* A, int64_t lda, const int32_t
     hipExtLaunchKernelGGL((fwd_head_loss_kernel<256, 1, 8>), grid, dim3(512), 0, stream,
                           e0, e1, 0, p);
   GA_CHECK_LAUNCH("fwd_head_loss");
+  return GA_OK;
+}
+
+extern "C" int ga_fused_eval_supported(int n_layers, const int* dims) {
+  return n_layers == 3 && dims && ga_fused_first_layer_ok(dims[0], dims[1]) &&
+         dims[1] <= 256 && ga_fused_width_ok(dims[2]) && dims[3] >= 1 && dims[3] <= 8;
+}
+
+extern "C" int ga_fused_eval_forward(const float* X, int64_t ldx, const int32_t* idx,
+                                     int64_t M, const int* dims, const float* W1,
+                                     const float* b1, const float* W2, const float* b2,
+                                     const float* Wh, const float* bh, float* out,
+                                     int64_t ldo, hipStream_t stream) {
+  GA_REQUIRE(X && dims && W1 && b1 && W2 && b2 && Wh && bh && out,
+             "ga_fused_eval_forward: null pointer");
+  GA_REQUIRE(ga_fused_eval_supported(3, dims), "ga_fused_eval_forward: unsupported shape");
+  GA_REQUIRE(M >= 1 && M < (1ll << 31) && ldx >= dims[0] && ldo >= dims[3],
+             "ga_fused_eval_forward: bad sizes");
+  GA_REQUIRE(ga_aligned16(W1) && ga_aligned16(W2) && ga_aligned16(b2) && ga_aligned16(Wh),
+             "ga_fused_eval_forward: operands must be 16-B aligned");
+  const int in_w = dims[0], K = dims[1], width = dims[2], A = dims[3];
+  FwdLossParams p;
+  memset(&p, 0, sizeof(p));
+  p.g.B = W2; p.g.ldb = (K + 3) & ~3;
+  p.g.M = (int)M; p.g.N = width; p.g.K = K; p.g.bias = b2;
+  p.head_W = Wh; p.head_ldw = (width + 3) & ~3; p.head_bias = bh;
+  p.loss.idx = idx; p.loss.A = A; p.loss.kind = 2;
+  p.l1_X = X; p.l1_ldx = ldx; p.l1_W = W1; p.l1_b = b1; p.l1_in = in_w;
+  p.eval_out = out; p.eval_ldo = ldo;
+  const dim3 grid((unsigned)ga_fused_tiles(M));
+  const double flops = 2.0 * (double)M * ((double)K * in_w + (double)width * (K + A));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  ga_prof_events(GA_PROF_EVAL_FWD, flops, &e0, &e1);
+  if (width == 64)
+    hipExtLaunchKernelGGL((mlp_eval_forward_kernel<64, 2, 2>), grid, dim3(256), 0, stream,
+                          e0, e1, 0, p);
+  else if (width == 128)
+    hipExtLaunchKernelGGL((mlp_eval_forward_kernel<128, 1, 4>), grid, dim3(256), 0, stream,
+                          e0, e1, 0, p);
+  else
+    hipExtLaunchKernelGGL((mlp_eval_forward_kernel<256, 1, 8>), grid, dim3(512), 0, stream,
+                          e0, e1, 0, p);
+  GA_CHECK_LAUNCH("mlp_eval_forward");
   return GA_OK;
 }
 

@@ -30,6 +30,7 @@
 #include "prof.h"
 
 #include "gemm_core.h"
+#include "fused_train.h"
 
 namespace {
 
@@ -423,6 +424,22 @@ extern "C" int ga_mlp_forward_fused_f32(const ga_mlp_desc* d, const float* param
 // one workgroup per CU (140 KB of LDS) and its per-layer epilogues are exposed,
 // which costs what the saved activation round trip gains.  The rollout step
 // (policy_step_fused_kernel, n_envs rows) is where the fusion pays.
+// Outputs-only forward of a whole two-hidden-layer tanh network in one launch
+// (fused_train.hip: mlp_eval_forward_kernel); ga_set_eval_forward(0) makes callers
+// that ask fall back to the per-layer kernels.
+static int g_eval_forward = -1;
+extern "C" int ga_set_eval_forward(int on) {
+  g_eval_forward = on != 0;
+  return GA_OK;
+}
+extern "C" int ga_mlp_forward_eval_supported(const ga_mlp_desc* d) {
+  if (g_eval_forward < 0) {
+    const char* e = getenv("GARAGE_AMD_EVAL_FORWARD");
+    g_eval_forward = e ? atoi(e) != 0 : 1;
+  }
+  return g_eval_forward && d && d->n_layers == 3 && d->hidden_act == 0 &&
+         d->output_act == 0 && !d->layer_norm && ga_fused_eval_supported(3, d->dims);
+}
 static int g_fused_forward = 0;
 extern "C" int ga_set_fused_forward(int on) {
   g_fused_forward = on != 0;
@@ -498,7 +515,18 @@ extern "C" int ga_mlp_forward_f32(const ga_mlp_desc* d, const float* params,
   GA_REQUIRE(params && X, "ga_mlp_forward_f32: null pointer");
   // out == NULL: hidden layers only (the head is fused into the loss kernel)
   GA_REQUIRE(out || d->n_layers >= 2, "ga_mlp_forward_f32: nothing to compute");
-  GA_REQUIRE(d->n_layers == 1 || acts, "ga_mlp_forward_f32: acts workspace needed");
+  // acts == NULL: outputs only (ga_mlp_forward_eval_supported: the whole network in
+  // one launch, no activation reaches memory)
+  if (!acts && d->n_layers > 1) {
+    GA_REQUIRE(out && ga_mlp_forward_eval_supported(d),
+               "ga_mlp_forward_f32: acts workspace needed");
+    GA_REQUIRE(M >= 0 && M < (1ll << 31), "ga_mlp_forward_f32: bad M");
+    if (M == 0) return GA_OK;
+    return ga_fused_eval_forward(X, ldx, row_idx, M, d->dims, params + d->w_off[0],
+                                 params + d->b_off[0], params + d->w_off[1],
+                                 params + d->b_off[1], params + d->w_off[2],
+                                 params + d->b_off[2], out, ldo, stream);
+  }
   GA_REQUIRE(M >= 0 && M < (1ll << 31), "ga_mlp_forward_f32: bad M");
   GA_REQUIRE(ldx % 4 == 0 && ldx >= d->dims[0], "ga_mlp_forward_f32: ldx %lld",
              (long long)ldx);

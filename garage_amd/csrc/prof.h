@@ -15,7 +15,8 @@ enum GaProfKind {
   GA_PROF_FUSED_FWD = 9,    // fwd_head_loss_kernel<*>  (last hidden layer + head + loss)
   GA_PROF_FUSED_DGRAD = 10, // dgrad_wgrad0_kernel<*>   (data grad + first-layer wgrad)
   GA_PROF_NARROW_STEP = 11, // narrow_train_kernel<*>  (whole forward + backward, H <= 64)
-  GA_PROF_KINDS = 12
+  GA_PROF_EVAL_FWD = 12,    // mlp_eval_forward_kernel<*> (whole MLP, outputs only)
+  GA_PROF_KINDS = 13
 };
 
 // When profiling is on, hands out a (start, stop) event pair to attach to ONE

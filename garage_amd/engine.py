@@ -201,17 +201,28 @@ class FlatMLP:
         return self._dout[:M * self.ld_out].view(M, self.ld_out)
 
     # -- kernels ----------------------------------------------------------------
-    def forward(self, X, M, row_idx=None, out=None):
-        """``out[M, ld_out] = MLP(X[row_idx])``; X is ``(rows, ldx)`` padded."""
+    def forward(self, X, M, row_idx=None, out=None, keep_acts=True):
+        """``out[M, ld_out] = MLP(X[row_idx])``; X is ``(rows, ldx)`` padded.
+
+        ``keep_acts=False``: the caller wants the outputs only (no ``backward`` /
+        ``jvp`` on this pass) -- networks the library can evaluate in one launch
+        then leave the activation workspace untouched."""
         self._workspace(M)
         assert X.dtype == torch.float32 and X.stride(-1) == 1
         ldx = X.stride(0) if X.dim() == 2 else round4(self.in_dim)
         if out is None:
             out = self.out_view(M)
+        acts = self._acts
+        if not keep_acts and M >= self.EVAL_MIN_ROWS and \
+                _lib.load().ga_mlp_forward_eval_supported(C.byref(self._desc)):
+            acts = None
         call('ga_mlp_forward_f32', C.byref(self._desc), dptr(self.params),
-             dptr(X), ldx, dptr(row_idx), M, dptr(self._acts), dptr(out),
+             dptr(X), ldx, dptr(row_idx), M, dptr(acts), dptr(out),
              out.stride(0), stream_ptr())
         return out
+
+    # below this the per-layer kernels' small-M tiles are as fast
+    EVAL_MIN_ROWS = 4096
 
     def head_fusable(self):
         """Can the last layer be computed inside the loss kernel

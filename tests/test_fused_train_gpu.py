@@ -250,3 +250,50 @@ def test_first_layer_inside_the_fused_kernel_is_taken_and_matches(case):
     for k, v in res[1][2].items():
         assert np.isclose(res[0][2][k], v, rtol=2e-5, atol=2e-6), (k, v,
                                                                   res[0][2][k])
+
+
+@pytest.mark.parametrize('shape', [
+    # in, hidden, out, rows
+    (17, (256, 256), 6, 70000),
+    (17, (256, 256), 1, 4097),
+    (4, (64, 64), 2, 5000),
+    (9, (128, 128), 3, 8191),
+    (32, (64, 256), 8, 4096),
+])
+def test_outputs_only_forward_matches_the_per_layer_forward(shape):
+    """``forward(keep_acts=False)`` -- the full-batch evaluation passes of
+    ``_train_once`` (vpg.py:147-184: baselines, old log-likelihoods, LossBefore /
+    LossAfter / KL) -- computes the whole network in one launch
+    (``mlp_eval_forward_kernel``) and writes only the outputs: same values as the
+    per-layer kernels to rounding, gathered rows and ragged last tiles included,
+    and the activation workspace of an earlier pass is left alone."""
+    from garage_amd import _lib
+    from garage_amd.engine import FlatMLP
+    in_dim, hidden, out_dim, M = shape
+    lib = _lib.load()
+    dev = torch.device('cuda:0')
+    torch.manual_seed(3)
+    net = FlatMLP(in_dim, out_dim, hidden, dev)
+    net.params.copy_(torch.randn_like(net.params) * 0.3)
+    import ctypes as C
+    assert lib.ga_mlp_forward_eval_supported(C.byref(net._desc)) == 1
+    rows = M + 1000
+    X = torch.randn(rows, (in_dim + 3) // 4 * 4, device=dev)
+    idx = torch.randperm(rows, device=dev)[:M].to(torch.int32)
+    for row_idx in (None, idx):
+        ref = net.forward(X, M, row_idx=row_idx).clone()
+        acts = net._acts.clone()
+        net._acts.fill_(7.0)
+        got = net.forward(X, M, row_idx=row_idx, keep_acts=False).clone()
+        assert torch.equal(net._acts, torch.full_like(net._acts, 7.0))
+        net._acts.copy_(acts)
+        assert torch.isfinite(got[:, :out_dim]).all()
+        assert torch.allclose(got[:, :out_dim], ref[:, :out_dim], atol=2e-5,
+                              rtol=1e-5)
+    # networks outside the kernel's shapes keep the per-layer path
+    other = FlatMLP(40, 2, (64, 64), dev)
+    assert lib.ga_mlp_forward_eval_supported(C.byref(other._desc)) == 0
+    relu = FlatMLP(in_dim, out_dim, hidden, dev, hidden_act='relu')
+    assert lib.ga_mlp_forward_eval_supported(C.byref(relu._desc)) == 0
+    y = relu.forward(X, M, keep_acts=False)
+    assert torch.isfinite(y[:, :out_dim]).all()
