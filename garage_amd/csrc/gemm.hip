@@ -437,8 +437,10 @@ extern "C" int ga_mlp_forward_eval_supported(const ga_mlp_desc* d) {
     const char* e = getenv("GARAGE_AMD_EVAL_FORWARD");
     g_eval_forward = e ? atoi(e) != 0 : 1;
   }
+  // (64-wide layers: the per-layer kernels' 64 x 64 tiles are 2 % faster at C2)
   return g_eval_forward && d && d->n_layers == 3 && d->hidden_act == 0 &&
-         d->output_act == 0 && !d->layer_norm && ga_fused_eval_supported(3, d->dims);
+         d->output_act == 0 && !d->layer_norm && d->dims[1] >= 128 && d->dims[2] >= 128 &&
+         ga_fused_eval_supported(3, d->dims);
 }
 static int g_fused_forward = 0;
 extern "C" int ga_set_fused_forward(int on) {

@@ -126,8 +126,8 @@ int ga_mlp_forward_fused_f32(const ga_mlp_desc* d, const float* params,
                              ga_stream_t stream);
 int ga_set_fused_forward(int on);
 /* Outputs only: ga_mlp_forward_f32 with acts == NULL computes the whole network in
- * one launch without writing any activation (two hidden tanh layers of 64 / 128 /
- * 256 units, <= 32 inputs, <= 8 linear outputs: the full-batch evaluation passes of
+ * one launch without writing any activation (two hidden tanh layers of 128 / 256
+ * units, <= 32 inputs, <= 8 linear outputs: the full-batch evaluation passes of
  * vpg.py:147-184 -- baselines, old log-likelihoods, LossBefore / LossAfter / KL).
  * ga_mlp_forward_eval_supported(d) says whether a network qualifies;
  * ga_set_eval_forward(0) (GARAGE_AMD_EVAL_FORWARD=0) makes it answer no. */

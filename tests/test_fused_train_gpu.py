@@ -256,9 +256,9 @@ def test_first_layer_inside_the_fused_kernel_is_taken_and_matches(case):
     # in, hidden, out, rows
     (17, (256, 256), 6, 70000),
     (17, (256, 256), 1, 4097),
-    (4, (64, 64), 2, 5000),
     (9, (128, 128), 3, 8191),
-    (32, (64, 256), 8, 4096),
+    (32, (128, 256), 8, 4096),
+    (20, (256, 128), 2, 6000),
 ])
 def test_outputs_only_forward_matches_the_per_layer_forward(shape):
     """``forward(keep_acts=False)`` -- the full-batch evaluation passes of
@@ -291,8 +291,10 @@ def test_outputs_only_forward_matches_the_per_layer_forward(shape):
         assert torch.allclose(got[:, :out_dim], ref[:, :out_dim], atol=2e-5,
                               rtol=1e-5)
     # networks outside the kernel's shapes keep the per-layer path
-    other = FlatMLP(40, 2, (64, 64), dev)
+    other = FlatMLP(40, 2, (128, 128), dev)
     assert lib.ga_mlp_forward_eval_supported(C.byref(other._desc)) == 0
+    narrow = FlatMLP(4, 2, (64, 64), dev)  # the 64 x 64 GEMM tiles are faster there
+    assert lib.ga_mlp_forward_eval_supported(C.byref(narrow._desc)) == 0
     relu = FlatMLP(in_dim, out_dim, hidden, dev, hidden_act='relu')
     assert lib.ga_mlp_forward_eval_supported(C.byref(relu._desc)) == 0
     y = relu.forward(X, M, keep_acts=False)
