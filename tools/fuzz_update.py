@@ -2,6 +2,17 @@
 iteration each, HIP path against the oracle (parameters and logged scalars).
 
     python tools/fuzz_update.py [n_cases] [first_seed]
+
+A BAD case is not necessarily a bug: 24 fp32 Adam steps on PPO's clipped objective
+are discontinuous in the inputs (a sample whose ratio sits on the clip boundary, a
+gradient element at rounding-noise level that Adam turns into a full step).  To
+tell: FUZZ_ORACLE_THREADS=1 / =8 change the summation order of the ORACLE's own
+CPU GEMMs, FUZZ_DUMP=file.npz saves both sides' parameters -- if the oracle
+differs from itself by as much as the HIP path differs from it, the case is at the
+noise floor of the problem, not of the kernels.  FUZZ_EPOCHS / FUZZ_MB re-run a case
+with fewer steps: a kernel bug shows in the first steps, a boundary event only
+once the ratios have moved (seed 1069 of the default range: 3e-8 after the first
+epoch's 12 steps, 8e-4 after the second's; seed 5085 likewise).
 """
 import os
 import sys
@@ -95,7 +106,9 @@ def one_case(seed):
     acts = (rng.randint(0, A, size=S).astype(np.int64) if discrete else
             (0.7 * rng.randn(S, A)).astype(np.float32))
     rew = rng.randn(S)
-    E = 2
+    E = int(os.environ.get('FUZZ_EPOCHS', 2))  # (FUZZ_EPOCHS / FUZZ_MB: bisect a BAD case)
+    if os.environ.get('FUZZ_MB'):
+        mb = int(os.environ['FUZZ_MB']) or None
     with nets.hidden_nonlinearity(policy=ACTS[pa], value=ACTS[va]), \
             nets.output_nonlinearity(policy=torch.tanh if out_tanh else None), \
             nets.std_parameterization('softplus' if softplus else 'exp'):
@@ -145,10 +158,19 @@ def one_case(seed):
             worst = max(worst, float(d.max()))
             if not (d.max() <= 2e-4 and d.mean() <= 5e-6):
                 bad.append((k, float(d.max()), float(d.mean())))
+    dump = os.environ.get('FUZZ_DUMP')
+    if dump:  # oracle and HIP parameters of the case, for a closer look at a BAD one
+        np.savez(dump,
+                 **{'oracle/' + k: np.asarray(v) for d_ in (wpol, wvf)
+                    for k, v in d_.items()},
+                 **{'hip/' + k: v.numpy() for d_ in (pol.state_dict(), vf.state_dict())
+                    for k, v in d_.items()})
     return desc, worst, bad
 
 
 def main():
+    if os.environ.get('FUZZ_ORACLE_THREADS'):
+        torch.set_num_threads(int(os.environ['FUZZ_ORACLE_THREADS']))
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
     failures = 0
