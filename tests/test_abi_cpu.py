@@ -59,3 +59,13 @@ def test_host_loops_under_address_sanitizer():
                          text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert 'host loops ok' in out.stdout
+
+
+def test_driver_build_entry_point():
+    """``__graft_entry__.build()`` -- what the driver runs on a CPU-only machine --
+    compiles (a no-op when the library is current), imports the package and agrees
+    with the loader on the ABI version."""
+    import __graft_entry__ as entry
+    from garage_amd import _lib
+    entry.build()
+    assert _lib.load().ga_abi_version() == _lib.ABI_VERSION
