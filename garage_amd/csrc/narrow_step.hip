@@ -99,7 +99,11 @@ __device__ __forceinline__ ns_f32x16 ns_tile(const float* A, int lda, const floa
 // workgroup of the policy pass and one of the value-function pass (two streams)
 // share a CU.
 template <int H, int NS_LDX>
-__global__ __launch_bounds__(NS_THREADS) void narrow_train_kernel(NarrowParams p) {
+// (2 waves per SIMD where the LDS tiles allow two workgroups per CU: one of each
+// network's chain -- without the bound the compiler takes 254 + 64 registers and
+// the two chains' launches can only take turns)
+__global__ __launch_bounds__(NS_THREADS, NS_LDX <= 20 ? 2 : 1) void narrow_train_kernel(
+    NarrowParams p) {
   constexpr int LDH = H + 4;
   constexpr int CT = H / 32;        // column tiles of a hidden layer
   constexpr int QW = H / 4;         // hidden columns per wave in the VALU phases
