@@ -195,8 +195,11 @@ constexpr int SW_LDS_FLOATS = 8192;    // 32 KB: narrow stage, then reduction st
 // NV = round4(NS) / 4; NSUM: also the column sums of the narrow operand; DZ: also
 // the data gradient of the layer below (the wide operand is then its tanh output)
 template <int NV, bool NSUM, bool DZ = false>
-__global__ __launch_bounds__(SW_THREADS) void skinny_wgrad_kernel(SkinnyWgradParams p) {
-  constexpr int U = NV <= 2 ? 8 : 4;
+// (two waves per SIMD: a streaming kernel lives on the loads it has in flight; left
+// alone the compiler takes 280-350 registers for the DZ variants: one wave per SIMD)
+__global__ __launch_bounds__(SW_THREADS, (DZ && NV >= 4) ? 1 : 2) void skinny_wgrad_kernel(
+    SkinnyWgradParams p) {
+  constexpr int U = NV <= 2 ? (DZ ? 4 : 8) : 4;
   __shared__ __attribute__((aligned(16))) float red[SW_LDS_FLOATS];
   const int tid = threadIdx.x;
   const int q = tid % p.qpr;
