@@ -799,6 +799,10 @@ struct ReduceRegionsParams {
 };
 
 __global__ __launch_bounds__(256) void reduce_regions_adam_kernel(ReduceRegionsParams p) {
+  // A short launch on its chain's critical path that usually lands beside the other
+  // chain's GEMM-class kernel (traced: 17-57 us there against 11 us alone): its waves
+  // go first on the CU.  Interleaved A/B on one box: C3 9.13 -> 9.80 M env-steps/s.
+  __builtin_amdgcn_s_setprio(3);
   if (blockIdx.x == gridDim.x - 1) {
     // ---- the loss scalars and the log-std slot (flat index 0), one wave
     if (threadIdx.x >= 64) return;
