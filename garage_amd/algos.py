@@ -994,23 +994,44 @@ class TRPO(VPG):
     def _train(self, batch, adv, returns, old_ll):
         import ctypes as C
         S = batch.n_samples
-        self._train_policy(batch, adv, old_ll, None)
         opt, vf = self._vf_optimizer, self._value_function
         native = (type(self)._train_value_function
                   is VPG._train_value_function
                   and (opt.grad_hook is None
                        or getattr(opt, 'native_comm', None) is not None))
         if not native:
+            self._train_policy(batch, adv, old_ll, None)
             for idx in opt.minibatch_indices(S):
                 self._train_value_function(batch, returns, idx)
             return
+        # One GPU: the value function's epochs go to a second stream and run under
+        # the policy step (conjugate gradient + line search: full-batch kernels
+        # with a host round trip per iteration).  The two share no written state
+        # (trpo.py / vpg.py:244-248 finish the policy first; the policy step draws
+        # no random numbers, so the value function's shuffles are the same), only
+        # the wall time changes.  With a process group the order stays sequential:
+        # two chains of collectives on two communicators are not worth the risk.
+        overlap = (getattr(self, 'overlap_updates', True)
+                   and self._comm is None)
+        if not overlap:
+            self._train_policy(batch, adv, old_ll, None)
         a, keep, n_mb = self._update_args(opt, vf, 1, batch, adv, returns,
-                                          old_ll, 0)
+                                          old_ll, 1 if overlap else 0)
+        stream = stream_ptr()
+        main = torch.cuda.current_stream()
+        if overlap:
+            if getattr(self, '_side_stream', None) is None:
+                self._side_stream = torch.cuda.Stream()
+            self._side_stream.wait_stream(main)  # returns, baselines are ready
+            stream = C.c_void_p(self._side_stream.cuda_stream)
         for perm in opt.epoch_permutations(S):
             a.perm = None if perm is None else perm.data_ptr()
             a.step0 = vf.net.adam_steps
-            call('ga_update_epoch', C.byref(a), stream_ptr())
+            call('ga_update_epoch', C.byref(a), stream)
             vf.net.adam_steps += n_mb
+        if overlap:
+            self._train_policy(batch, adv, old_ll, None)
+            main.wait_stream(self._side_stream)
         del keep
 
     def _dot(self, a, b):
