@@ -530,6 +530,7 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* slabs,
                                                            int64_t n_splits,
                                                            int64_t stride, int64_t n,
                                                            float* out, float scale) {
+  __builtin_amdgcn_s_setprio(3);  // (see adam_kernel)
   // 64 float4 columns x 4 slab groups per block: 4x the workgroups of a
   // column-per-thread layout and 4 independent 16-B loads in flight per thread;
   // the groups are combined through LDS in a fixed order (deterministic).
@@ -603,6 +604,9 @@ __device__ __forceinline__ void adam_update(const AdamParams& a, float g, float&
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(AdamParams a) {
+  // (a short launch on its chain's critical path: its waves go first beside the other
+  // chain's GEMMs, see reduce_regions_adam_kernel)
+  __builtin_amdgcn_s_setprio(3);
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= a.n) return;
   float p = a.p[i], m = a.m[i], v = a.v[i];
@@ -619,6 +623,7 @@ __global__ __launch_bounds__(256) void reduce_adam_kernel(const float* slabs,
                                                           int64_t n_splits,
                                                           int64_t stride, int zero_slot0,
                                                           AdamParams a, float* grads) {
+  __builtin_amdgcn_s_setprio(3);  // (see adam_kernel)
   __shared__ float4 part[4][64];
   const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int64_t i4 = ((int64_t)blockIdx.x * 64 + col) * 4;
