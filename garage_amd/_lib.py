@@ -86,7 +86,7 @@ class UpdateArgs(C.Structure):
                 ('partials_floats', c_i64), ('phase', c_i32)]
 
 
-ABI_VERSION = 3  # ga_abi_version() of the library these structs mirror
+ABI_VERSION = 4  # ga_abi_version() of the library these structs mirror
 
 # name -> (restype, argtypes); mirrors include/garage_amd.h one to one.
 SIGNATURES = {
@@ -213,6 +213,8 @@ SIGNATURES = {
     'ga_gather_u8': (c_int, [ptr, ptr, c_i64, ptr, ptr]),
     'ga_permutation_i32': (c_int, [c_i64, c_u64, ptr, ptr]),
     'ga_episode_sums_f32': (c_int, [ptr, ptr, c_i64, ptr, ptr]),
+    'ga_minibatch_range': (c_i64, [c_i64, c_i64, c_i64, c_int, c_i64,
+                                   C.POINTER(c_i64), C.POINTER(c_i64)]),
     'ga_update_epoch': (c_int, [C.POINTER(UpdateArgs), ptr]),
     'ga_update_partials_floats': (c_i64, [C.POINTER(MlpDesc), c_i64]),
     'ga_set_fused_train': (c_int, [c_int]),
@@ -230,6 +232,7 @@ SIGNATURES = {
     'ga_set_ordered_allreduce': (c_int, [c_int]),
     'ga_prof_enable': (c_int, [c_int]),
     'ga_prof_collect': (c_int, [C.POINTER(c_f64), c_int]),
+    'ga_launch_count': (c_i64, [c_int]),
 }
 
 

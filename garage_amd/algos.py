@@ -357,6 +357,8 @@ class VPG:
         vf_before, _, _ = self._value_loss_pass(batch, returns, S, None,
                                                 v=values)
 
+        steps_before = (pol.net.adam_steps,
+                        self._value_function.net.adam_steps)
         self._train(batch, adv, returns, old_ll)
 
         # ---- diagnostics after the update (vpg.py:178-184) -------------------
@@ -385,18 +387,27 @@ class VPG:
         # one of its grid barriers ever gave up (its results are then garbage)
         # (such a launch, and every later one, returns before any parameter is
         # written: the networks hold the last complete optimizer step)
-        faulted = False
+        faulted = []
         for tag in (0, 1):
             ws = reduction_workspace(dev, tag)
             if float(ws[-1]) != 0.0:
                 ws[-2:].zero_()  # re-arm the barrier words for the next call
-                faulted = True
+                faulted.append(tag)
         if faulted:
+            # Adam's step counts were advanced on the host for steps the device
+            # skipped: put them back to the iteration's start, so that a caller
+            # who catches this and carries on (ga_set_small_step(0)) does not
+            # train with bias corrections of steps that never happened
+            pol.net.adam_steps, self._value_function.net.adam_steps = \
+                steps_before
             raise RuntimeError(
-                'ga_small_step: a grid barrier timed out; the optimizer steps '
-                'from that point on were skipped (parameters are those of the '
-                'last complete step). Disable the one-launch step with '
-                'ga_set_small_step(0).')
+                'ga_small_step: a grid barrier timed out (reduction workspace '
+                'tag(s) {}: 0 = the main stream\'s network, 1 = the side '
+                'stream\'s); the optimizer steps from that point on were '
+                'skipped (parameters and Adam moments are those of the last '
+                'complete step, the step counts those of the start of this '
+                'iteration). Disable the one-launch step with '
+                'ga_set_small_step(0).'.format(faulted))
         tab = logger.tabular
         with tab.prefix(self.policy.name):
             tab.record('/LossBefore', pl_b)
@@ -1019,12 +1030,20 @@ class TRPO(VPG):
                                           old_ll, 1 if overlap else 0)
         stream = stream_ptr()
         main = torch.cuda.current_stream()
+        # Every epoch's permutation is drawn on the main stream BEFORE the side
+        # stream's wait and stays referenced until the join below: a permutation
+        # drawn lazily inside the loop would be read by the side stream without
+        # an edge from the kernel that writes it, and its block could be handed
+        # to a later epoch's draw while the side stream still gathers through it
+        # (the same rule as _train_native_pair).
+        perms = list(opt.epoch_permutations(S))
         if overlap:
             if getattr(self, '_side_stream', None) is None:
                 self._side_stream = torch.cuda.Stream()
-            self._side_stream.wait_stream(main)  # returns, baselines are ready
+            # returns, baselines and the permutations are ready
+            self._side_stream.wait_stream(main)
             stream = C.c_void_p(self._side_stream.cuda_stream)
-        for perm in opt.epoch_permutations(S):
+        for perm in perms:
             a.perm = None if perm is None else perm.data_ptr()
             a.step0 = vf.net.adam_steps
             call('ga_update_epoch', C.byref(a), stream)
@@ -1032,7 +1051,7 @@ class TRPO(VPG):
         if overlap:
             self._train_policy(batch, adv, old_ll, None)
             main.wait_stream(self._side_stream)
-        del keep
+        del keep, perms
 
     def _dot(self, a, b):
         """Host float of ``a . b`` (fp64 accumulation on the device)."""

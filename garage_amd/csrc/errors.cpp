@@ -13,4 +13,4 @@ void ga_set_error(const char* fmt, ...) {
 
 extern "C" const char* ga_last_error(void) { return g_err; }
 
-extern "C" int ga_abi_version(void) { return 3; }
+extern "C" int ga_abi_version(void) { return 4; }

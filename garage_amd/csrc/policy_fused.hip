@@ -20,6 +20,7 @@
 // a whole rollout is ONE launch with the weights resident on the CU (see the
 // kernel).
 #include "common.h"
+#include "prof.h"
 
 #include "rollout_dev.h"
 
@@ -835,6 +836,7 @@ static int policy_step_launch(const ga_mlp_desc_c* d, const float* params,
   // a whole rollout in one launch keeps the weights on the CU (see the kernel)
   const bool resident = n_steps > 1 && d->dims[0] <= KC &&
                         (d->n_layers == 2 || d->n_layers == 3) && !g_ps_no_resident;
+  if (resident) ga_prof_count(GA_PROF_ROLLOUT);
   if (resident)
     hipLaunchKernelGGL(policy_step_fused_kernel<true>, grid, dim3(256), 0, stream, p);
   else

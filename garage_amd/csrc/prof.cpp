@@ -15,6 +15,9 @@ struct Sample {
   double work;
 };
 bool g_on = false;
+// launches per kind since the library was loaded, counted whether timing is on or
+// not (tests assert which kernels an update took: ga_launch_count)
+int64_t g_launches[GA_PROF_KINDS] = {0};
 std::vector<Sample> g_samples;
 std::vector<hipEvent_t> g_pool;
 constexpr size_t kMaxSamples = 200000;
@@ -34,6 +37,7 @@ hipEvent_t get_event() {
 void ga_prof_events(int kind, double work, hipEvent_t* start, hipEvent_t* stop) {
   *start = nullptr;
   *stop = nullptr;
+  if (kind >= 0 && kind < GA_PROF_KINDS) ++g_launches[kind];
   if (!g_on || g_samples.size() >= kMaxSamples) return;
   Sample s;
   s.start = get_event();
@@ -43,6 +47,14 @@ void ga_prof_events(int kind, double work, hipEvent_t* start, hipEvent_t* stop) 
   g_samples.push_back(s);
   *start = s.start;
   *stop = s.stop;
+}
+
+void ga_prof_count(int kind) {
+  if (kind >= 0 && kind < GA_PROF_KINDS) ++g_launches[kind];
+}
+
+extern "C" int64_t ga_launch_count(int kind) {
+  return (kind >= 0 && kind < GA_PROF_KINDS) ? g_launches[kind] : -1;
 }
 
 extern "C" int ga_prof_enable(int on) {

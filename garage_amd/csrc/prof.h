@@ -16,7 +16,10 @@ enum GaProfKind {
   GA_PROF_FUSED_DGRAD = 10, // dgrad_wgrad0_kernel<*>   (data grad + first-layer wgrad)
   GA_PROF_NARROW_STEP = 11, // narrow_train_kernel<*>  (whole forward + backward, H <= 64)
   GA_PROF_EVAL_FWD = 12,    // mlp_eval_forward_kernel<*> (whole MLP, outputs only)
-  GA_PROF_KINDS = 13
+  GA_PROF_ROLLOUT = 13,     // policy_step_fused_kernel<true>: a whole rollout (policy +
+                            // env + bookkeeping for n_steps > 1) in one launch; counted
+                            // only (ga_launch_count), never timed
+  GA_PROF_KINDS = 14
 };
 
 // When profiling is on, hands out a (start, stop) event pair to attach to ONE
@@ -24,3 +27,5 @@ enum GaProfKind {
 // kernel's own duration (what rocprofv3 reports), with no launch gaps in it.
 // When off, both stay null and the launch is an ordinary one.
 void ga_prof_events(int kind, double work, hipEvent_t* start, hipEvent_t* stop);
+// Counts a launch of `kind` without timing it (ga_launch_count).
+void ga_prof_count(int kind);

@@ -533,6 +533,30 @@ int run_minibatch(const ga_update_args* a, int64_t k, ga_stream_t stream,
 
 }  // namespace
 
+// Host-only: which ids of a pass's permutation form minibatch k, and how many
+// minibatches the pass has -- the split ga_update_epoch* walks.  Exists so that
+// the Python side's OptimizerWrapper.minibatch_bounds (which sizes workspaces and
+// per-step gradient weights for data-parallel runs) can be checked against it
+// without a GPU.  Returns the number of minibatches, < 0 on bad arguments.
+extern "C" int64_t ga_minibatch_range(int64_t S, int64_t mb, int64_t n_mb, int has_perm,
+                                      int64_t k, int64_t* start, int64_t* M) {
+  ga_update_args a;
+  memset(&a, 0, sizeof(a));
+  a.S = S; a.mb = mb; a.n_mb = n_mb;
+  a.perm = has_perm ? reinterpret_cast<const int32_t*>(&a) : nullptr;  // never read
+  if (S <= 0 || (has_perm && mb <= 0 && n_mb <= 0) || n_mb < 0 || (has_perm && n_mb > S)) {
+    ga_set_error("ga_minibatch_range: bad sizes");
+    return -1;
+  }
+  const int64_t n = n_minibatches(&a);
+  if (k < 0 || k >= n) {
+    ga_set_error("ga_minibatch_range: k out of range");
+    return -1;
+  }
+  if (start && M) minibatch_range(&a, k, start, M);
+  return n;
+}
+
 extern "C" int ga_update_epoch(const ga_update_args* a, ga_stream_t stream) {
   int rc = check_args(a);
   if (rc) return rc;

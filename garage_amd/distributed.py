@@ -116,6 +116,13 @@ class NativeComm:
         self.rank = comm.rank
         self.rccl_ranks = int(lib.ga_comm_count(self.handle))
 
+    def destroy(self):
+        """Release the communicator (collective in RCCL: call on every rank)."""
+        if getattr(self, 'handle', None):
+            from garage_amd import _lib
+            _lib.load().ga_comm_destroy(self.handle)
+            self.handle = None
+
     @staticmethod
     def _agree(comm, ok, what):
         flag = torch.tensor([1.0 if ok else 0.0], device='cuda')
@@ -123,6 +130,11 @@ class NativeComm:
         if float(flag.item()) < 1.0:
             raise RuntimeError('native RCCL communicator: a rank failed in ' +
                                what)
+
+
+def _make_native_comm(comm):
+    """Seam for tests (a world of one GPU cannot make RCCL fail half way)."""
+    return NativeComm(comm)
 
 
 def combine_moments(stats, comm):
@@ -146,29 +158,41 @@ def shard_algo(algo, comm):
         return algo
     algo._comm = comm
     use_rccl = dist.get_backend(comm.group) == 'nccl'
-    for module, opt in ((algo.policy, algo._policy_optimizer),
-                        (algo._value_function, algo._vf_optimizer)):
+    pairs = ((algo.policy, algo._policy_optimizer),
+             (algo._value_function, algo._vf_optimizer))
+    for module, opt in pairs:
         comm.broadcast(module.net.params)
         comm.broadcast(module.net.exp_avg)
         comm.broadcast(module.net.exp_avg_sq)
         # the local gradient is pre-scaled by S_local / S_global
         # (OptimizerWrapper.dp_grad_scale), so the exchange is a plain sum
         opt.grad_hook = comm.all_reduce
-        # RCCL inside the C++ epoch loop; one communicator per network because
-        # the two passes run on two streams and a communicator's collectives
-        # must be issued in one order on every rank
         opt.native_comm = None
-        if use_rccl and os.environ.get('GARAGE_AMD_NATIVE_COMM', '1') != '0':
-            try:
-                opt.native_comm = NativeComm(comm)
-            except RuntimeError as exc:  # pragma: no cover - needs >1 GPU
-                # fall back to the Python-driven minibatch loop, which
-                # all-reduces through torch.distributed (same results, more
-                # host overhead); NativeComm raises on every rank or on none
-                import warnings
-                warnings.warn('native RCCL communicator unavailable ({}); '
-                              'using torch.distributed for the gradient '
-                              'all-reduce'.format(exc))
+    # RCCL inside the C++ epoch loop; one communicator per network because the
+    # two passes run on two streams and a communicator's collectives must be
+    # issued in one order on every rank.  All or none: either BOTH networks of
+    # EVERY rank hold a communicator, or both take the Python minibatch loop
+    # with torch.distributed all-reduces (NativeComm raises on every rank or
+    # on none, so the decision is the same everywhere) -- a mixed state would
+    # run one network's steps through the C++ loop and the other's through
+    # Python, and report neither correctly.
+    if use_rccl and os.environ.get('GARAGE_AMD_NATIVE_COMM', '1') != '0':
+        made = []
+        try:
+            for _ in pairs:
+                made.append(_make_native_comm(comm))
+        except RuntimeError as exc:
+            # fall back to the Python-driven minibatch loop, which all-reduces
+            # through torch.distributed (same results, more host overhead)
+            import warnings
+            for c in made:
+                c.destroy()
+            made = []
+            warnings.warn('native RCCL communicator unavailable ({}); using '
+                          'torch.distributed for the gradient all-reduce of '
+                          'both networks'.format(exc))
+        for (_, opt), c in zip(pairs, made):
+            opt.native_comm = c
     algo._old_policy.sync(algo.policy)
     return algo
 
@@ -185,5 +209,10 @@ def gradient_exchange(algo):
         return ('rccl all-reduce inside the C++ epoch loop (one library-owned '
                 'communicator per network)', min(n.rccl_ranks for n in native))
     backend = dist.get_backend(algo._comm.group)
+    if any(n is not None for n in native):  # shard_algo never leaves this
+        return ('MIXED: native communicator for {} only, torch.distributed '
+                '({}) for the other network'.format(
+                    'the policy' if native[0] is not None else
+                    'the value function', backend), None)
     return ('torch.distributed all-reduce ({}) from the Python minibatch loop'
             ' (FALLBACK: no native communicator)'.format(backend), None)

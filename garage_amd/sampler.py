@@ -516,6 +516,16 @@ class GpuVecWorker:
         rows = [log.get(int(c), {}).get(int(e), {})
                 for e, c in zip(envs, ends)]
         keys = next(r for r in rows if r).keys()
+        for e, r in enumerate(rows):
+            missing = [k for k in keys if k not in r]
+            if missing:
+                # (the reference's EpisodeBatch.concatenate needs every episode
+                # to carry the same episode_info keys, _dtypes.py:592-632)
+                raise ValueError(
+                    'episode {} (env {}, ended at step {}) reports no '
+                    'episode_info {!r}; every reset() of a batch must report '
+                    'the same keys'.format(e, int(envs[e]), int(ends[e]),
+                                           missing))
         return {k: np.asarray([r[k] for r in rows]) for k in keys}
 
     @staticmethod
@@ -535,33 +545,62 @@ class GpuVecWorker:
                                    for e, c in zip(envs, cols)])
         return out
 
-    # -- reference-shaped API (one rollout() = until >=1 episode completes) ---
+    # -- reference-shaped API (sampler/worker.py:46-77) -------------------------
+    # start_episode / step_episode / collect_episode run on one persistent
+    # rollout buffer: a step is the same launches as everywhere else plus ONE
+    # device sync (the count of episodes that ended in it), collect_episode packs
+    # the columns stepped since the last collection.  rollout() is the three
+    # calls in the reference's order (default_worker.py:176-186).
     def start_episode(self):
+        """``vec_worker.py:107-137``."""
         self._start()
 
-    def rollout(self):
-        """``default_worker.py:176-186`` semantics, one device sync per step."""
-        self._start()
-        P = int(self._max_episode_length)
+    def _api_buffer(self):
         if getattr(self, '_api_buf', None) is None:
+            P = int(self._max_episode_length)
             self._api_buf = self._alloc_buffers(self._n_envs * P)
-            self._api_col = 0
-            self._api_first = 0
-        b = self._api_buf
-        while True:
-            if self._api_col >= b['Tcap']:
-                raise RuntimeError('rollout buffer exhausted')
-            self._step(b, self._api_col)
-            self._api_col += 1
-            if int(b['step_eps'][self._api_col - 1].item()) > 0:
-                break
-        batch = self._pack(b, self._api_col, first_step=self._api_col - 1)
-        if self._api_col + P >= b['Tcap']:
+            self._api_col = 0    # next column to step into
+            self._api_first = 0  # first column not yet handed out
+        return self._api_buf
+
+    def step_episode(self):
+        """``vec_worker.py:176-204``: one vectorised step of every environment;
+        True iff at least one episode completed in it."""
+        if self._ep_t is None:
+            self._start()
+        b = self._api_buffer()
+        if self._api_col >= b['Tcap']:
+            b = self._api_buf = self._grown(b, self._api_col)
+        col = self._api_col
+        self._step(b, col)
+        self._api_col = col + 1
+        return int(b['step_eps'][col].item()) > 0
+
+    def collect_episode(self):
+        """``vec_worker.py:206-219``: the episodes completed since the last call,
+        in (completion step, env) order."""
+        b = self._api_buffer()
+        first, col = self._api_first, self._api_col
+        if col <= first or int(b['step_eps'][first:col].sum().item()) == 0:
+            # (the reference falls into EpisodeBatch.concatenate() of nothing)
+            raise ValueError('collect_episode(): no episode has completed '
+                             'since the last call')
+        batch = self._pack(b, col, first_step=first)
+        self._api_first = col
+        if col + int(self._max_episode_length) >= b['Tcap']:
             self._rebase_api_buffer()
         return batch
 
+    def rollout(self):
+        """``default_worker.py:176-186``: step until an episode completes."""
+        self.start_episode()
+        while not self.step_episode():
+            pass
+        return self.collect_episode()
+
     def _rebase_api_buffer(self):
-        """Move the in-flight tails of the API buffer back to column 0."""
+        """Move the in-flight tails of the API buffer back to column 0 (every
+        completed episode has been handed out: called by collect_episode)."""
         old, col = self._api_buf, self._api_col
         P = int(self._max_episode_length)
         new = self._alloc_buffers(self._n_envs * P)
@@ -573,15 +612,20 @@ class GpuVecWorker:
         new['ep_infos'] = {c - (col - keep): v
                            for c, v in old['ep_infos'].items()
                            if c >= col - keep}
-        self._api_buf, self._api_col = new, keep
+        self._api_buf, self._api_col, self._api_first = new, keep, keep
 
-    def step_episode(self):
-        raise NotImplementedError(
-            'GpuVecWorker exposes rollout() / rollout_samples(); per-step '
-            'host control would serialise the device')
-
-    def collect_episode(self):
-        raise NotImplementedError('use rollout()')
+    def _grown(self, old, col):
+        """A rollout buffer of twice the columns holding columns ``[0, col)`` of
+        ``old`` (steps taken without a collection in between)."""
+        new = self._alloc_buffers(self._n_envs * 2 * old['Tcap'])
+        for k in ('obs', 'act', 'head', 'lastobs', 'rew', 'st', 'tail'):
+            if old[k] is not None:
+                new[k][:, :col] = old[k][:, :col]
+        for k in ('step_eps', 'step_samples'):
+            new[k][:col] = old[k][:col]
+        new['infos'][:col] = old['infos'][:col]
+        new['ep_infos'] = dict(old['ep_infos'])
+        return new
 
     def shutdown(self):
         if self.env is not None:
@@ -635,12 +679,37 @@ class GpuFragmentWorker(GpuVecWorker):
     def rollout_samples(self, num_samples):
         raise NotImplementedError('fragment workers are driven by rollout()')
 
-    def rollout(self):
+    def start_episode(self):
+        """``fragment_worker.py:85-91``."""
         self._start()
-        n, tpc = self._n_envs, self._timesteps_per_call
-        b = self._alloc_buffers(n * tpc)
-        for col in range(tpc):
-            self._step(b, col)
+
+    def step_episode(self):
+        """``fragment_worker.py:93-119``: one step of every environment; True
+        iff an episode ended (TERMINAL or ``max_episode_length``) in it."""
+        if self._ep_t is None:
+            self._start()
+        b = getattr(self, '_frag_buf', None)
+        if b is None:
+            b = self._frag_buf = self._alloc_buffers(
+                self._n_envs * self._timesteps_per_call)
+            self._frag_col = 0
+        if self._frag_col >= b['Tcap']:
+            b = self._frag_buf = self._grown(b, self._frag_col)
+        col = self._frag_col
+        self._step(b, col)
+        self._frag_col = col + 1
+        return int(b['step_eps'][col].item()) > 0
+
+    def collect_episode(self):
+        """``fragment_worker.py:121-138``: the fragments closed by an episode end
+        since the last call in (step, env) order, then the still-running ones
+        in env order."""
+        b, tpc = getattr(self, '_frag_buf', None), getattr(self, '_frag_col', 0)
+        if b is None or tpc == 0:
+            raise ValueError('collect_episode(): no step has been taken since '
+                             'the last call')
+        n = self._n_envs
+        self._frag_buf, self._frag_col = None, 0
         # fragment table on the host: the (n, tpc) tail matrix is tiny
         tail = b['tail'][:, :tpc].to(torch.int32).cpu().numpy()
         env_id, end, length = [], [], []
@@ -659,6 +728,13 @@ class GpuFragmentWorker(GpuVecWorker):
                 length.append(tpc - cut[i])
         return self._pack_fragments(b, np.asarray(env_id), np.asarray(end),
                                     np.asarray(length), n_closed)
+
+    def rollout(self):
+        """``fragment_worker.py:140-151``."""
+        self.start_episode()
+        for _ in range(self._timesteps_per_call):
+            self.step_episode()
+        return self.collect_episode()
 
     def _pack_fragments(self, b, env_id, end, length, n_closed):
         dev, tcap = self.device, b['Tcap']
@@ -710,24 +786,6 @@ class GpuFragmentWorker(GpuVecWorker):
             discrete=is_discrete(self.env.spec.action_space),
             env_infos=self._packed_env_infos(b, src, tcap),
             episode_infos=self._packed_episode_infos(b, ep_env, ep_end))
-
-    @staticmethod
-    def _packed_episode_infos(b, ep_env, ep_end):
-        """``episode_infos`` of the packed batch: per key an ``(N, ...)`` array,
-        row ``e`` = what ``reset()`` reported for episode ``e``
-        (``default_worker.py:94-96,158-161``; the reference's ``VecWorker`` loses
-        them after an env's first episode, SURVEY.md Q23 -- the intended
-        ``DefaultWorker`` layout is kept here)."""
-        log = b.get('ep_infos')
-        if not log or not any(info for col in log.values()
-                              for info in col.values()):
-            return {}
-        envs = ep_env.cpu().numpy()
-        ends = ep_end.cpu().numpy()
-        rows = [log.get(int(c), {}).get(int(e), {})
-                for e, c in zip(envs, ends)]
-        keys = next(r for r in rows if r).keys()
-        return {k: np.asarray([r[k] for r in rows]) for k in keys}
 
 
 class GpuVecSampler:

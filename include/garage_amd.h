@@ -29,7 +29,7 @@ extern "C" {
 
 typedef void* ga_stream_t; /* hipStream_t */
 
-int ga_abi_version(void); /* 3 */
+int ga_abi_version(void); /* 4 */
 /* Wherever a policy's scalar std parameter crosses this interface it comes as
  * (log_std pointer, has_min, min_log_std, has_max, max_log_std) and goes through
  * GaussianMLPBaseModule.forward's transformation
@@ -552,6 +552,15 @@ typedef struct {
                                 loop exchanges and steps itself) */
 } ga_update_args;
 int ga_update_epoch(const ga_update_args* args, ga_stream_t stream);
+/* Host-only (no GPU needed): the split of a pass into minibatches that
+ * ga_update_epoch* walks -- ids [*start, *start + *M) of the permutation form
+ * minibatch k; returns the number of minibatches of the pass (< 0: bad arguments).
+ * S, mb, n_mb as in ga_update_args; has_perm = (perm != NULL).  The Python side's
+ * OptimizerWrapper.minibatch_bounds must agree with it on every rank (the reference's
+ * BatchDataset split, np/optimizers/minibatch_dataset.py:20-35, and the even split of
+ * data-parallel runs); tests/test_host_logic_cpu.py compares the two. */
+int64_t ga_minibatch_range(int64_t S, int64_t mb, int64_t n_mb, int has_perm, int64_t k,
+                           int64_t* start, int64_t* M);
 /* Floats of `partials` scratch the fused step needs for minibatches of up to M rows
  * of this network; 0: the network's shapes take the per-layer kernels (last hidden
  * layer not 64 / 128 / 256 wide, or a head of more than 8 outputs). */
@@ -617,6 +626,12 @@ int ga_set_ordered_allreduce(int on);
  * (a HOST pointer). */
 int ga_prof_enable(int on);
 int ga_prof_collect(double* out_host, int n_kinds);
+/* Launches of kernel kind `kind` (csrc/prof.h: 9 = fwd_head_loss_kernel, 10 =
+ * dgrad_wgrad0_kernel, 11 = narrow_train_kernel, 12 = mlp_eval_forward_kernel, 13 =
+ * a whole rollout in one policy_step_fused_kernel launch, ...)
+ * since the library was loaded, counted whether timing is on or not; -1 for an
+ * unknown kind.  Tests use it to assert WHICH kernels an update dispatched to. */
+int64_t ga_launch_count(int kind);
 
 #ifdef __cplusplus
 }

@@ -27,6 +27,7 @@ _SQRT3 = np.float32(1.7320508)
 STREAM_OBS = 0
 STREAM_REWARD = 1
 STREAM_LENGTH = 2
+STREAM_ACTION = 3
 
 
 def philox4x32(c0, c1, c2, c3, seed):
@@ -62,6 +63,32 @@ def synthetic_values(seed, env_id, episode, t, stream, count):
     r = philox4x32(env_id, episode, t, c3, seed)
     vals = np.stack(r, axis=-1).reshape(-1)[:count]
     return u32_to_unit_variance(vals)
+
+
+def action_noise(seed, env_ids, step, act_dim):
+    """The standard-normal draws the device policy step adds to the means of
+    step ``step`` (global step counter of the worker) when it is not teacher
+    forced: per env, Philox blocks ``(env, step, b, STREAM_ACTION << 16)`` turned
+    into pairs by Box-Muller, ``u = ((x >> 8) + 0.5) 2^-24``.  This is the
+    build's own stream (the reference draws from torch's global RNG,
+    ``stochastic_policy.py:85``); logs and sincos are the host's, so the device
+    agrees to rounding (1e-6), not bit for bit.  Returns ``(len(env_ids),
+    act_dim)`` float32."""
+    env_ids = np.asarray(env_ids, dtype=np.uint64)
+    blocks = (act_dim + 3) // 4
+    out = np.zeros((env_ids.size, 4 * blocks), np.float32)
+    for b in range(blocks):
+        r = philox4x32(env_ids, int(step) & 0xFFFFFFFF, b,
+                       np.uint64(STREAM_ACTION) << np.uint64(16), seed)
+        u = [((x >> np.uint32(8)).astype(np.float32) + np.float32(0.5)) *
+             np.float32(2.0**-24) for x in r]
+        for pair in range(2):
+            a, c = u[2 * pair], u[2 * pair + 1]
+            rad = np.sqrt(np.float32(-2.0) * np.log(a))
+            ang = np.float32(6.28318530717958647692) * c
+            out[:, 4 * b + 2 * pair] = rad * np.cos(ang)
+            out[:, 4 * b + 2 * pair + 1] = rad * np.sin(ang)
+    return out[:, :act_dim]
 
 
 def synthetic_length(seed, env_id, episode, min_len, max_len):

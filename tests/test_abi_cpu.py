@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     # the ctypes table and the header must describe the same set
     assert sorted(_lib.SIGNATURES) == names
-    assert lib.ga_abi_version() == 3
+    assert lib.ga_abi_version() == 4
 
 
 def test_argument_errors_are_reported_without_a_gpu():

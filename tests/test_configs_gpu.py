@@ -1,7 +1,13 @@
-"""BASELINE.json configs[1] (C2) and configs[4] (C5) through ``-m gpu``.
+"""BASELINE.json configs[1] (C2), configs[2] (C3) and configs[4] (C5) through
+``-m gpu``.
 
-C3 (configs[2]) is covered by ``test_fullsize_gpu.py`` and the goldens.  Each of
-the other two GPU configurations gets
+C3 -- the configuration the headline metric is quoted on -- at full size is held to
+the properties of ``test_fullsize_gpu.py``; here its PRODUCTION kernels
+(``fwd_head_loss_kernel<256,1,8,true>``, ``dgrad_wgrad0_kernel<256,1,8>``,
+``mlp_eval_forward_kernel<256,1,8>``, the whole rollout in one
+``policy_step_fused_kernel`` launch) are compared with the oracle directly, with
+launch counters asserting that those kernels were the ones taken.  Each of
+the three GPU configurations gets
   (a) an oracle-parity iteration at its REAL shapes -- observation / action
       widths, network, policy head, ragged lengths, minibatches large enough to
       take the same kernel dispatch as the full-size run (C2: 64x64 tiles with the
@@ -109,6 +115,113 @@ def _oracle_iterations(cfg, n_envs, E, mb, iterations, atol_params,
                 assert d.max() <= atol_params, (k, it, d.max(), d.mean())
                 assert d.mean() <= 0.1 * atol_params, (k, it, d.max(), d.mean())
     return eps
+
+
+# csrc/prof.h: kinds of ga_launch_count
+K_FUSED_FWD, K_FUSED_DGRAD, K_NARROW, K_EVAL_FWD, K_ROLLOUT = 9, 10, 11, 12, 13
+
+
+def _launches():
+    from garage_amd import _lib
+    lib = _lib.load()
+    return {k: int(lib.ga_launch_count(k))
+            for k in (K_FUSED_FWD, K_FUSED_DGRAD, K_NARROW, K_EVAL_FWD,
+                      K_ROLLOUT)}
+
+
+@pytest.mark.parametrize('linear_adam', [False, True])
+def test_c3_shape_iteration_matches_oracle(linear_adam):
+    """obs 17, act 6, tanh MLP(256, 256) policy and value, T = P = 256: 64 envs
+    -> 16 384 samples, minibatches of 4096 rows = 64 whole 64-row tiles, i.e. the
+    dispatch of the bench (first layer + last hidden layer + head + loss in
+    ``fwd_head_loss_kernel<256,1,8,true>``, ``dgrad_wgrad0_kernel<256,1,8>``, the
+    full-batch passes in ``mlp_eval_forward_kernel<256,1,8>``), two iterations
+    against the oracle (``vpg.py:136-206``); ``linear_adam``: parameters after 8
+    steps per network of an Adam that is linear in the gradient, at 1e-6."""
+    before = _launches()
+    if linear_adam:
+        _oracle_iterations('c3', n_envs=64, E=2, mb=4096, iterations=1,
+                           atol_params=1e-6, linear_adam=True)
+        iters = 1
+    else:
+        _oracle_iterations('c3', n_envs=64, E=2, mb=4096, iterations=2,
+                           atol_params=2e-6)
+        iters = 2
+    after = _launches()
+    steps = iters * 2 * 2 * 4  # iterations x networks x epochs x minibatches
+    assert after[K_FUSED_FWD] - before[K_FUSED_FWD] == steps
+    assert after[K_FUSED_DGRAD] - before[K_FUSED_DGRAD] == steps
+    assert after[K_NARROW] == before[K_NARROW]
+    # baselines + old log-likelihoods + LossAfter / KL passes of both networks
+    assert after[K_EVAL_FWD] - before[K_EVAL_FWD] >= 4 * iters
+    # the sampler took the whole rollout in one launch per obtain_samples
+    assert after[K_ROLLOUT] - before[K_ROLLOUT] == iters
+
+
+def test_c3_whole_rollout_launch_matches_oracle_vecworker():
+    """The whole rollout of C3's policy -- MLP(256, 256), obs 17, act 6, 64 envs x
+    256 steps, device Philox action noise -- in ONE launch
+    (``policy_step_fused_kernel<true>``: weights resident on the CU) against the
+    oracle's ``VecWorker`` (``sampler/vec_worker.py:176-204``) stepping the per-env
+    CPU twins with the same noise stream: observations / lengths / step types bit
+    for bit, actions / means / rewards to 1e-5."""
+    import bench
+    from garage_amd.envs import SyntheticVecEnv
+    from garage_amd.policies import GaussianMLPPolicy
+    from garage_amd.sampler import GpuVecSampler, GpuVecWorker
+    from oracle import envs as oenvs
+    from oracle import networks as nets
+    from oracle import sampler as osamp
+    cfg = bench.CONFIGS['c3']
+    n, O, A, P = 64, cfg['obs_dim'], cfg['act_dim'], cfg['T']
+    seed = 9
+    torch.manual_seed(seed)
+    env = SyntheticVecEnv(n, O, A, P, min_len=None, seed=seed)
+    pol = GaussianMLPPolicy(env.spec, hidden_sizes=cfg['hidden'])
+    sampler = GpuVecSampler(pol, env, max_episode_length=P, n_workers=1,
+                            worker_class=GpuVecWorker, seed=seed,
+                            worker_args=dict(n_envs=n))
+    params = pol.state_dict()
+    noise_seed = seed + 7919  # GpuVecWorker: seed + 7919 (worker_number + 1)
+
+    class CpuPolicy:
+        calls = 0
+
+        def reset(self, do_resets=None):
+            pass
+
+        def get_actions(self, obs):
+            with torch.no_grad():
+                dist, info = nets.policy_forward(
+                    params, torch.from_numpy(np.asarray(obs, np.float32)))
+            z = oenvs.action_noise(noise_seed, np.arange(n), self.calls, A)
+            a = dist.mean + dist.stddev * torch.from_numpy(z)
+            self.calls += 1
+            return a.numpy(), {'mean': info['mean'].numpy()}
+
+    ref = osamp.OracleLocalSampler(
+        CpuPolicy(),
+        [[oenvs.SyntheticEnv(i, O, A, P, min_len=None, seed=seed)
+          for i in range(n)]], max_episode_length=P, n_workers=1,
+        worker_class=osamp.OracleVecWorker, worker_args=dict(n_envs=n))
+    before = _launches()[K_ROLLOUT]
+    eps = sampler.obtain_samples(0, n * P, None)
+    assert _launches()[K_ROLLOUT] - before == 1
+    want = ref.obtain_samples(0, n * P, None)
+    assert np.array_equal(eps.lengths, want.lengths)
+    assert (np.asarray(eps.lengths) == P).all()
+    assert np.array_equal([int(s) for s in eps.step_types],
+                          [int(s) for s in want.step_types])
+    assert np.array_equal(eps.observations, want.observations)  # bit exact
+    assert np.array_equal(eps.last_observations, want.last_observations)
+    assert np.allclose(eps.agent_infos['mean'], want.agent_infos['mean'],
+                       atol=1e-5, rtol=0)
+    assert np.allclose(eps.actions, want.actions, atol=1e-5, rtol=0)
+    assert np.allclose(eps.rewards, want.rewards, atol=1e-5, rtol=0)
+    # the draws are standard normal: a wrong stream would still pass "close"
+    z = (eps.actions - eps.agent_infos['mean']) / np.exp(
+        eps.agent_infos['log_std'])
+    assert abs(z.mean()) < 0.02 and abs(z.std() - 1.0) < 0.02
 
 
 def test_c2_shape_iteration_matches_oracle():

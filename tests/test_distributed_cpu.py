@@ -120,6 +120,98 @@ def _broadcast(comm):
 
 
 @pytest.mark.timeout(180)
+def _all_or_none(comm):
+    """shard_algo's native-communicator decision, two gloo ranks: the second
+    communicator fails (on every rank, as NativeComm's own handshake makes it)
+    -> the first one is released and BOTH networks fall back."""
+    import types
+    import warnings
+
+    import torch.distributed as dist
+
+    from garage_amd import distributed as D
+
+    class Net:
+
+        def __init__(self):
+            self.params = torch.full((8, ), float(comm.rank))
+            self.exp_avg = torch.zeros(8)
+            self.exp_avg_sq = torch.zeros(8)
+
+    class Old:
+        synced = False
+
+        def sync(self, policy):
+            self.synced = True
+
+    def make_algo():
+        mod = lambda: types.SimpleNamespace(net=Net())  # noqa: E731
+        opt = lambda: types.SimpleNamespace(grad_hook=None)  # noqa: E731
+        return types.SimpleNamespace(
+            policy=mod(), _value_function=mod(), _policy_optimizer=opt(),
+            _vf_optimizer=opt(), _old_policy=Old(), _comm=None)
+
+    made = []
+
+    class Fake:
+
+        def __init__(self):
+            self.alive, self.rccl_ranks = True, comm.world_size
+            made.append(self)
+
+        def destroy(self):
+            self.alive = False
+
+    real_backend, real_make = dist.get_backend, D._make_native_comm
+    dist.get_backend = lambda group=None: 'nccl'
+    try:
+        # (1) the second construction fails
+        calls = []
+
+        def flaky(c):
+            calls.append(1)
+            if len(calls) == 2:
+                raise RuntimeError('native RCCL communicator: a rank failed '
+                                   'in ga_comm_init_rank: test')
+            return Fake()
+
+        D._make_native_comm = flaky
+        algo = make_algo()
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter('always')
+            D.shard_algo(algo, comm)
+        assert len(calls) == 2 and len(made) == 1 and not made[0].alive
+        assert algo._policy_optimizer.native_comm is None
+        assert algo._vf_optimizer.native_comm is None
+        assert any('both networks' in str(x.message) for x in w)
+        assert algo._policy_optimizer.grad_hook is not None
+        text, ranks = D.gradient_exchange(algo)
+        assert 'FALLBACK' in text and ranks is None
+        # rank 0's parameters were broadcast either way
+        assert float(algo.policy.net.params.sum()) == 0.0
+        assert algo._old_policy.synced
+        # (2) both succeed -> both native
+        D._make_native_comm = lambda c: Fake()
+        algo = make_algo()
+        D.shard_algo(algo, comm)
+        assert algo._policy_optimizer.native_comm.alive
+        assert algo._vf_optimizer.native_comm.alive
+        assert algo._policy_optimizer.native_comm is not \
+            algo._vf_optimizer.native_comm
+        text, ranks = D.gradient_exchange(algo)
+        assert text.startswith('rccl all-reduce') and ranks == comm.world_size
+        # (3) a hand-made mixed state is reported as such, never as a fallback
+        algo._vf_optimizer.native_comm = None
+        text, ranks = D.gradient_exchange(algo)
+        assert text.startswith('MIXED') and ranks is None
+    finally:
+        dist.get_backend, D._make_native_comm = real_backend, real_make
+
+
+def test_native_communicators_are_all_or_none_two_ranks():
+    _run(_all_or_none)
+
+
 def test_global_advantage_moments_two_ranks():
     _run(_moments)
 

@@ -250,6 +250,58 @@ def test_data_parallel_ranks_take_the_same_number_of_optimizer_steps():
     assert OptimizerWrapper(torch.optim.Adam, None).minibatch_bounds(7) == [0, 7]
 
 
+def test_native_minibatch_split_equals_python_bounds():
+    """``ga_update_epoch*`` (C++ ``minibatch_range``) and
+    ``OptimizerWrapper.minibatch_bounds`` must cut a pass at the same ids on every
+    rank -- workspaces and the per-step gradient weights of data-parallel runs
+    are sized from the Python side (round-2 advisor finding).  Ragged counts,
+    both split modes (``BatchDataset``'s ``mb``-sized minibatches,
+    ``np/optimizers/minibatch_dataset.py:20-35``; the even split into
+    ``dp_minibatches``), through the host-only C entry point."""
+    import ctypes as C
+
+    import torch
+
+    from garage_amd import _lib
+    from garage_amd.optimizers import OptimizerWrapper, data_parallel_plan
+    lib = _lib.load()
+
+    def native(S, mb, n_mb, has_perm):
+        start, M = C.c_int64(), C.c_int64()
+        n = lib.ga_minibatch_range(S, mb, n_mb, has_perm, 0, None, None)
+        assert n >= 1, _lib.last_error() if hasattr(_lib, 'last_error') else n
+        b = []
+        for k in range(n):
+            assert lib.ga_minibatch_range(S, mb, n_mb, has_perm, k,
+                                          C.byref(start), C.byref(M)) == n
+            b.append((start.value, M.value))
+        assert all(b[k][0] + b[k][1] == b[k + 1][0] for k in range(n - 1))
+        return [x[0] for x in b] + [b[-1][0] + b[-1][1]]
+
+    rng = np.random.RandomState(1)
+    for S in [1, 5, 63, 64, 65, 127, 128, 1000, 9900, 9921, 16384, 1048576] + \
+            [int(v) for v in rng.randint(1, 20000, size=100)]:
+        for mb in (1, 7, 64, 4096, 32768):
+            opt = OptimizerWrapper(torch.optim.Adam, None, 1, mb)
+            assert native(S, mb, 0, 1) == opt.minibatch_bounds(S), (S, mb)
+        # no minibatching: one full batch, no permutation
+        assert native(S, 0, 0, 0) == \
+            OptimizerWrapper(torch.optim.Adam, None).minibatch_bounds(S)
+    for _ in range(200):
+        counts = tuple(int(v) for v in rng.randint(300, 12000,
+                                                   size=rng.randint(2, 9)))
+        if min(counts) < -(-max(counts) // 64):
+            continue
+        for r, n in enumerate(counts):
+            opt = OptimizerWrapper(torch.optim.Adam, None, 1, 64)
+            opt.dp_minibatches, opt.dp_grad_scales = \
+                data_parallel_plan(counts, 64, r)
+            assert native(n, 64, int(opt.dp_minibatches), 1) == \
+                opt.minibatch_bounds(n), (counts, r)
+    assert lib.ga_minibatch_range(0, 64, 0, 1, 0, None, None) < 0
+    assert lib.ga_minibatch_range(10, 64, 0, 1, 1, None, None) < 0
+
+
 def test_step_types_as_uint8_fast_and_fallback_paths():
     """Object arrays of the enum singletons (what garage's EpisodeBatch holds),
     integer arrays, mixed objects (plain ints among the members) and empties."""

@@ -310,3 +310,50 @@ def test_trpo_iteration_matches_oracle_larger_batch():
         assert np.allclose(v.numpy(), wpol[k], atol=2e-3 * dscale), k
     for k, v in vf.state_dict().items():
         assert np.allclose(v.numpy(), wvf[k], atol=5e-6), k
+
+
+def test_trpo_overlapped_value_passes_equal_serial_bitwise():
+    """TRPO on one GPU runs the value function's epochs on a second stream under
+    the policy step (``garage_amd.algos.TRPO._train``); the reference finishes the
+    policy first (``vpg.py:244-248``).  The two schedules must hold the same bits:
+    at C3's size (1 M samples, E = 10 x 32 minibatches, device permutations) the
+    side stream lags the host by many epochs, so a permutation that is drawn
+    lazily, or whose memory is recycled while the side stream still gathers
+    through it, shows up here as a difference (round-2 advisor finding)."""
+    import bench
+    cfg = bench.CONFIGS['c3']
+    algo, sampler, pol, S = bench.build_engine(cfg, None, seed=2,
+                                               algo_name='trpo')
+    vf = algo._value_function
+    eps = sampler.obtain_samples(0, S, None)
+
+    def snap():
+        return (pol.net.params.clone(), vf.net.params.clone(),
+                vf.net.exp_avg.clone(), vf.net.exp_avg_sq.clone(),
+                vf.net.adam_steps, algo._vf_optimizer._draws,
+                algo._old_policy.params.clone())
+
+    def restore(s):
+        pol.net.params.copy_(s[0])
+        vf.net.params.copy_(s[1])
+        vf.net.exp_avg.copy_(s[2])
+        vf.net.exp_avg_sq.copy_(s[3])
+        vf.net.adam_steps = s[4]
+        algo._vf_optimizer._draws = s[5]
+        algo._old_policy.params.copy_(s[6])
+
+    s0 = snap()
+    results = []
+    for overlap in (True, False, True):
+        restore(s0)
+        algo.overlap_updates = overlap
+        algo._train_once(0, eps)
+        torch.cuda.synchronize()
+        results.append((pol.net.params.clone(), vf.net.params.clone(),
+                        vf.net.exp_avg_sq.clone(), dict(algo.last_tabular)))
+    for got in results[1:]:
+        assert torch.equal(got[0], results[0][0])
+        assert torch.equal(got[1], results[0][1])
+        assert torch.equal(got[2], results[0][2])
+        assert got[3] == results[0][3]
+    assert not torch.equal(results[0][1], s0[1])
