@@ -584,6 +584,11 @@ int ga_set_narrow_step(int on);
  * separate launch (they are still written once for the backward pass); 0: the
  * first layer runs as its own launch. */
 int ga_set_fused_first_layer(int on);
+/* The software-pipelined k-loop of the fused forward kernels (first-layer producer,
+ * H1 spill and weight prefetch issued in the shadow of the step's MFMAs; compiled for
+ * first layers of 17 .. 20 inputs at 256 units): 1 default, 0 the plain loop (also
+ * GARAGE_AMD_PIPELINED_KLOOP=0).  Bit-identical results either way. */
+int ga_set_pipelined_kloop(int on);
 /* The policy pass and the value-function pass of one epoch, minibatch by
  * minibatch alternately on two streams.  The reference runs them back to back
  * (vpg.py:244-248); they share no written state, so the results are identical

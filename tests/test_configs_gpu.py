@@ -144,8 +144,14 @@ def test_c3_shape_iteration_matches_oracle(linear_adam):
                            atol_params=1e-6, linear_adam=True)
         iters = 1
     else:
+        # default Adam (lr 2.5e-4): the bulk of every tensor within 5e-7 of the
+        # oracle's (measured mean difference 1e-9), single elements of the
+        # 256 x 256 layer within 5e-6 -- where a gradient is ~1e-8, its last bits
+        # (summation order) decide a visible part of lr m / (sqrt(v) + 1e-8);
+        # measured max 2.6e-6 = 1 % of lr after 8 steps.  The gradients
+        # themselves are pinned at 1e-6 by the linear_adam variant.
         _oracle_iterations('c3', n_envs=64, E=2, mb=4096, iterations=2,
-                           atol_params=2e-6)
+                           atol_params=5e-6)
         iters = 2
     after = _launches()
     steps = iters * 2 * 2 * 4  # iterations x networks x epochs x minibatches

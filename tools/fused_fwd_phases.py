@@ -5,7 +5,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from garage_amd import _lib
 lib = _lib.load()
-cfg = bench.CONFIGS[sys.argv[1] if len(sys.argv) > 1 else 'c3']
+cfg = dict(bench.CONFIGS[sys.argv[1] if len(sys.argv) > 1 else 'c3'])
+if len(sys.argv) > 2:  # minibatches per epoch: 64 -> 256 tiles, one workgroup per CU
+    cfg['minibatches'] = int(sys.argv[2])
 algo, sampler, pol, S = bench.build_engine(cfg, None)
 algo.overlap_updates = False
 eps = sampler.obtain_samples(0, S, None)
@@ -22,7 +24,8 @@ for n, d in zip(names, np.diff(t)):
     print('%-30s %6.2f us' % (n, d / 100.0))
 print('total                          %6.2f us' % ((t[-1] - t[0]) / 100.0))
 
-n = 512
+n = min(512, (S // bench.n_minibatches(cfg) + 63) // 64)
+print('workgroups per launch:', n)
 sk = (C.c_longlong * (3 * n))()
 assert lib.ga_fused_fwd_debug_skew(sk, n) == 0
 a = np.array(list(sk), dtype=np.int64).reshape(n, 3) / 100.0
