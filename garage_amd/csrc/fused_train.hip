@@ -328,7 +328,9 @@ __device__ __forceinline__ void fwd_head_loss_body(const FwdLossParams& p) {
                                                      4 * (e % (BK / 4)));
           }
         }
+#ifndef GA_ABL_NOFETCH
         if constexpr (MORE) fetch_b(s + 1);
+#endif
         FT_SB;
         ft_f32x4 e4[NSUB], o4[NSUB];
         float hv[NSUB][4];
@@ -390,7 +392,11 @@ __device__ __forceinline__ void fwd_head_loss_body(const FwdLossParams& p) {
             for (int i = 0; i < TM; ++i) {
               const float4 aq = af[g & 1][i];
               const float aa = q == 0 ? aq.x : q == 1 ? aq.y : q == 2 ? aq.z : aq.w;
+#ifdef GA_ABL_NOMFMA
+              acc[i][j][slot & 15] += aa * bb;
+#else
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa, bb, acc[i][j], 0, 0, 0);
+#endif
             }
           }
           FT_SB;
@@ -402,11 +408,19 @@ __device__ __forceinline__ void fwd_head_loss_body(const FwdLossParams& p) {
                   As + (wm0 + 32 * i + l31) * LDK + 8 * (g + 1) + 4 * half);
           }
           // side tasks from slot 1 on, one per slot
+#ifdef GA_ABL_NOPRODUCE
+          if (slot - 1 == NSUB) side(slot - 1);
+#elif defined(GA_ABL_NOSPILL)
+          if (slot >= 1 && slot - 1 < TASKS && slot - 1 != NSUB) side(slot - 1);
+#else
           if (slot >= 1 && slot - 1 < TASKS) side(slot - 1);
+#endif
           FT_SB;
         }
         __builtin_amdgcn_s_setprio(0);
+#ifndef GA_ABL_NOBARRIER
         __syncthreads();
+#endif
       };
 #undef FT_SB
       const bool full = m0 + FT_ROWS <= M;

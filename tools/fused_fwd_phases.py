@@ -4,6 +4,8 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from garage_amd import _lib
+if os.environ.get('GA_VARIANT_LIB'):  # tools/ablate_fused_fwd.sh
+    _lib.LIB_PATH = os.path.abspath(os.environ['GA_VARIANT_LIB'])
 lib = _lib.load()
 cfg = dict(bench.CONFIGS[sys.argv[1] if len(sys.argv) > 1 else 'c3'])
 if len(sys.argv) > 2:  # minibatches per epoch: 64 -> 256 tiles, one workgroup per CU
