@@ -471,6 +471,12 @@ def main():
                     choices=[0, 1, 2],
                     help='A/B switch (ga_set_fused_head_forward): 0 separate '
                     'head launch, 1 default, 2 also 256-wide hidden layers')
+    ap.add_argument('--dp', action='store_true',
+                    help='with --gpus 1: run the DATA-PARALLEL code path on one GPU '
+                    '-- a real nccl (= RCCL) process group of one rank, the '
+                    'library-owned communicators, reduce -> ncclAllReduce -> Adam '
+                    'per optimizer step -- to price its launch chain against the '
+                    'plain single-process one')
     ap.add_argument('--no-overlap', action='store_true',
                     help='run the policy and value-function passes one after '
                     'the other on one stream (isolated per-kernel timings)')
@@ -480,6 +486,26 @@ def main():
         return scan_bench(args)
     from garage_amd.distributed import gradient_exchange, init_from_env
     comm = init_from_env()
+    if args.dp and comm is None:
+        # a world of ONE rank is still a real process group: shard_algo creates the
+        # RCCL communicators and every optimizer step goes through the C++ loop's
+        # data-parallel branch (a one-rank sum is the identity)
+        import socket
+
+        import torch.distributed as dist
+
+        from garage_amd.distributed import Comm
+        if args.gpus != 1:
+            raise SystemExit('bench.py: --dp prices the data-parallel path on ONE '
+                             'GPU; with --gpus N > 1 it is what runs anyway')
+        with socket.socket() as sock:
+            sock.bind(('127.0.0.1', 0))
+            port = sock.getsockname()[1]
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', str(port))
+        torch.cuda.set_device(0)
+        dist.init_process_group(backend='nccl', rank=0, world_size=1)
+        comm = Comm()
     world = comm.world_size if comm is not None else 1
     rank = comm.rank if comm is not None else 0
     if world != args.gpus:
@@ -577,6 +603,8 @@ def main():
     exchange, rccl_ranks = gradient_exchange(algo)
     line['grad_allreduce'] = exchange
     line['rccl_ranks'] = rccl_ranks
+    if args.dp:
+        line['config']['parallelism'] = 'dp1 (data-parallel code path, one rank)'
     if rows is not None:
         gemms = [rows[k] for k in GEMM_KINDS if rows[k]['launches'] > 0]
         dom = max(gemms, key=lambda r: r['total_ms'])

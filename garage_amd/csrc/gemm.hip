@@ -609,6 +609,25 @@ extern "C" int64_t ga_mlp_backward_splits(const ga_mlp_desc* d, int64_t M) {
   bool small = true;
   for (int l = 0; l <= d->n_layers; ++l) small = small && d->dims[l] <= 64;
   if (small) s = ga_ceil_div(M, 128);
+  // wide layers have many output tiles per split: fewer, longer splits then fill the
+  // chip just as well, and every split less is a slab of the whole parameter vector
+  // not written and not read back (C5, 512-wide layers: 16 tiles per split; 128 splits
+  // of 512 rows moved 744 MB of slabs per optimizer step, 64 splits of 1024 rows --
+  // 1024 workgroups for the widest layer -- move half).  256 x 256 layers (4 tiles)
+  // keep 128 splits.
+  int64_t tiles = 1;
+  for (int l = 0; l < d->n_layers; ++l) {
+    const int64_t t = ga_ceil_div(d->dims[l + 1], 128) * ga_ceil_div(d->dims[l], 128);
+    tiles = t > tiles ? t : tiles;
+  }
+  static int64_t target = -1;  // workgroups of the widest layer's weight gradient
+  if (target < 0) {
+    const char* e = getenv("GARAGE_AMD_WGRAD_WORKGROUPS");  // developer sweep
+    target = e ? atoll(e) : 1024;
+    if (target < 1) target = 1024;
+  }
+  const int64_t by_tiles = ga_ceil_div(target, tiles);
+  if (!small && s > by_tiles) s = by_tiles;
   if (s < 1) s = 1;
   if (s > 128) s = 128;
   return s;

@@ -262,3 +262,28 @@ def test_gradient_additivity_over_minibatches_c3(dev, engine):
     scale = float(full.abs().max())
     assert scale > 0
     assert float((acc - full).abs().max()) < 2e-5 * scale
+
+
+def test_scan_recurrences_hold_at_c4_footprint():
+    """The whole-episode scan at the C4 footprint (32768 rows x 256 steps, what
+    ``bench.py`` reports as ``roofline_gae_scan_c4``): the defining recurrences on
+    every cell."""
+    from garage_amd.engine import gae_scan
+    dev = torch.device('cuda', 0)
+    g = torch.Generator(device='cpu').manual_seed(3)
+    n, T = 32768, 256
+    r = torch.randn(n, T, generator=g).to(dev)
+    v = torch.randn(n, T, generator=g).to(dev)
+    adv, ret = gae_scan(r, v, discount=0.99, gae_lambda=0.97,
+                        max_episode_length=T)
+    # G_t = r_t + gamma G_{t+1};  A_t = delta_t + gamma lambda A_{t+1}
+    rd, vd, ad, gd = r.double(), v.double(), adv.double(), ret.double()
+    res_g = gd[:, :-1] - (rd[:, :-1] + 0.99 * gd[:, 1:])
+    vnext = torch.cat([vd[:, 1:], torch.zeros(n, 1, device=dev,
+                                              dtype=torch.float64)], 1)
+    g32 = float(torch.tensor(0.99, dtype=torch.float32))
+    c32 = float(torch.tensor(0.99 * 0.97, dtype=torch.float32))
+    delta = rd + g32 * vnext - vd
+    res_a = ad[:, :-1] - (delta[:, :-1] + c32 * ad[:, 1:])
+    assert float(res_g.abs().max()) < 2e-5 and float(res_a.abs().max()) < 2e-5
+    assert float((gd[:, -1] - rd[:, -1]).abs().max()) < 1e-6
