@@ -50,6 +50,16 @@
 #include "loss_rows.h"
 #include "fused_train.h"
 
+// ---- Audit (round 3) of out-of-range lanes / idle waves (the class of the round-2
+// small_step fault).  Clamped loads whose value is masked afterwards: gathered row
+// ids idx[min(m, M - 1)] (fused forward prologue, wave 0's sample, data gradient's
+// observation quads and H1 quads), first-layer inputs X[..][min(k, in_w - 1)], the
+// data gradient's observation quad min(e % 8, ld0 / 4 - 1), everything inside
+// gemm_mainloop (TileLoader clamps rows and the last k vector).  Guarded loads: W1 /
+// b1 staging (e < K * ld0 / 4, e < K), weight fragments (row wn0 + l31 < BN = the
+// layer's width, k < K since K % 32 == 0), head weights and bias (j < A), bias
+// columns (< BN).  Stores of rows >= M are predicated; per-tile partials are sized by
+// ga_update_partials_floats (tests/host/update_loop_harness.cpp, check 9).
 namespace {
 
 constexpr int FT_ROWS = 64;  // rows per workgroup tile

@@ -27,6 +27,14 @@
 #include "fused_train.h"
 #include "loss_rows.h"
 
+// ---- Audit (round 3) of out-of-range lanes / idle waves: no clamped "dead" loads in
+// this kernel.  Every global load is behind its own bounds test -- sample row
+// m = min(m0 + lane, M - 1) (wave 0 only); observation quads under m0 + rr < M &&
+// 4 q < ld0; W1 / W2 / W_head staged by loops bounded by the layer's own sizes
+// (n < H, 4 q < ld0 resp. q < H / 4, j < A); biases under tid < H resp. tid < A.  The
+// waves that have no tile at H = 32 (tile_on == false) touch LDS only.  Partial sums
+// go to part + blockIdx.x * stride with stride = ga_narrow_step_stride (checked
+// against exactly-sized buffers by tests/host/update_loop_harness.cpp, check 9).
 namespace {
 
 constexpr int NS_ROWS = 64;

@@ -24,6 +24,14 @@
 
 #include "rollout_dev.h"
 
+// ---- Audit (round 3) of out-of-range lanes / idle waves.  Clamped loads (value
+// discarded by the matching store's mask): WeightStage::load and the training
+// forward's wload -- nrow = min(f >> 3, N - 1), k = min(k0 + 4 (f & 7), last vector of
+// the row).  Guarded loads: the register-resident second layer (ncol < N && k < K,
+// a 16-B read at k <= ld - 4), biases (ncol < dims[l + 1], tid < dims[L]), the output
+// layer's [N][ld] block (e < N * ld / 4), observations (env < n && c < in_w), noise
+// rows (per env < n).  Nothing is fetched from an index derived from a wave number
+// alone.
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));

@@ -29,6 +29,27 @@
 #include "common.h"
 #include "small_step.h"
 
+// ---- Audit (round 3) of global loads whose lane / wave index can lie outside the
+// layer -- the class of the round-2 fault (idle waves of a 32-wide net prefetching
+// optimizer state past a small network's parameter buffer).  A load here is either
+// guarded by its own bounds test or issued from an index CLAMPED into the buffer (its
+// value is then discarded: a conditionally written register array would live in
+// scratch memory).  Every site, with the bound that makes it safe:
+//   p.idx[r]                live ? ... : 0            (rows >= M read nothing)
+//   p.idx[rr], X rows       rr = min(.., M - 1); q = min(.., ld0 / 4 - 1)
+//   b0[min(tid, H - 1)]; b1[c0 + tid] for tid < 16 (c0 + 15 < H); bh / Wh guarded by
+//                           tid - 16 < A, tid / 16 < A
+//   W2 columns (wc)         e = min(.., H * 4 - 1)          -> n < H, c0 + 4 q + 3 < H
+//   W1 (w0q)                e = min(.., H * ld0 / 4 - 1)
+//   W2 own rows (w2q)       e = min(.., 16 * (H / 4) - 1)   -> row c0 + 15 < H
+//   dZ2 exchange (dq)       e = min(.., 64 * (H / 4) - 1)   -> p.xdz[64][H]
+//   head shares (pv)        g < gridDim.x ? ... : 0         -> p.xh2[H / 16][64][8]
+//   Adam prefetch (ap/am/av) cj = min(cg + 4 t, H / 32 - 1)  (the round-2 fix)
+// Largest flat index over all of them: w_off[1] + H * H - 1 and b_off[2] + A - 1, both
+// inside the flat layout; the exchanges need 32 H and 64 H floats of the activation
+// workspaces (update.cpp takes this path from 32 workspace rows up: 64 H floats).
+// tests/host/update_loop_harness.cpp (check 9) restates these formulas against
+// exactly-sized buffers under AddressSanitizer.
 namespace {
 
 constexpr int SS_ROWS = 64;

@@ -150,8 +150,37 @@ int ga_small_step_supported(int n_layers, const int* dims, int64_t M) {
          dims[0] <= 32 && dims[3] <= 8 && M >= 1 && M <= 64;
 }
 int ga_small_step_resident(int, int) { return 1; }
+// (check 9 sets these: floats behind a->params / a->xh2 / a->xdz that the caller owns)
+static int64_t g_ss_n_flat = 0, g_ss_ws_floats = 0;
+static int g_ss_extent_errors = 0;
 int ga_small_step(const ga_small_step_args* a, void*) {
   logf("small_step M=%d step=%lld", a->M, (long long)a->step);
+  if (g_ss_n_flat > 0) {
+    // the largest offsets small_step_kernel's index formulas reach (small_step.hip),
+    // last workgroup (c0 = H - 16), idle waves included -- their prefetches are
+    // clamped to the layer's last tile, which is what this arithmetic restates
+    const int64_t H = a->H, ld0 = (a->in_w + 3) & ~3, A = a->out_w;
+    const int64_t c0 = H - 16;
+    int64_t reach[8];
+    reach[0] = a->w_off[0] + H * ld0 - 1;                              // W1 staging
+    reach[1] = a->w_off[1] + (H - 1) * H + c0 + 15;                    // W2 columns
+    reach[2] = a->w_off[1] + (c0 + 15) * H + H - 1;                    // W2 own rows
+    reach[3] = a->w_off[1] + (c0 + 15) * H + 32 * (H / 32 - 1) + 31;   // Adam prefetch
+    reach[4] = a->w_off[2] + (A - 1) * H + c0 + 15;                    // head columns
+    reach[5] = a->b_off[0] + H - 1;
+    reach[6] = a->b_off[1] + c0 + 15;
+    reach[7] = a->b_off[2] + A - 1;
+    for (int i = 0; i < 8; ++i)
+      if (reach[i] >= g_ss_n_flat) ++g_ss_extent_errors;
+    // the two exchanges: head shares [H / 16][64][8], dZ2 [64][H] -- written here
+    // so that AddressSanitizer sees the extents
+    memset(a->xh2, 0, sizeof(float) * (size_t)((H / 16) * 64 * 8));
+    memset(a->xdz, 0, sizeof(float) * (size_t)(64 * H));
+    if ((H / 16) * 64 * 8 > g_ss_ws_floats || 64 * H > g_ss_ws_floats)
+      ++g_ss_extent_errors;
+    // and the optimizer state at the largest index
+    a->params[reach[3]] = a->exp_avg[reach[3]] = a->exp_avg_sq[reach[3]] = 0.f;
+  }
   return 0;
 }
 int ga_act_slope_mul_f32(float*, int64_t, const float*, int64_t, int64_t M, int N, int act,
@@ -493,6 +522,56 @@ int main() {
     ga_set_fused_env_step(1);
     CHECK(ga_rollout_synth_steps(&pol.d, pol.params.data(), &h, &env, &rec, A, B, nullptr,
                                  nullptr, nullptr, 14, nullptr) != 0);  // past Tcap
+  }
+  // 9. Host-computed extents against what the kernels' index formulas reach, at the
+  //    extreme shapes (32-wide nets, 1-row minibatches, 8 outputs, 32 inputs): every
+  //    buffer is allocated at EXACTLY the size the Python side computes
+  //    (ga_update_partials_floats; activation workspaces = largest minibatch x sum of
+  //    the hidden widths; the flat parameter layout) and the fakes write / index the
+  //    kernels' full extents, so an undersized buffer is an AddressSanitizer report.
+  {
+    ga_set_fused_train(1);
+    ga_set_small_step(1);
+    const int ins[] = {1, 4, 17, 31, 32};
+    const int hs[] = {32, 64, 128, 256};
+    const int outs[] = {1, 6, 8};
+    const int64_t ms[] = {1, 31, 32, 63, 64, 65, 200, 4096};
+    int fused = 0, narrow = 0, small = 0;
+    for (int in : ins) for (int h : hs) for (int out : outs) for (int64_t M : ms) {
+      Net net(in, h, h, out);
+      const int64_t need = ga_update_partials_floats(&net.d, M);
+      std::vector<float> partials((size_t)(need > 0 ? need : 1), 1.f);
+      // activation workspaces as garage_amd/engine.py sizes them: rows x (h1 + h2)
+      const int64_t ws_floats = M * 2 * (int64_t)h;
+      std::vector<float> acts((size_t)ws_floats), dacts((size_t)ws_floats);
+      std::vector<float> flat(net.params.size()), m1(net.params.size()),
+          m2(net.params.size());
+      std::vector<int32_t> perm((size_t)M);
+      for (int64_t i = 0; i < M; ++i) perm[(size_t)i] = (int32_t)i;
+      ga_update_args a = net.args(M, M, perm.data(), out == 1 ? 1 : 0);
+      a.params = flat.data(); a.grads = flat.data();
+      a.exp_avg = m1.data(); a.exp_avg_sq = m2.data();
+      a.acts = acts.data(); a.dacts = dacts.data();
+      net.d.act_off[0] = 0; net.d.act_off[1] = M * h;
+      a.partials = need > 0 ? partials.data() : nullptr;
+      a.partials_floats = need;
+      const int64_t splits = ga_mlp_backward_splits(&net.d, M);
+      std::vector<float> slabs((size_t)(splits * (int64_t)flat.size()));
+      a.slabs = slabs.data(); a.max_splits = splits;
+      g_ss_n_flat = (int64_t)flat.size();
+      g_ss_ws_floats = ws_floats;
+      g_log.clear();
+      CHECK(ga_update_epoch(&a, nullptr) == 0);
+      fused += count("fused_fwd");
+      narrow += count("narrow M=");
+      small += count("small_step");
+      // a 2 x H net with <= 64 rows must only take the one-launch step when its two
+      // exchanges fit the activation workspaces (32 rows up)
+      if (count("small_step")) CHECK(M >= 32 && M <= 64);
+    }
+    g_ss_n_flat = 0;
+    CHECK(g_ss_extent_errors == 0);
+    CHECK(fused > 0 && narrow > 0 && small > 0);
   }
   if (g_failed) {
     fprintf(stderr, "%d check(s) failed\n", g_failed);
