@@ -231,6 +231,7 @@ SIGNATURES = {
     'ga_comm_count': (c_int, [ptr]),
     'ga_comm_destroy': (c_int, [ptr]),
     'ga_set_ordered_allreduce': (c_int, [c_int]),
+    'ga_set_merged_pair': (c_int, [c_int]),
     'ga_prof_enable': (c_int, [c_int]),
     'ga_prof_collect': (c_int, [C.POINTER(c_f64), c_int]),
     'ga_launch_count': (c_i64, [c_int]),

@@ -70,6 +70,42 @@ int ga_narrow_train_step(const float* params, const int64_t* w_off, const int64_
                          int in_w, int H, int out_w, const float* X, int64_t ldx,
                          int64_t M, const ga_fused_loss_args* loss, float* part,
                          double* lpart, hipStream_t stream);
+// ---- two networks in one launch each (the policy's and the value function's step k):
+// same shapes for both (width 256, first layer in the kernel), same row count
+int ga_fused_pair_supported(int width, int K, int in_w);
+int ga_fused_fwd_head_loss_pair(
+    int64_t M, int width, int K,
+    const float* Wa, int64_t ldwa, const float* biasa, const float* head_Wa,
+    int64_t head_ldwa, const float* head_biasa, const ga_fused_loss_args* lossa,
+    float* dZa, int64_t lddza, float* hparta, double* lparta,
+    const ga_fused_first_layer* firsta,
+    const float* Wb, int64_t ldwb, const float* biasb, const float* head_Wb,
+    int64_t head_ldwb, const float* head_biasb, const ga_fused_loss_args* lossb,
+    float* dZb, int64_t lddzb, float* hpartb, double* lpartb,
+    const ga_fused_first_layer* firstb, hipStream_t stream);
+int ga_fused_dgrad_wgrad0_pair(
+    int64_t M, int width, int K, int in_w,
+    const float* dZ2a, int64_t lddza, const float* W2a, int64_t ldwa, const float* H1a,
+    int64_t ldha, const float* Xa, int64_t ldxa, const int32_t* idxa, float* wparta,
+    const float* dZ2b, int64_t lddzb, const float* W2b, int64_t ldwb, const float* H1b,
+    int64_t ldhb, const float* Xb, int64_t ldxb, const int32_t* idxb, float* wpartb,
+    hipStream_t stream);
+// gemm.hip: the weight-gradient GEMM of the middle layer (dW2 = dZ2^T H1, split-K
+// slabs + bias column sums) of two 3-layer networks in one grid
+int ga_wgrad_mid_pair(int64_t M, int64_t n_splits, int out_w, int in_w,
+                      const float* dza, const float* ina, float* slabs_wa, float* slabs_ba,
+                      int64_t slab_stride_a,
+                      const float* dzb, const float* inb, float* slabs_wb, float* slabs_bb,
+                      int64_t slab_stride_b, hipStream_t stream);
+typedef struct ga_reduce_net {
+  const ga_fused_region* regions; int n_regions;
+  float* params; float* grads; float* exp_avg; float* exp_avg_sq;
+  int64_t step; double lr, beta1, beta2, eps; float scale; int do_adam, zero_slot0;
+  const double* lpart; int n_lpart; int64_t M; const ga_fused_loss_args* loss;
+  float* loss_out;
+} ga_reduce_net;
+int ga_reduce_regions_adam_pair(const ga_reduce_net* a, const ga_reduce_net* b,
+                                hipStream_t stream);
 int ga_reduce_regions_adam(const ga_fused_region* regions, int n_regions, float* params,
                            float* grads, float* exp_avg, float* exp_avg_sq, int64_t step,
                            double lr, double beta1, double beta2, double eps, float scale,

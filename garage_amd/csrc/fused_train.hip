@@ -92,9 +92,9 @@ struct FwdLossParams {
 // FT_STAMP: timestamp i of workgroup 8; FT_MARK: slot (0 start, 1 end of the k-loop,
 // 2 end) of EVERY workgroup, behind the 16 values of workgroup 8: the skew of a launch
 #define FT_STAMP(i) \
-  if (p.dbg && blockIdx.x == 8 && threadIdx.x == 0) p.dbg[i] = wall_clock64()
+  if (p.dbg && ft_tile == 8 && threadIdx.x == 0) p.dbg[i] = wall_clock64()
 #define FT_MARK(slot) \
-  if (p.dbg && threadIdx.x == 0) p.dbg[16 + 3 * blockIdx.x + (slot)] = wall_clock64()
+  if (p.dbg && threadIdx.x == 0) p.dbg[16 + 3 * ft_tile + (slot)] = wall_clock64()
 
 typedef const __attribute__((address_space(4))) float* ft_uniform_ptr;
 typedef float ft_f32x4 __attribute__((ext_vector_type(4)));
@@ -146,8 +146,12 @@ __device__ __forceinline__ void ft_kstep(const float* As, const float* Bs,
 // KSC > 0 (with L1): round4(inputs) / 4 is the compile-time constant KSC and the
 // k-loop is the software-pipelined one (see "pipelined k-loop" below); 0: any width,
 // the plain loop.
+// ft_tile / ft_tiles: this workgroup's 64-row tile and the number of tiles of ITS
+// network's minibatch (a pair launch carries the tiles of two networks in one grid)
 template <int BN, int WAVES_M, int WAVES_N, bool L1, bool EVAL, int KSC = 0>
-__device__ __forceinline__ void fwd_head_loss_body(const FwdLossParams& p) {
+__device__ __forceinline__ void fwd_head_loss_body(const FwdLossParams& p,
+                                                   const int ft_tile,
+                                                   const int ft_tiles) {
   static_assert(L1 || !EVAL, "the evaluation forward computes the first layer itself");
   static_assert(L1 || KSC == 0, "KSC belongs to the first-layer producer");
   constexpr int NT = 64 * WAVES_M * WAVES_N;
@@ -180,7 +184,7 @@ __device__ __forceinline__ void fwd_head_loss_body(const FwdLossParams& p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm0 = (wave / WAVES_N) * WM;
   const int wn0 = (wave % WAVES_N) * WN;
-  const int m0 = blockIdx.x * FT_ROWS;
+  const int m0 = ft_tile * FT_ROWS;
   const int M = p.g.M;
   const LossRowArgs& L = p.loss;
 
@@ -499,7 +503,7 @@ __device__ __forceinline__ void fwd_head_loss_body(const FwdLossParams& p) {
     }
 #ifdef GA_FT_LOOP_STAMPS
     if (p.dbg && tid == 0) {
-      long long* o = p.dbg + 16 + 3 * 4096 + 4 * blockIdx.x;
+      long long* o = p.dbg + 16 + 3 * 4096 + 4 * ft_tile;
       o[0] = c_mma; o[1] = c_bar1; o[2] = c_store; o[3] = c_bar2;
     }
 #endif
@@ -656,8 +660,8 @@ __device__ __forceinline__ void fwd_head_loss_body(const FwdLossParams& p) {
     first = ga_wave_sum(first);
     second = ga_wave_sum(second);
     if (lane == 0) {
-      p.lpart[2 * blockIdx.x + 0] = first;
-      p.lpart[2 * blockIdx.x + 1] = second;
+      p.lpart[2 * ft_tile + 0] = first;
+      p.lpart[2 * ft_tile + 1] = second;
     }
   } else {
     for (int e = tid - 64; e < HN * (BN / 4); e += NT - 64) {
@@ -719,7 +723,7 @@ __device__ __forceinline__ void fwd_head_loss_body(const FwdLossParams& p) {
 #pragma unroll
       for (int jj = 0; jj < JPG; ++jj) g[jj] = fmaf(doutl[r * HN + j0 + jj], h, g[jj]);
     }
-    float* hp = p.hpart + (int64_t)blockIdx.x * (HN * BN + HN);
+    float* hp = p.hpart + (int64_t)ft_tile * (HN * BN + HN);
 #pragma unroll
     for (int jj = 0; jj < JPG; ++jj) hp[(j0 + jj) * BN + c] = g[jj];
     if (tid < HN) {
@@ -729,7 +733,7 @@ __device__ __forceinline__ void fwd_head_loss_body(const FwdLossParams& p) {
     }
   }
   };
-  if (blockIdx.x >= (gridDim.x + 1) / 2) {
+  if (ft_tile >= (ft_tiles + 1) / 2) {
     phase_head_grad();
     FT_STAMP(7);
     phase_dz();
@@ -746,14 +750,36 @@ template <int BN, int WAVES_M, int WAVES_N, bool L1 = false, int KSC = 0>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N,
                              WAVES_M * WAVES_N == 8 ? 4 : 2) void fwd_head_loss_kernel(
     FwdLossParams p) {
-  fwd_head_loss_body<BN, WAVES_M, WAVES_N, L1, false, KSC>(p);
+  fwd_head_loss_body<BN, WAVES_M, WAVES_N, L1, false, KSC>(p, (int)blockIdx.x,
+                                                           (int)gridDim.x);
+}
+
+// The same step of TWO networks (the policy's and the value function's minibatch k:
+// vpg.py:244-248 runs them one after the other, neither reads what the other
+// writes) in one grid: workgroup b takes tile b / 2 of network b % 2.  Twice the
+// workgroups per launch: the second generation starts as first-generation
+// workgroups retire, one launch ramp and drain instead of two, and -- unlike two
+// free-running streams -- the same schedule every time.
+struct FwdLossPair {
+  FwdLossParams a, b;
+};
+template <int BN, int WAVES_M, int WAVES_N, int KSC>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N,
+                             WAVES_M * WAVES_N == 8 ? 4 : 2) void fwd_head_loss_pair_kernel(
+    FwdLossPair pp) {
+  const int tile = (int)(blockIdx.x >> 1), tiles = (int)(gridDim.x >> 1);
+  if (blockIdx.x & 1)
+    fwd_head_loss_body<BN, WAVES_M, WAVES_N, true, false, KSC>(pp.b, tile, tiles);
+  else
+    fwd_head_loss_body<BN, WAVES_M, WAVES_N, true, false, KSC>(pp.a, tile, tiles);
 }
 
 template <int BN, int WAVES_M, int WAVES_N, int KSC = 0>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N,
                              WAVES_M * WAVES_N == 8 ? 4 : 2) void mlp_eval_forward_kernel(
     FwdLossParams p) {
-  fwd_head_loss_body<BN, WAVES_M, WAVES_N, true, true, KSC>(p);
+  fwd_head_loss_body<BN, WAVES_M, WAVES_N, true, true, KSC>(p, (int)blockIdx.x,
+                                                            (int)gridDim.x);
 }
 
 // The pipelined k-loop is compiled for first layers of 17 .. 20 inputs (KSC = 5: the
@@ -783,9 +809,8 @@ struct DgradWgrad0Params {
 };
 
 template <int BN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N,
-                             WAVES_M * WAVES_N == 8 ? 4 : 2) void dgrad_wgrad0_kernel(
-    DgradWgrad0Params p) {
+__device__ __forceinline__ void dgrad_wgrad0_body(const DgradWgrad0Params& p,
+                                                  const int ft_tile) {
   constexpr int NT = 64 * WAVES_M * WAVES_N;
   constexpr int WM = FT_ROWS / WAVES_M, WN = BN / WAVES_N;
   constexpr int TM = WM / 32, TN = WN / 32;
@@ -807,7 +832,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N,
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm0 = (wave / WAVES_N) * WM;
   const int wn0 = (wave % WAVES_N) * WN;
-  const int m0 = blockIdx.x * FT_ROWS;
+  const int m0 = ft_tile * FT_ROWS;
   const int M = p.g.M;
   const int ld0 = (p.in_w + 3) & ~3;
 
@@ -903,7 +928,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N,
   // and of db1[n] (column sums of dZ1)
   {
     const int half = lane >> 5, l31 = lane & 31;
-    float* wp = p.wpart + (int64_t)blockIdx.x * ((int64_t)BN * ld0 + BN);
+    float* wp = p.wpart + (int64_t)ft_tile * ((int64_t)BN * ld0 + BN);
     for (int t = wave; t < BN / 32; t += NT / 64) {
       f32x16 acc0, acc1;
 #pragma unroll
@@ -941,6 +966,28 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N,
   FT_MARK(2);
 }
 
+template <int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N,
+                             WAVES_M * WAVES_N == 8 ? 4 : 2) void dgrad_wgrad0_kernel(
+    DgradWgrad0Params p) {
+  dgrad_wgrad0_body<BN, WAVES_M, WAVES_N>(p, (int)blockIdx.x);
+}
+
+struct DgradWgrad0Pair {
+  DgradWgrad0Params a, b;
+};
+// two networks in one grid (see fwd_head_loss_pair_kernel)
+template <int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N,
+                             WAVES_M * WAVES_N == 8 ? 4 : 2) void dgrad_wgrad0_pair_kernel(
+    DgradWgrad0Pair pp) {
+  const int tile = (int)(blockIdx.x >> 1);
+  if (blockIdx.x & 1)
+    dgrad_wgrad0_body<BN, WAVES_M, WAVES_N>(pp.b, tile);
+  else
+    dgrad_wgrad0_body<BN, WAVES_M, WAVES_N>(pp.a, tile);
+}
+
 // ---------------------------------------------------------------------------
 struct FtAdam {  // losses.hip: AdamParams / adam_update
   float* p; float* m; float* v;
@@ -967,22 +1014,28 @@ struct FtRegion {
   int n_part;
   int quads;          // quads per workgroup: 64 or 16
   int64_t vbeg;       // first workgroup of the region
+  int net;            // which network's buffers (a pair launch steps two)
 };
-struct ReduceRegionsParams {
-  FtRegion r[FT_MAX_REGIONS];
-  int n_regions;
-  int64_t n_virtual;  // workgroups over all regions
+struct FtNet {
   FtAdam a;
   float* grads;       // the reduced (scaled) gradient is also written here
   float scale;
   int do_adam;        // 0: stop after writing grads (an all-reduce follows)
   int zero_slot0;     // the log-std slot is not trained
-  // loss finish (one extra block): batch sums -> loss value, log-std gradient
+  // loss finish (one extra block per network): batch sums -> loss value, log-std
+  // gradient
   const double* lpart;
   int n_lpart;
   int64_t M;
   LossRowArgs loss;
   float* loss_out;
+};
+struct ReduceRegionsParams {
+  FtRegion r[FT_MAX_REGIONS];
+  int n_regions;
+  int n_nets;         // 1 or 2
+  int64_t n_virtual;  // workgroups over all regions
+  FtNet net[2];
 };
 
 __global__ __launch_bounds__(256) void reduce_regions_adam_kernel(ReduceRegionsParams p) {
@@ -990,26 +1043,28 @@ __global__ __launch_bounds__(256) void reduce_regions_adam_kernel(ReduceRegionsP
   // chain's GEMM-class kernel (traced: 17-57 us there against 11 us alone): its waves
   // go first on the CU.  Interleaved A/B on one box: C3 9.13 -> 9.80 M env-steps/s.
   __builtin_amdgcn_s_setprio(3);
-  if (blockIdx.x == gridDim.x - 1) {
-    // ---- the loss scalars and the log-std slot (flat index 0), one wave
+  if ((int64_t)blockIdx.x >= p.n_virtual) {
+    // ---- the loss scalars and the log-std slot (flat index 0) of one network, one
+    //      wave
     if (threadIdx.x >= 64) return;
+    const FtNet& N = p.net[(int64_t)blockIdx.x - p.n_virtual];
     double first = 0.0, second = 0.0;
-    for (int b = threadIdx.x; b < p.n_lpart; b += 64) {
-      first += p.lpart[2 * b + 0];
-      second += p.lpart[2 * b + 1];
+    for (int b = threadIdx.x; b < N.n_lpart; b += 64) {
+      first += N.lpart[2 * b + 0];
+      second += N.lpart[2 * b + 1];
     }
     first = ga_wave_sum(first);
     second = ga_wave_sum(second);
     if (threadIdx.x != 0) return;
     float loss, dls;
-    lr_finish(p.loss, first, second, p.M, &loss, &dls);
-    if (p.loss_out) *p.loss_out = loss;
-    float g = p.zero_slot0 ? 0.f : dls * p.scale;
-    p.grads[0] = g;
-    if (p.do_adam) {
-      float pp = p.a.p[0], mm = p.a.m[0], vv = p.a.v[0];
-      ft_adam_update(p.a, g, pp, mm, vv);
-      p.a.p[0] = pp; p.a.m[0] = mm; p.a.v[0] = vv;
+    lr_finish(N.loss, first, second, N.M, &loss, &dls);
+    if (N.loss_out) *N.loss_out = loss;
+    float g = N.zero_slot0 ? 0.f : dls * N.scale;
+    N.grads[0] = g;
+    if (N.do_adam) {
+      float pp = N.a.p[0], mm = N.a.m[0], vv = N.a.v[0];
+      ft_adam_update(N.a, g, pp, mm, vv);
+      N.a.p[0] = pp; N.a.m[0] = mm; N.a.v[0] = vv;
     }
     return;
   }
@@ -1027,6 +1082,7 @@ __global__ __launch_bounds__(256) void reduce_regions_adam_kernel(ReduceRegionsP
   for (int k = 1; k < p.n_regions; ++k)
     if (b >= p.r[k].vbeg) ri = k;
   const FtRegion& R = p.r[ri];
+  const FtNet& N = p.net[R.net];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int Q = R.quads;  // 64 or 16
   const int lwc = 64 / Q;
@@ -1073,19 +1129,19 @@ __global__ __launch_bounds__(256) void reduce_regions_adam_kernel(ReduceRegionsP
   }
   const int64_t i = R.beg + 4 * e4;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) g[j] *= p.scale;
-  *reinterpret_cast<float4*>(p.grads + i) = make_float4(g[0], g[1], g[2], g[3]);
-  if (p.do_adam) {
-    float4 p4 = *reinterpret_cast<float4*>(p.a.p + i);
-    float4 m4 = *reinterpret_cast<float4*>(p.a.m + i);
-    float4 v4 = *reinterpret_cast<float4*>(p.a.v + i);
+  for (int j = 0; j < 4; ++j) g[j] *= N.scale;
+  *reinterpret_cast<float4*>(N.grads + i) = make_float4(g[0], g[1], g[2], g[3]);
+  if (N.do_adam) {
+    float4 p4 = *reinterpret_cast<float4*>(N.a.p + i);
+    float4 m4 = *reinterpret_cast<float4*>(N.a.m + i);
+    float4 v4 = *reinterpret_cast<float4*>(N.a.v + i);
     float pp[4] = {p4.x, p4.y, p4.z, p4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w},
           vv[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) ft_adam_update(p.a, g[j], pp[j], mm[j], vv[j]);
-    *reinterpret_cast<float4*>(p.a.p + i) = make_float4(pp[0], pp[1], pp[2], pp[3]);
-    *reinterpret_cast<float4*>(p.a.m + i) = make_float4(mm[0], mm[1], mm[2], mm[3]);
-    *reinterpret_cast<float4*>(p.a.v + i) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    for (int j = 0; j < 4; ++j) ft_adam_update(N.a, g[j], pp[j], mm[j], vv[j]);
+    *reinterpret_cast<float4*>(N.a.p + i) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+    *reinterpret_cast<float4*>(N.a.m + i) = make_float4(mm[0], mm[1], mm[2], mm[3]);
+    *reinterpret_cast<float4*>(N.a.v + i) = make_float4(vv[0], vv[1], vv[2], vv[3]);
   }
 }
 
@@ -1172,14 +1228,13 @@ extern "C" int ga_fused_first_layer_ok(int in_w, int K) {
          (int64_t)K * ((in_w + 3) & ~3) <= FT_W1_FLOATS;
 }
 
-extern "C" int ga_fused_fwd_head_loss(const float* A, int64_t lda, const int32_t* a_idx,
-                                      const float* W, int64_t ldw, const float* bias,
-                                      int64_t M, int width, int K, const float* head_W,
-                                      int64_t head_ldw, const float* head_bias,
-                                      const ga_fused_loss_args* loss, float* dZ,
-                                      int64_t lddz, float* hpart, double* lpart,
-                                      const ga_fused_first_layer* first,
-                                      hipStream_t stream) {
+// validation + kernel parameters of one network's launch
+static int fwd_build(const float* A, int64_t lda, const int32_t* a_idx, const float* W,
+                     int64_t ldw, const float* bias, int64_t M, int width, int K,
+                     const float* head_W, int64_t head_ldw, const float* head_bias,
+                     const ga_fused_loss_args* loss, float* dZ, int64_t lddz,
+                     float* hpart, double* lpart, const ga_fused_first_layer* first,
+                     FwdLossParams* out, double* flops_out) {
   GA_REQUIRE((A || first) && W && bias && head_W && head_bias && loss && dZ && hpart &&
                  lpart,
              "ga_fused_fwd_head_loss: null pointer");
@@ -1209,15 +1264,13 @@ extern "C" int ga_fused_fwd_head_loss(const float* A, int64_t lda, const int32_t
              "ga_fused_fwd_head_loss: missing / misaligned minibatch arrays");
   GA_REQUIRE(loss->kind == 2 || loss->log_std, "ga_fused_fwd_head_loss: log_std");
   GA_REQUIRE(loss->algo == 0 || loss->algo == 1, "ga_fused_fwd_head_loss: algo");
-  FwdLossParams p;
+  FwdLossParams& p = *out;
   memset(&p, 0, sizeof(p));
   p.g.A = A; p.g.lda = lda; p.g.a_idx = a_idx; p.g.B = W; p.g.ldb = ldw;
   p.g.M = (int)M; p.g.N = width; p.g.K = K; p.g.bias = bias;
   p.head_W = head_W; p.head_ldw = head_ldw; p.head_bias = head_bias;
   p.loss = loss_args(loss, M);
   p.dZ = dZ; p.lddz = lddz; p.hpart = hpart; p.lpart = lpart;
-  p.dbg = ga_fused_tiles(M) <= FT_DBG_BLOCKS ? g_ft_dbg : nullptr;
-  const dim3 grid((unsigned)ga_fused_tiles(M));
   // algorithmic flops of the layers computed
   double flops = 2.0 * (double)M * width * ((double)K + loss->A);
   if (first) {
@@ -1225,6 +1278,25 @@ extern "C" int ga_fused_fwd_head_loss(const float* A, int64_t lda, const int32_t
     p.l1_in = first->in_w; p.l1_H = first->H; p.l1_ldh = first->ldh;
     flops += 2.0 * (double)M * K * first->in_w;
   }
+  *flops_out = flops;
+  return GA_OK;
+}
+
+extern "C" int ga_fused_fwd_head_loss(const float* A, int64_t lda, const int32_t* a_idx,
+                                      const float* W, int64_t ldw, const float* bias,
+                                      int64_t M, int width, int K, const float* head_W,
+                                      int64_t head_ldw, const float* head_bias,
+                                      const ga_fused_loss_args* loss, float* dZ,
+                                      int64_t lddz, float* hpart, double* lpart,
+                                      const ga_fused_first_layer* first,
+                                      hipStream_t stream) {
+  FwdLossParams p;
+  double flops = 0.0;
+  const int rc = fwd_build(A, lda, a_idx, W, ldw, bias, M, width, K, head_W, head_ldw,
+                           head_bias, loss, dZ, lddz, hpart, lpart, first, &p, &flops);
+  if (rc) return rc;
+  p.dbg = ga_fused_tiles(M) <= FT_DBG_BLOCKS ? g_ft_dbg : nullptr;
+  const dim3 grid((unsigned)ga_fused_tiles(M));
   hipEvent_t e0 = nullptr, e1 = nullptr;
   ga_prof_events(GA_PROF_FUSED_FWD, flops, &e0, &e1);
   if (first && width == 64)
@@ -1249,6 +1321,49 @@ extern "C" int ga_fused_fwd_head_loss(const float* A, int64_t lda, const int32_t
     hipExtLaunchKernelGGL((fwd_head_loss_kernel<256, 1, 8>), grid, dim3(512), 0, stream,
                           e0, e1, 0, p);
   GA_CHECK_LAUNCH("fwd_head_loss");
+  return GA_OK;
+}
+
+// Pair launches are compiled for 256-wide last hidden layers with the first layer in
+// the kernel (the C3-class networks the two-chain schedule was built for).
+extern "C" int ga_fused_pair_supported(int width, int K, int in_w) {
+  return width == 256 && K <= 256 && ga_fused_first_layer_ok(in_w, K);
+}
+
+// The two networks' launches of ga_fused_fwd_head_loss (first layer in the kernel) in
+// ONE grid; both must have the same width, K, input width and row count.
+extern "C" int ga_fused_fwd_head_loss_pair(
+    int64_t M, int width, int K,
+    const float* Wa, int64_t ldwa, const float* biasa, const float* head_Wa,
+    int64_t head_ldwa, const float* head_biasa, const ga_fused_loss_args* lossa,
+    float* dZa, int64_t lddza, float* hparta, double* lparta,
+    const ga_fused_first_layer* firsta,
+    const float* Wb, int64_t ldwb, const float* biasb, const float* head_Wb,
+    int64_t head_ldwb, const float* head_biasb, const ga_fused_loss_args* lossb,
+    float* dZb, int64_t lddzb, float* hpartb, double* lpartb,
+    const ga_fused_first_layer* firstb, hipStream_t stream) {
+  GA_REQUIRE(firsta && firstb && firsta->in_w == firstb->in_w &&
+                 ga_fused_pair_supported(width, K, firsta->in_w),
+             "ga_fused_fwd_head_loss_pair: unsupported shapes");
+  FwdLossPair pp;
+  double fa = 0.0, fb = 0.0;
+  int rc = fwd_build(nullptr, 0, nullptr, Wa, ldwa, biasa, M, width, K, head_Wa, head_ldwa,
+                     head_biasa, lossa, dZa, lddza, hparta, lparta, firsta, &pp.a, &fa);
+  if (rc) return rc;
+  rc = fwd_build(nullptr, 0, nullptr, Wb, ldwb, biasb, M, width, K, head_Wb, head_ldwb,
+                 head_biasb, lossb, dZb, lddzb, hpartb, lpartb, firstb, &pp.b, &fb);
+  if (rc) return rc;
+  const dim3 grid((unsigned)(2 * ga_fused_tiles(M)));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  ga_prof_events(GA_PROF_FUSED_FWD, fa + fb, &e0, &e1);
+  ga_prof_count(GA_PROF_FUSED_FWD);  // (one launch, two networks' steps)
+  if ((firsta->in_w + 3) / 4 == 5 && pipelined_kloop_on())
+    hipExtLaunchKernelGGL((fwd_head_loss_pair_kernel<256, 1, 8, 5>), grid, dim3(512), 0,
+                          stream, e0, e1, 0, pp);
+  else
+    hipExtLaunchKernelGGL((fwd_head_loss_pair_kernel<256, 1, 8, 0>), grid, dim3(512), 0,
+                          stream, e0, e1, 0, pp);
+  GA_CHECK_LAUNCH("fwd_head_loss_pair");
   return GA_OK;
 }
 
@@ -1298,11 +1413,10 @@ extern "C" int ga_fused_eval_forward(const float* X, int64_t ldx, const int32_t*
   return GA_OK;
 }
 
-extern "C" int ga_fused_dgrad_wgrad0(const float* dZ2, int64_t lddz, const float* W2,
-                                     int64_t ldw, int64_t M, int width, int K,
-                                     const float* H1, int64_t ldh, const float* X,
-                                     int64_t ldx, const int32_t* idx, int in_w,
-                                     float* wpart, hipStream_t stream) {
+static int dgrad_build(const float* dZ2, int64_t lddz, const float* W2, int64_t ldw,
+                       int64_t M, int width, int K, const float* H1, int64_t ldh,
+                       const float* X, int64_t ldx, const int32_t* idx, int in_w,
+                       float* wpart, DgradWgrad0Params* out, double* flops_out) {
   GA_REQUIRE(dZ2 && W2 && H1 && X && wpart, "ga_fused_dgrad_wgrad0: null pointer");
   GA_REQUIRE(ga_fused_width_ok(width) && M >= 1 && M < (1ll << 31) && K >= 1 &&
                  in_w >= 1 && in_w <= 32,
@@ -1311,15 +1425,28 @@ extern "C" int ga_fused_dgrad_wgrad0(const float* dZ2, int64_t lddz, const float
                  ldx >= ((in_w + 3) & ~3) && ga_aligned16(dZ2) && ga_aligned16(W2) &&
                  ga_aligned16(H1) && ga_aligned16(X) && ga_aligned16(wpart),
              "ga_fused_dgrad_wgrad0: operands must be 16-B aligned quads");
-  DgradWgrad0Params p;
+  DgradWgrad0Params& p = *out;
   memset(&p, 0, sizeof(p));
   p.g.A = dZ2; p.g.lda = lddz; p.g.B = W2; p.g.ldb = ldw;
   p.g.M = (int)M; p.g.N = width; p.g.K = K;
   p.H = H1; p.ldh = ldh; p.X = X; p.ldx = ldx; p.idx = idx; p.in_w = in_w;
   p.wpart = wpart;
+  *flops_out = 2.0 * (double)M * width * ((double)K + in_w);
+  return GA_OK;
+}
+
+extern "C" int ga_fused_dgrad_wgrad0(const float* dZ2, int64_t lddz, const float* W2,
+                                     int64_t ldw, int64_t M, int width, int K,
+                                     const float* H1, int64_t ldh, const float* X,
+                                     int64_t ldx, const int32_t* idx, int in_w,
+                                     float* wpart, hipStream_t stream) {
+  DgradWgrad0Params p;
+  double flops = 0.0;
+  const int rc = dgrad_build(dZ2, lddz, W2, ldw, M, width, K, H1, ldh, X, ldx, idx, in_w,
+                             wpart, &p, &flops);
+  if (rc) return rc;
   p.dbg = ga_fused_tiles(M) <= FT_DBG_BLOCKS ? g_dg_dbg : nullptr;
   const dim3 grid((unsigned)ga_fused_tiles(M));
-  const double flops = 2.0 * (double)M * width * ((double)K + in_w);
   hipEvent_t e0 = nullptr, e1 = nullptr;
   ga_prof_events(GA_PROF_FUSED_DGRAD, flops, &e0, &e1);
   if (width == 64)
@@ -1335,21 +1462,46 @@ extern "C" int ga_fused_dgrad_wgrad0(const float* dZ2, int64_t lddz, const float
   return GA_OK;
 }
 
-extern "C" int ga_reduce_regions_adam(const ga_fused_region* regions, int n_regions,
-                                      float* params, float* grads, float* exp_avg,
-                                      float* exp_avg_sq, int64_t step, double lr,
-                                      double beta1, double beta2, double eps, float scale,
-                                      int do_adam, int zero_slot0, const double* lpart,
-                                      int n_lpart, int64_t M,
-                                      const ga_fused_loss_args* loss, float* loss_out,
-                                      hipStream_t stream) {
+// two networks' launches of ga_fused_dgrad_wgrad0 in one grid (width 256)
+extern "C" int ga_fused_dgrad_wgrad0_pair(
+    int64_t M, int width, int K, int in_w,
+    const float* dZ2a, int64_t lddza, const float* W2a, int64_t ldwa, const float* H1a,
+    int64_t ldha, const float* Xa, int64_t ldxa, const int32_t* idxa, float* wparta,
+    const float* dZ2b, int64_t lddzb, const float* W2b, int64_t ldwb, const float* H1b,
+    int64_t ldhb, const float* Xb, int64_t ldxb, const int32_t* idxb, float* wpartb,
+    hipStream_t stream) {
+  GA_REQUIRE(width == 256, "ga_fused_dgrad_wgrad0_pair: unsupported width");
+  DgradWgrad0Pair pp;
+  double fa = 0.0, fb = 0.0;
+  int rc = dgrad_build(dZ2a, lddza, W2a, ldwa, M, width, K, H1a, ldha, Xa, ldxa, idxa,
+                       in_w, wparta, &pp.a, &fa);
+  if (rc) return rc;
+  rc = dgrad_build(dZ2b, lddzb, W2b, ldwb, M, width, K, H1b, ldhb, Xb, ldxb, idxb, in_w,
+                   wpartb, &pp.b, &fb);
+  if (rc) return rc;
+  const dim3 grid((unsigned)(2 * ga_fused_tiles(M)));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  ga_prof_events(GA_PROF_FUSED_DGRAD, fa + fb, &e0, &e1);
+  ga_prof_count(GA_PROF_FUSED_DGRAD);
+  hipExtLaunchKernelGGL((dgrad_wgrad0_pair_kernel<256, 1, 8>), grid, dim3(512), 0, stream,
+                        e0, e1, 0, pp);
+  GA_CHECK_LAUNCH("dgrad_wgrad0_pair");
+  return GA_OK;
+}
+
+// regions + optimizer constants of one network into slot `net` of the launch
+static int reduce_add_net(ReduceRegionsParams& p, int net, const ga_fused_region* regions,
+                          int n_regions, float* params, float* grads, float* exp_avg,
+                          float* exp_avg_sq, int64_t step, double lr, double beta1,
+                          double beta2, double eps, float scale, int do_adam,
+                          int zero_slot0, const double* lpart, int n_lpart, int64_t M,
+                          const ga_fused_loss_args* loss, float* loss_out) {
   GA_REQUIRE(regions && params && grads && exp_avg && exp_avg_sq && lpart && loss,
              "ga_reduce_regions_adam: null pointer");
-  GA_REQUIRE(n_regions >= 1 && n_regions <= FT_MAX_REGIONS && step >= 1 && n_lpart >= 1,
+  GA_REQUIRE(n_regions >= 1 && p.n_regions + n_regions <= FT_MAX_REGIONS && step >= 1 &&
+                 n_lpart >= 1,
              "ga_reduce_regions_adam: bad arguments");
-  ReduceRegionsParams p;
-  memset(&p, 0, sizeof(p));
-  int64_t v = 0;
+  int64_t v = p.n_virtual;
   for (int k = 0; k < n_regions; ++k) {
     // regions are walked 4 elements at a time: the flat layout pads every weight
     // row and bias vector to a multiple of 4 floats, and the padding of every
@@ -1358,30 +1510,74 @@ extern "C" int ga_reduce_regions_adam(const ga_fused_region* regions, int n_regi
                    regions[k].beg >= 4 && regions[k].beg % 4 == 0 &&
                    regions[k].stride % 4 == 0 && ga_aligned16(regions[k].src),
                "ga_reduce_regions_adam: bad region %d", k);
-    p.r[k].beg = regions[k].beg; p.r[k].n = (regions[k].n + 3) & ~(int64_t)3;
-    p.r[k].src = regions[k].src;
-    p.r[k].stride = regions[k].stride; p.r[k].n_part = regions[k].n_part;
-    p.r[k].quads = regions[k].n_part <= 128 ? 64 : 16;
-    p.r[k].vbeg = v;
-    v += ga_ceil_div(p.r[k].n / 4, p.r[k].quads);  // workgroups of this region
+    FtRegion& r = p.r[p.n_regions + k];
+    r.beg = regions[k].beg; r.n = (regions[k].n + 3) & ~(int64_t)3;
+    r.src = regions[k].src;
+    r.stride = regions[k].stride; r.n_part = regions[k].n_part;
+    r.quads = regions[k].n_part <= 128 ? 64 : 16;
+    r.vbeg = v;
+    r.net = net;
+    v += ga_ceil_div(r.n / 4, r.quads);  // workgroups of this region
   }
-  p.n_regions = n_regions;
+  p.n_regions += n_regions;
   p.n_virtual = v;
-  p.a.p = params; p.a.m = exp_avg; p.a.v = exp_avg_sq;
-  p.a.lerp_w = (float)(1.0 - beta1);
-  p.a.beta2 = (float)beta2;
-  p.a.one_minus_beta2 = (float)(1.0 - beta2);
+  FtNet& N = p.net[net];
+  N.a.p = params; N.a.m = exp_avg; N.a.v = exp_avg_sq;
+  N.a.lerp_w = (float)(1.0 - beta1);
+  N.a.beta2 = (float)beta2;
+  N.a.one_minus_beta2 = (float)(1.0 - beta2);
   const double bc1 = 1.0 - pow(beta1, (double)step);
   const double bc2 = 1.0 - pow(beta2, (double)step);
-  p.a.neg_step_size = (float)(-(lr / bc1));
-  p.a.bc2_sqrt = (float)sqrt(bc2);
-  p.a.eps = (float)eps;
-  p.grads = grads; p.scale = scale; p.do_adam = do_adam; p.zero_slot0 = zero_slot0;
-  p.lpart = lpart; p.n_lpart = n_lpart; p.M = M;
-  p.loss = loss_args(loss, M);
-  p.loss_out = loss_out;
-  const unsigned blocks = (unsigned)v + 1;  // + the loss block
+  N.a.neg_step_size = (float)(-(lr / bc1));
+  N.a.bc2_sqrt = (float)sqrt(bc2);
+  N.a.eps = (float)eps;
+  N.grads = grads; N.scale = scale; N.do_adam = do_adam; N.zero_slot0 = zero_slot0;
+  N.lpart = lpart; N.n_lpart = n_lpart; N.M = M;
+  N.loss = loss_args(loss, M);
+  N.loss_out = loss_out;
+  return GA_OK;
+}
+
+extern "C" int ga_reduce_regions_adam(const ga_fused_region* regions, int n_regions,
+                                      float* params, float* grads, float* exp_avg,
+                                      float* exp_avg_sq, int64_t step, double lr,
+                                      double beta1, double beta2, double eps, float scale,
+                                      int do_adam, int zero_slot0, const double* lpart,
+                                      int n_lpart, int64_t M,
+                                      const ga_fused_loss_args* loss, float* loss_out,
+                                      hipStream_t stream) {
+  ReduceRegionsParams p;
+  memset(&p, 0, sizeof(p));
+  const int rc = reduce_add_net(p, 0, regions, n_regions, params, grads, exp_avg,
+                                exp_avg_sq, step, lr, beta1, beta2, eps, scale, do_adam,
+                                zero_slot0, lpart, n_lpart, M, loss, loss_out);
+  if (rc) return rc;
+  p.n_nets = 1;
+  const unsigned blocks = (unsigned)p.n_virtual + 1;  // + the loss block
   hipLaunchKernelGGL(reduce_regions_adam_kernel, dim3(blocks), dim3(256), 0, stream, p);
   GA_CHECK_LAUNCH("reduce_regions_adam");
+  return GA_OK;
+}
+
+// both networks' optimizer steps in one launch (regions of two flat buffers, two loss
+// blocks); the same per-element arithmetic and summation trees as two single launches
+extern "C" int ga_reduce_regions_adam_pair(const ga_reduce_net* a, const ga_reduce_net* b,
+                                           hipStream_t stream) {
+  GA_REQUIRE(a && b, "ga_reduce_regions_adam_pair: null pointer");
+  ReduceRegionsParams p;
+  memset(&p, 0, sizeof(p));
+  const ga_reduce_net* nets[2] = {a, b};
+  for (int i = 0; i < 2; ++i) {
+    const ga_reduce_net* n = nets[i];
+    const int rc = reduce_add_net(p, i, n->regions, n->n_regions, n->params, n->grads,
+                                  n->exp_avg, n->exp_avg_sq, n->step, n->lr, n->beta1,
+                                  n->beta2, n->eps, n->scale, n->do_adam, n->zero_slot0,
+                                  n->lpart, n->n_lpart, n->M, n->loss, n->loss_out);
+    if (rc) return rc;
+  }
+  p.n_nets = 2;
+  const unsigned blocks = (unsigned)p.n_virtual + 2;  // + the two loss blocks
+  hipLaunchKernelGGL(reduce_regions_adam_kernel, dim3(blocks), dim3(256), 0, stream, p);
+  GA_CHECK_LAUNCH("reduce_regions_adam_pair");
   return GA_OK;
 }

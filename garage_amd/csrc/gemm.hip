@@ -100,13 +100,10 @@ __device__ __forceinline__ void head_on_staged_rows(const GemmParams& p,
   }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KC, bool B_KC,
-          int BKT = BK, bool HEAD = false>
-#ifdef GA_GEMM_WAVES_PER_EU  // A/B builds (tools/build_variants.sh)
-__attribute__((amdgpu_waves_per_eu(GA_GEMM_WAVES_PER_EU, 8)))
-#endif
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_f32_kernel(
-    GemmParams p) {
+// bid: the workgroup's linear id within ITS problem (a pair launch carries two)
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KC, bool B_KC, int BKT,
+          bool HEAD>
+__device__ __forceinline__ void gemm_f32_body(const GemmParams& p, const int bid) {
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int TM = WM / 32, TN = WN / 32;
   // row-contiguous operands: [BK][BR + PAD]; k-contiguous ones: [BR][BK + PAD]
@@ -131,11 +128,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_f32_kernel(
   // split shares the split's A and B rows
   int bx, by, bz;
   if (p.gz == 1) {
-    ga_xcd_group((int)blockIdx.x, p.gx, p.gy, &bx, &by);
+    ga_xcd_group(bid, p.gx, p.gy, &bx, &by);
     bz = 0;
   } else {
     int mem;
-    ga_xcd_group((int)blockIdx.x, p.gz, p.gx * p.gy, &bz, &mem);
+    ga_xcd_group(bid, p.gz, p.gx * p.gy, &bz, &mem);
     bx = mem % p.gx;
     by = mem / p.gx;
   }
@@ -279,6 +276,32 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_f32_kernel(
     if ((int)threadIdx.x < W && base + (int)threadIdx.x < lim)
       p.colsum[(int64_t)split * p.colsum_split_stride + base + threadIdx.x] = csum;
   }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KC, bool B_KC,
+          int BKT = BK, bool HEAD = false>
+#ifdef GA_GEMM_WAVES_PER_EU  // A/B builds (tools/build_variants.sh)
+__attribute__((amdgpu_waves_per_eu(GA_GEMM_WAVES_PER_EU, 8)))
+#endif
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_f32_kernel(
+    GemmParams p) {
+  gemm_f32_body<BM, BN, WAVES_M, WAVES_N, A_KC, B_KC, BKT, HEAD>(p, (int)blockIdx.x);
+}
+
+// Two problems of the same shape in one grid (the policy's and the value function's
+// weight-gradient GEMM of one optimizer step): workgroup b takes workgroup b / 2 of
+// problem b % 2 (see fwd_head_loss_pair_kernel, fused_train.hip).
+struct GemmPair {
+  GemmParams a, b;
+};
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_f32_pair_kernel(
+    GemmPair pp) {
+  const int bid = (int)(blockIdx.x >> 1);
+  if (blockIdx.x & 1)
+    gemm_f32_body<BM, BN, WAVES_M, WAVES_N, A_KC, B_KC, BK, false>(pp.b, bid);
+  else
+    gemm_f32_body<BM, BN, WAVES_M, WAVES_N, A_KC, B_KC, BK, false>(pp.a, bid);
 }
 
 static int g_small_m = 1;
@@ -641,6 +664,60 @@ extern "C" int ga_mlp_backward_range_f32(const ga_mlp_desc* d, const float* para
                                          int64_t slab_stride, int64_t n_splits,
                                          int l_start, int fused_first,
                                          hipStream_t stream);
+
+// dW = dz^T in (+ db = column sums of dz) of the MIDDLE layer of two 3-layer networks,
+// both out_w x in_w with 33 .. wide sides (the 128 x 128-tile kernel), split-K over the
+// M rows into n_splits slabs each: the launch ga_mlp_backward_range_f32 makes for
+// layer 1 with fused_first = 1, for two networks in one grid.  Same tiles, same k
+// ranges, same summation order per element.
+extern "C" int ga_wgrad_mid_pair(int64_t M, int64_t n_splits, int out_w, int in_w,
+                                 const float* dza, const float* ina, float* slabs_wa,
+                                 float* slabs_ba, int64_t slab_stride_a,
+                                 const float* dzb, const float* inb, float* slabs_wb,
+                                 float* slabs_bb, int64_t slab_stride_b,
+                                 hipStream_t stream) {
+  GA_REQUIRE(dza && ina && slabs_wa && slabs_ba && dzb && inb && slabs_wb && slabs_bb,
+             "ga_wgrad_mid_pair: null pointer");
+  GA_REQUIRE(M > 0 && M < (1ll << 31) && n_splits >= 1 && n_splits <= 1024 &&
+                 out_w > 64 && in_w > 64 && slab_stride_a % 4 == 0 &&
+                 slab_stride_b % 4 == 0,
+             "ga_wgrad_mid_pair: unsupported shape");
+  GA_REQUIRE(ga_aligned16(dza) && ga_aligned16(ina) && ga_aligned16(slabs_wa) &&
+                 ga_aligned16(dzb) && ga_aligned16(inb) && ga_aligned16(slabs_wb),
+             "ga_wgrad_mid_pair: pointers must be 16-B aligned");
+  const int kps = (int)(ga_ceil_div(ga_ceil_div(M, n_splits), BK) * BK);
+  GemmPair pp;
+  const float* dz[2] = {dza, dzb};
+  const float* in[2] = {ina, inb};
+  float* sw[2] = {slabs_wa, slabs_wb};
+  float* sb[2] = {slabs_ba, slabs_bb};
+  const int64_t ss[2] = {slab_stride_a, slab_stride_b};
+  for (int i = 0; i < 2; ++i) {
+    GemmParams& p = i ? pp.b : pp.a;
+    memset(&p, 0, sizeof(p));
+    p.K = (int)M;
+    p.k_per_split = kps;
+    p.epi = EPI_PLAIN;
+    p.c_split_stride = ss[i];
+    p.colsum = sb[i];
+    p.colsum_split_stride = ss[i];
+    p.A = dz[i]; p.lda = round4(out_w); p.B = in[i]; p.ldb = round4(in_w);
+    p.M = out_w; p.N = in_w;
+    p.C = sw[i]; p.c_rs = round4(in_w); p.c_cs = 1;
+    p.colsum_of_b = 0;
+    p.gx = (int)ga_ceil_div(p.M, 128); p.gy = (int)ga_ceil_div(p.N, 128);
+    p.gz = (int)n_splits;
+  }
+  const double flops = 2.0 * 2.0 * (double)out_w * (double)in_w * (double)M;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  ga_prof_events(GA_PROF_GEMM_TN_128, flops, &e0, &e1);
+  ga_prof_count(GA_PROF_GEMM_TN_128);
+  const dim3 grid((unsigned)(2 * pp.a.gx * pp.a.gy * pp.a.gz));
+  hipExtLaunchKernelGGL((gemm_f32_pair_kernel<128, 128, 2, 4, false, false>), grid,
+                        dim3(512), 0, stream, e0, e1, 0, pp);
+  GA_CHECK_LAUNCH("gemm_f32_pair");
+  return GA_OK;
+}
 
 extern "C" int ga_mlp_backward_f32(const ga_mlp_desc* d, const float* params,
                                    const float* X, int64_t ldx,

@@ -568,6 +568,180 @@ extern "C" int ga_update_epoch(const ga_update_args* a, ga_stream_t stream) {
   return 0;
 }
 
+// 1 (opt-in; GARAGE_AMD_MERGED_PAIR=1): when both passes take the fused 256-wide
+// kernels with the same shapes, ga_update_epoch_pair runs step k of BOTH networks as
+// four launches on ONE stream -- each launch a grid over the tiles of both
+// (fused_train.hip / gemm.hip *_pair kernels) -- instead of two free-running
+// four-launch chains on two streams.  Same arithmetic per network (bit-identical
+// results) and the same schedule every time, but measured SLOWER than the two
+// streams (round 3, C3: 114.2 ms per iteration against 110.0-111.8 in the two-stream
+// mode's slow phase regime, 106 in its fast one, 116.2 on one stream): a pair launch
+// takes exactly twice a single one (114.0 us against 2 x 57.2), because a CU's
+// throughput on these kernels does not improve with more co-resident tiles of the
+// SAME kernel -- what the two streams overlap is DIFFERENT
+// kernels.  0 (default): the two-stream schedule.
+static int g_merged_pair = -1;
+extern "C" int ga_set_merged_pair(int on) {
+  g_merged_pair = on != 0;
+  return 0;
+}
+static int merged_pair_on() {
+  if (g_merged_pair < 0) {
+    const char* e = getenv("GARAGE_AMD_MERGED_PAIR");
+    g_merged_pair = (e && e[0] == '1') ? 1 : 0;
+  }
+  return g_merged_pair;
+}
+
+namespace {
+
+struct MergedNet {
+  ga_fused_loss_args la;
+  ga_fused_first_layer fl;
+  double* lpart;
+  float* hpart;
+  float* wpart;
+  ga_fused_region reg[8];
+  int nr;
+};
+
+// can step k of the two passes run as pair launches?
+bool merged_ok(const ga_update_args* a, const ga_update_args* b, int64_t k) {
+  const ga_update_args* two[2] = {a, b};
+  int64_t M0 = 0, start;
+  for (int i = 0; i < 2; ++i) {
+    const ga_update_args* x = two[i];
+    int64_t M;
+    minibatch_range(x, k, &start, &M);
+    if (i == 0) M0 = M;
+    if (M != M0 || M <= 64) return false;
+    const ga_mlp_desc* d = x->desc;
+    if (x->comm || x->phase != 0 || !g_fused_train || g_fuse_head || !x->partials ||
+        x->kind < 0 || x->kind > 2 || (x->algo != 0 && x->algo != 1) || !x->acts ||
+        !x->dacts || d->n_layers != 3)
+      return false;
+    const FusedPlan f = fused_plan(d, M);
+    if (!f.ok || f.narrow || !f.first || f.floats > x->partials_floats) return false;
+    if (!fused_first_layer_on() || !ga_fused_first_layer_ok(d->dims[0], d->dims[1]))
+      return false;
+    // (the pair kernels are compiled for two 256-wide hidden layers)
+    if (!ga_fused_pair_supported(d->dims[2], d->dims[1], d->dims[0]) || d->dims[1] != 256)
+      return false;
+    if (d->dims[0] != a->desc->dims[0] || d->dims[1] != a->desc->dims[1] ||
+        d->dims[2] != a->desc->dims[2])
+      return false;
+    if (ga_mlp_backward_splits(d, M) > x->max_splits) return false;
+  }
+  return ga_mlp_backward_splits(a->desc, M0) == ga_mlp_backward_splits(b->desc, M0);
+}
+
+void merged_fill(const ga_update_args* a, const FusedPlan& f, const int32_t* idx,
+                 int64_t splits, MergedNet* n) {
+  const ga_mlp_desc* d = a->desc;
+  auto r4 = [](int v) { return (int64_t)((v + 3) & ~3); };
+  const int out_w = d->dims[3];
+  ga_fused_loss_args& la = n->la;
+  memset(&la, 0, sizeof(la));
+  la.kind = a->kind; la.actions = a->actions; la.lda = a->lda; la.old_ll = a->old_ll;
+  la.adv = a->adv; la.returns = a->returns; la.idx = idx; la.log_std = a->params;
+  la.has_min = a->has_min; la.has_max = a->has_max; la.min_log_std = a->min_log_std;
+  la.max_log_std = a->max_log_std; la.A = out_w; la.algo = a->algo; la.clip = a->clip;
+  la.ent_coeff = a->ent_coeff; la.ent_flags = a->ent_flags;
+  la.double_softmax = a->double_softmax;
+  n->lpart = reinterpret_cast<double*>(a->partials + f.lpart_off);
+  n->hpart = a->partials + f.hpart_off;
+  n->wpart = a->partials + f.wpart_off;
+  ga_fused_first_layer& fl = n->fl;
+  fl.X = a->X; fl.ldx = a->ldx; fl.W = a->params + d->w_off[0];
+  fl.b = a->params + d->b_off[0]; fl.in_w = d->dims[0];
+  fl.H = a->acts + d->act_off[0]; fl.ldh = r4(d->dims[1]);
+  // the parameter regions, exactly as run_minibatch_fused lists them
+  const int wl = d->dims[2];
+  n->nr = 0;
+  for (int l = 0; l < 3; ++l) {
+    const int64_t wn = (int64_t)d->dims[l + 1] * r4(d->dims[l]);
+    ga_fused_region& w = n->reg[n->nr++];
+    ga_fused_region& bb = n->reg[n->nr++];
+    w.beg = d->w_off[l]; w.n = wn;
+    bb.beg = d->b_off[l]; bb.n = d->dims[l + 1];
+    if (l == 2) {
+      w.src = n->hpart; bb.src = n->hpart + 8 * (int64_t)wl;
+      w.stride = bb.stride = f.hstride; w.n_part = bb.n_part = (int)f.tiles;
+    } else if (l == 0) {
+      w.src = n->wpart; bb.src = n->wpart + wn;
+      w.stride = bb.stride = f.wstride; w.n_part = bb.n_part = (int)f.tiles;
+    } else {
+      w.src = a->slabs + d->w_off[l]; bb.src = a->slabs + d->b_off[l];
+      w.stride = bb.stride = a->n_flat; w.n_part = bb.n_part = (int)splits;
+    }
+  }
+}
+
+// step k of both passes: four pair launches on `stream_`
+int run_minibatch_merged(const ga_update_args* a, const ga_update_args* b, int64_t k,
+                         ga_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  auto r4 = [](int v) { return (int64_t)((v + 3) & ~3); };
+  int64_t sa, sb, M, Mb;
+  minibatch_range(a, k, &sa, &M);
+  minibatch_range(b, k, &sb, &Mb);
+  const ga_mlp_desc* da = a->desc;
+  const ga_mlp_desc* db = b->desc;
+  const int64_t splits = ga_mlp_backward_splits(da, M);
+  const FusedPlan fa = fused_plan(da, M), fb = fused_plan(db, M);
+  const int32_t* ia = a->perm ? a->perm + sa : nullptr;
+  const int32_t* ib = b->perm ? b->perm + sb : nullptr;
+  MergedNet na, nb;
+  merged_fill(a, fa, ia, splits, &na);
+  merged_fill(b, fb, ib, splits, &nb);
+  const int in_w = da->dims[0], K = da->dims[1], wl = da->dims[2];
+  GA_TRACE(stream_, "merged step k=%lld M=%lld", (long long)k, (long long)M);
+  int rc = ga_fused_fwd_head_loss_pair(
+      M, wl, K,
+      a->params + da->w_off[1], r4(K), a->params + da->b_off[1],
+      a->params + da->w_off[2], r4(wl), a->params + da->b_off[2], &na.la,
+      a->dacts + da->act_off[1], r4(wl), na.hpart, na.lpart, &na.fl,
+      b->params + db->w_off[1], r4(K), b->params + db->b_off[1],
+      b->params + db->w_off[2], r4(wl), b->params + db->b_off[2], &nb.la,
+      b->dacts + db->act_off[1], r4(wl), nb.hpart, nb.lpart, &nb.fl, stream);
+  if (rc) return rc;
+  rc = ga_wgrad_mid_pair(M, splits, wl, K,
+                         a->dacts + da->act_off[1], a->acts + da->act_off[0],
+                         a->slabs + da->w_off[1], a->slabs + da->b_off[1], a->n_flat,
+                         b->dacts + db->act_off[1], b->acts + db->act_off[0],
+                         b->slabs + db->w_off[1], b->slabs + db->b_off[1], b->n_flat,
+                         stream);
+  if (rc) return rc;
+  rc = ga_fused_dgrad_wgrad0_pair(
+      M, K, wl, in_w,
+      a->dacts + da->act_off[1], r4(wl), a->params + da->w_off[1], r4(K),
+      a->acts + da->act_off[0], r4(K), a->X, a->ldx, ia, na.wpart,
+      b->dacts + db->act_off[1], r4(wl), b->params + db->w_off[1], r4(K),
+      b->acts + db->act_off[0], r4(K), b->X, b->ldx, ib, nb.wpart, stream);
+  if (rc) return rc;
+  ga_reduce_net ra, rb;
+  const ga_update_args* two[2] = {a, b};
+  MergedNet* nets[2] = {&na, &nb};
+  const FusedPlan* plans[2] = {&fa, &fb};
+  ga_reduce_net* rr[2] = {&ra, &rb};
+  for (int i = 0; i < 2; ++i) {
+    const ga_update_args* x = two[i];
+    ga_reduce_net& r = *rr[i];
+    r.regions = nets[i]->reg; r.n_regions = nets[i]->nr;
+    r.params = x->params; r.grads = x->grads; r.exp_avg = x->exp_avg;
+    r.exp_avg_sq = x->exp_avg_sq; r.step = x->step0 + k + 1; r.lr = x->lr;
+    r.beta1 = x->beta1; r.beta2 = x->beta2; r.eps = x->eps; r.scale = step_scale(x, k);
+    r.do_adam = 1; r.zero_slot0 = !x->learn_std; r.lpart = nets[i]->lpart;
+    r.n_lpart = (int)plans[i]->tiles; r.M = M; r.loss = &nets[i]->la;
+    r.loss_out = x->losses ? x->losses + k : x->loss_scratch;
+  }
+  return ga_reduce_regions_adam_pair(&ra, &rb, stream);
+}
+
+hipEvent_t g_merge_events[2] = {nullptr, nullptr};
+
+}  // namespace
+
 extern "C" int ga_update_epoch_pair(const ga_update_args* a, ga_stream_t stream_a,
                                     const ga_update_args* b, ga_stream_t stream_b) {
   int rc = check_args(a);
@@ -580,6 +754,42 @@ extern "C" int ga_update_epoch_pair(const ga_update_args* a, ga_stream_t stream_
     return -1;
   }
   const int64_t na = n_minibatches(a), nb = n_minibatches(b);
+  if (merged_pair_on() && na == nb) {
+    bool all = true;
+    for (int64_t k = 0; k < na && all; ++k) all = merged_ok(a, b, k);
+    if (all) {
+      // everything goes to stream_a; stream_b is ordered around it, so that work the
+      // caller enqueues on either stream before / after this epoch sees the same
+      // dependencies as with the two-stream schedule
+      for (int i = 0; i < 2; ++i)
+        if (!g_merge_events[i] &&
+            hipEventCreateWithFlags(&g_merge_events[i], hipEventDisableTiming) !=
+                hipSuccess) {
+          g_merge_events[i] = nullptr;
+          ga_set_error("ga_update_epoch_pair: cannot create events");
+          return -2;
+        }
+      if (stream_a != stream_b) {
+        if (hipEventRecord(g_merge_events[0], (hipStream_t)stream_b) != hipSuccess ||
+            hipStreamWaitEvent((hipStream_t)stream_a, g_merge_events[0], 0) != hipSuccess) {
+          ga_set_error("ga_update_epoch_pair: stream ordering failed");
+          return -2;
+        }
+      }
+      for (int64_t k = 0; k < na; ++k) {
+        rc = run_minibatch_merged(a, b, k, stream_a);
+        if (rc) return rc;
+      }
+      if (stream_a != stream_b) {
+        if (hipEventRecord(g_merge_events[1], (hipStream_t)stream_a) != hipSuccess ||
+            hipStreamWaitEvent((hipStream_t)stream_b, g_merge_events[1], 0) != hipSuccess) {
+          ga_set_error("ga_update_epoch_pair: stream ordering failed");
+          return -2;
+        }
+      }
+      return 0;
+    }
+  }
   ArOrder oa, ob;
   if (g_ordered_allreduce && a->comm && b->comm) {
     if (!ar_events_ready()) {

@@ -621,6 +621,13 @@ int ga_comm_destroy(void* comm);
  * A's collective while its peer sits in network B's.  0: no such edges (the two
  * collectives may run concurrently; they are small enough to co-reside). */
 int ga_set_ordered_allreduce(int on);
+/* ga_update_epoch_pair, one process: 1 (opt-in, also GARAGE_AMD_MERGED_PAIR=1) step k of
+ * BOTH passes as four launches on stream_a, each a grid over the tiles of both networks
+ * (when both take the fused 256-wide kernels with the same shapes; stream_b is ordered
+ * around the epoch); 0 (default) two four-launch chains on the two streams.
+ * Bit-identical results; the merged schedule is the same every time but measured
+ * slower. */
+int ga_set_merged_pair(int on);
 
 /* ---- measurement ----------------------------------------------------------
  * Optional HIP-event timing of every GEMM / scan launch on its own stream

@@ -232,6 +232,66 @@ int ga_reduce_regions_adam(const ga_fused_region* r, int n, float*, float*, floa
   if (loss_out) *loss_out = 1.f;
   return 0;
 }
+// ---- pair launches (two networks per grid): the fakes write the same extents
+int ga_fused_pair_supported(int width, int K, int in_w) {
+  return width == 256 && K <= 256 && ga_fused_first_layer_ok(in_w, K);
+}
+int ga_fused_fwd_head_loss_pair(
+    int64_t M, int width, int K, const float*, int64_t, const float*, const float*, int64_t,
+    const float*, const ga_fused_loss_args* la, float*, int64_t, float* hpa, double* lpa,
+    const ga_fused_first_layer* fa, const float*, int64_t, const float*, const float*,
+    int64_t, const float*, const ga_fused_loss_args* lb, float*, int64_t, float* hpb,
+    double* lpb, const ga_fused_first_layer* fb, hipStream_t s) {
+  logf("pair_fwd stream=%p M=%lld width=%d K=%d A=%d/%d in=%d/%d", (void*)s, (long long)M,
+       width, K, la->A, lb->A, fa->in_w, fb->in_w);
+  const int64_t tiles = ga_fused_tiles(M);
+  float* hp[2] = {hpa, hpb};
+  double* lp[2] = {lpa, lpb};
+  for (int i = 0; i < 2; ++i)
+    for (int64_t t = 0; t < tiles; ++t) {
+      lp[i][2 * t] = lp[i][2 * t + 1] = 0.0;
+      memset(hp[i] + t * (8 * (int64_t)width + 8), 0, sizeof(float) * (8 * width + 8));
+    }
+  return 0;
+}
+int ga_wgrad_mid_pair(int64_t M, int64_t n_splits, int out_w, int in_w, const float*,
+                      const float*, float* swa, float* sba, int64_t ssa, const float*,
+                      const float*, float* swb, float* sbb, int64_t ssb, hipStream_t s) {
+  logf("pair_wgrad stream=%p M=%lld splits=%lld out=%d in=%d", (void*)s, (long long)M,
+       (long long)n_splits, out_w, in_w);
+  float* sw[2] = {swa, swb};
+  float* sb[2] = {sba, sbb};
+  const int64_t ss[2] = {ssa, ssb};
+  for (int i = 0; i < 2; ++i)
+    for (int64_t k = 0; k < n_splits; ++k) {
+      memset(sw[i] + k * ss[i], 0, sizeof(float) * (size_t)out_w * in_w);
+      memset(sb[i] + k * ss[i], 0, sizeof(float) * (size_t)out_w);
+    }
+  return 0;
+}
+int ga_fused_dgrad_wgrad0_pair(int64_t M, int width, int K, int in_w, const float*, int64_t,
+                               const float*, int64_t, const float*, int64_t, const float*,
+                               int64_t, const int32_t*, float* wpa, const float*, int64_t,
+                               const float*, int64_t, const float*, int64_t, const float*,
+                               int64_t, const int32_t*, float* wpb, hipStream_t s) {
+  logf("pair_dgrad stream=%p M=%lld width=%d K=%d in=%d", (void*)s, (long long)M, width, K,
+       in_w);
+  const int64_t ld0 = (in_w + 3) & ~3, tiles = ga_fused_tiles(M);
+  float* wp[2] = {wpa, wpb};
+  for (int i = 0; i < 2; ++i)
+    for (int64_t t = 0; t < tiles; ++t)
+      memset(wp[i] + t * (width * ld0 + width), 0, sizeof(float) * (width * ld0 + width));
+  return 0;
+}
+int ga_reduce_regions_adam_pair(const ga_reduce_net* a, const ga_reduce_net* b,
+                                hipStream_t s) {
+  logf("pair_reduce stream=%p steps=%lld/%lld regions=%d/%d adam=%d/%d M=%lld", (void*)s,
+       (long long)a->step, (long long)b->step, a->n_regions, b->n_regions, a->do_adam,
+       b->do_adam, (long long)a->M);
+  if (a->loss_out) *a->loss_out = 1.f;
+  if (b->loss_out) *b->loss_out = 1.f;
+  return 0;
+}
 int ga_narrow_step_supported(int n_layers, const int* dims) {
   return n_layers == 3 && dims[1] == dims[2] && (dims[1] == 32 || dims[1] == 64) &&
          dims[0] <= 32 && dims[3] <= 8;
@@ -522,6 +582,81 @@ int main() {
     ga_set_fused_env_step(1);
     CHECK(ga_rollout_synth_steps(&pol.d, pol.params.data(), &h, &env, &rec, A, B, nullptr,
                                  nullptr, nullptr, 14, nullptr) != 0);  // past Tcap
+  }
+  // 8b. Two 256-wide passes with equal shapes: ga_update_epoch_pair runs step k of
+  //     both as four pair launches on stream_a, ordered against stream_b on both
+  //     sides; a different minibatch count, a data-parallel communicator or
+  //     ga_set_merged_pair(0) give the two-stream schedule back
+  {
+    extern int ga_set_merged_pair(int on);
+    ga_set_fused_train(1);
+    ga_set_merged_pair(1);  // (opt-in: the two-stream schedule is the default)
+    Net pol(17, 256, 256, 6), vf(17, 256, 256, 1);
+    const int64_t S = 1000, mb = 300;  // 4 minibatches: 300, 300, 300, 100
+    std::vector<int32_t> pp((size_t)S), pv((size_t)S);
+    for (int64_t i = 0; i < S; ++i) { pp[(size_t)i] = (int32_t)i; pv[(size_t)i] = (int32_t)(S - 1 - i); }
+    const int64_t need = ga_update_partials_floats(&pol.d, mb);
+    CHECK(need > 0 && need == ga_update_partials_floats(&vf.d, mb));
+    std::vector<float> partp((size_t)need), partv((size_t)need);
+    const int64_t splits = ga_mlp_backward_splits(&pol.d, mb);
+    std::vector<float> slp((size_t)(splits * (int64_t)pol.params.size())),
+        slv((size_t)(splits * (int64_t)vf.params.size()));
+    std::vector<float> ap((size_t)(mb * 512)), dp((size_t)(mb * 512)), av((size_t)(mb * 512)),
+        dv((size_t)(mb * 512));
+    auto mk = [&](Net& n, std::vector<int32_t>& perm, int kind, std::vector<float>& part,
+                  std::vector<float>& slabs, std::vector<float>& acts,
+                  std::vector<float>& dacts) {
+      ga_update_args a = n.args(S, mb, perm.data(), kind);
+      a.partials = part.data(); a.partials_floats = need;
+      a.slabs = slabs.data(); a.max_splits = splits;
+      a.acts = acts.data(); a.dacts = dacts.data();
+      n.d.act_off[0] = 0; n.d.act_off[1] = mb * 256;
+      return a;
+    };
+    ga_update_args a = mk(pol, pp, 0, partp, slp, ap, dp);
+    ga_update_args b = mk(vf, pv, 1, partv, slv, av, dv);
+    std::vector<double> ws_b(2048, 0.0);
+    b.workspace = ws_b.data();
+    a.step0 = 10; b.step0 = 20;
+    g_log.clear();
+    {
+      const int rc8 = ga_update_epoch_pair(&a, (void*)0x10, &b, (void*)0x20);
+      if (rc8) fprintf(stderr, "8b: rc %d error '%s'\n", rc8, g_error.c_str());
+      if (getenv("GA_HARNESS_DUMP"))
+        for (auto& l : g_log) fprintf(stderr, "  | %s\n", l.c_str());
+      CHECK(rc8 == 0);
+    }
+    CHECK(count("pair_fwd stream=0x10") == 4 && count("pair_wgrad stream=0x10") == 4);
+    CHECK(count("pair_dgrad stream=0x10") == 4 && count("pair_reduce stream=0x10") == 4);
+    CHECK(count("pair_fwd stream=0x10 M=300 width=256 K=256 A=6/1 in=17/17") == 3);
+    CHECK(count("pair_fwd stream=0x10 M=100") == 1);
+    CHECK(count("pair_reduce stream=0x10 steps=11/21 regions=6/6 adam=1/1 M=300") == 1);
+    CHECK(count("pair_reduce stream=0x10 steps=14/24") == 1);
+    CHECK(count("fused_fwd") == 0 && count("reduce_regions") == 0);
+    // stream_a first waits for what stream_b holds, stream_b then for the epoch
+    CHECK(g_log.size() > 4 && g_log[0].rfind("record stream=0x20", 0) == 0 &&
+          g_log[1].rfind("wait stream=0x10", 0) == 0 &&
+          g_log[g_log.size() - 2].rfind("record stream=0x10", 0) == 0 &&
+          g_log.back().rfind("wait stream=0x20", 0) == 0);
+    // the two-stream schedule on request
+    ga_set_merged_pair(0);
+    g_log.clear();
+    CHECK(ga_update_epoch_pair(&a, (void*)0x10, &b, (void*)0x20) == 0);
+    CHECK(count("pair_") == 0 && count("fused_fwd") == 8 && count("reduce_regions n=") == 8);
+    ga_set_merged_pair(1);
+    // data parallel: never merged (each chain's all-reduce hides under the other)
+    ga_set_allreduce_hook(fake_allreduce);
+    a.comm = b.comm = (void*)0x1; a.world = b.world = 2; a.grad_scale = b.grad_scale = 0.5f;
+    g_log.clear();
+    CHECK(ga_update_epoch_pair(&a, (void*)0x10, &b, (void*)0x20) == 0);
+    CHECK(count("pair_") == 0 && count("allreduce") == 8);
+    a.comm = b.comm = nullptr;
+    // unequal minibatch counts: not merged
+    b.mb = 250;
+    g_log.clear();
+    CHECK(ga_update_epoch_pair(&a, (void*)0x10, &b, (void*)0x20) == 0);
+    CHECK(count("pair_") == 0 && count("fused_fwd") == 8);
+    ga_set_merged_pair(0);
   }
   // 9. Host-computed extents against what the kernels' index formulas reach, at the
   //    extreme shapes (32-wide nets, 1-row minibatches, 8 outputs, 32 inputs): every

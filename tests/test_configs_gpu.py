@@ -373,3 +373,46 @@ def test_c2_full_size_properties():
 def test_c5_full_size_properties():
     """8192 envs, obs 376, act 17, MLP(512, 512, 512), ragged lengths, P = 256."""
     _full_size_properties('c5')
+
+
+def test_c3_merged_pair_launches_equal_two_streams_bitwise():
+    """``ga_set_merged_pair(1)``: step k of the policy and of the value function as
+    four launches over the tiles of BOTH networks (``fwd_head_loss_pair_kernel``,
+    ``gemm_f32_pair_kernel``, ``dgrad_wgrad0_pair_kernel``, one
+    ``reduce_regions_adam_kernel`` for two flat buffers) -- the deterministic
+    alternative to the two free-running streams (opt-in: measured slower).  Same
+    arithmetic per network: the same bits as the two-stream and the one-stream
+    schedule at C3's full size, and half the launches."""
+    import bench
+    from garage_amd import _lib
+    lib = _lib.load()
+    cfg = bench.CONFIGS['c3']
+    algo, sampler, pol, S = bench.build_engine(cfg, None, seed=4)
+    eps = sampler.obtain_samples(0, S, None)
+    snap = _snapshot(algo)
+    out = []
+    launches = []
+    for merged, overlap in ((1, True), (0, True), (0, False)):
+        _restore(algo, snap)
+        lib.ga_set_merged_pair(merged)
+        algo.overlap_updates = overlap
+        before = _launches()
+        n0 = int(lib.ga_launch_count(2))  # weight-gradient GEMM kind
+        algo._train_once(0, eps)
+        torch.cuda.synchronize()
+        after = _launches()
+        launches.append((after[K_FUSED_FWD] - before[K_FUSED_FWD],
+                         int(lib.ga_launch_count(2)) - n0))
+        out.append((pol.net.params.clone(),
+                    algo._value_function.net.params.clone(),
+                    algo._value_function.net.exp_avg_sq.clone(),
+                    dict(algo.last_tabular)))
+    lib.ga_set_merged_pair(0)
+    algo.overlap_updates = True
+    for got in out[1:]:
+        assert torch.equal(got[0], out[0][0])
+        assert torch.equal(got[1], out[0][1])
+        assert torch.equal(got[2], out[0][2])
+        assert got[3] == out[0][3]
+    # a pair launch counts for both networks: the same totals on every schedule
+    assert launches[0] == launches[1] == launches[2] == (640, 640)
