@@ -159,7 +159,7 @@ KIND_NAMES = [
 GEMM_KINDS = (0, 1, 2, 3, 4, 5, 9, 10, 11, 12)  # MFMA kernels: work = flops
 
 
-TRAFFIC_FILE = 'profiles/r02_traffic.json'
+TRAFFIC_FILE = 'profiles/r03_traffic.json'
 
 
 def load_traffic():
@@ -270,6 +270,12 @@ def roofline_pass(algo, sampler, pol, S, itr):
             # the first layer is computed inside the kernel (ga_set_fused_first_layer)
             name = name.replace(',false> (last hidden layer',
                                 ',true> (first layer + last hidden layer')
+            if width == 256 and (in_w + 3) // 4 == 5 and \
+                    os.environ.get('GARAGE_AMD_PIPELINED_KLOOP', '1') != '0':
+                # the software-pipelined k-loop instantiation (17..20 inputs)
+                name = name.replace('<256,1,8,true>', '<256,1,8,true,5>')
+                name = name.replace('mlp_eval_forward_kernel<256,1,8>',
+                                    'mlp_eval_forward_kernel<256,1,8,5>')
         rows.append(dict(kernel=name, total_ms=ms, work=work,
                          launches=int(cnt)))
     return rows

@@ -7,7 +7,13 @@ OUT=${1:-gpurun_out/final}
 mkdir -p $OUT
 R=$PWD
 python bench.py > $OUT/c3.log 2> $OUT/c3.err
-python bench.py --no-overlap > $OUT/c3_serial.log 2>&1
+# run-to-run spread of the headline (five consecutive runs, one box)
+for i in 1 2 3 4 5; do python bench.py --cpu-envs 0 --no-scan-c4 --no-roofline > $OUT/c3_rep$i.log 2>&1; done
+python bench.py --no-overlap --cpu-envs 0 > $OUT/c3_serial.log 2>&1
+# the data-parallel code path priced on one GPU (1-rank RCCL group)
+python bench.py --dp --cpu-envs 0 --no-scan-c4 > $OUT/c3_dp.log 2>&1
+python bench.py --dp --no-overlap --cpu-envs 0 --no-scan-c4 > $OUT/c3_dp_serial.log 2>&1
+GARAGE_AMD_MERGED_PAIR=1 python bench.py --cpu-envs 0 --no-scan-c4 > $OUT/c3_merged.log 2>&1
 python bench.py --config c2 > $OUT/c2.log 2>&1
 python bench.py --config c5 --steps 3 --warmup 1 > $OUT/c5.log 2>&1
 python bench.py --config c1 > $OUT/c1.log 2>&1
