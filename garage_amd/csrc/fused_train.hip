@@ -190,10 +190,6 @@ __device__ __forceinline__ void fwd_head_loss_body(const FwdLossParams& p,
 
   FT_STAMP(0);
   FT_MARK(0);
-  // this lane's output columns' biases (used when the accumulators are staged)
-  float bcol[TN];
-#pragma unroll
-  for (int j = 0; j < TN; ++j) bcol[j] = p.g.bias[wn0 + 32 * j + (lane & 31)];
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -304,19 +300,20 @@ __device__ __forceinline__ void fwd_head_loss_body(const FwdLossParams& p,
       constexpr int SLOTS = (BK / 8) * 4 * TN;  // one slot = TM MFMAs
       constexpr int SPQ = FT_ROWS * (BK / 4) / NT;
       constexpr int LD0 = 4 * KSC;
+      // wave-uniform 64-bit bases + 32-bit lane offsets (one address register each)
+      const uint32_t wb_off = (uint32_t)(wn0 + l31) * (uint32_t)p.g.ldb + 4u * half;
+      float* h1_tile = p.l1_H + (int64_t)m0 * p.l1_ldh;
 #define FT_SB __builtin_amdgcn_sched_barrier(0)
       auto step = [&](int s, auto more_tag, auto full_tag) {
         constexpr bool MORE = decltype(more_tag)::value;
         constexpr bool FULL = decltype(full_tag)::value;
         const float* As = As2(s);
         float* An = As2(s + 1);
-        float4 bc[TN][4];
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) bc[j][g] = bn[j][g];
+        // (the B fragments of group g live in bn[.][g]; as soon as the group's MFMAs
+        // are issued the same registers receive the next step's group g -- a whole
+        // step of latency budget, no second register set, no copies)
         // -- the step's loads: A fragments of group 0 first (the MFMAs wait for
-        //    them), then the producer's weights, the spill's quads, the next B
+        //    them), then the producer's weights and the spill's quads
         float4 af[2][TM];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -342,9 +339,6 @@ __device__ __forceinline__ void fwd_head_loss_body(const FwdLossParams& p,
                                                      4 * (e % (BK / 4)));
           }
         }
-#ifndef GA_ABL_NOFETCH
-        if constexpr (MORE) fetch_b(s + 1);
-#endif
         FT_SB;
         ft_f32x4 e4[NSUB], o4[NSUB];
         float hv[NSUB][4];
@@ -374,8 +368,9 @@ __device__ __forceinline__ void fwd_head_loss_body(const FwdLossParams& p,
                 const int e = tid + NT * q;
                 const int row = e / (BK / 4), c4 = e % (BK / 4);
                 if (FULL || m0 + row < M)
-                  *reinterpret_cast<float4*>(p.l1_H + (int64_t)(m0 + row) * p.l1_ldh +
-                                             32 * s + 4 * c4) = sp[q];
+                  *reinterpret_cast<float4*>(
+                      h1_tile + ((uint32_t)row * (uint32_t)p.l1_ldh +
+                                 (uint32_t)(32 * s + 4 * c4))) = sp[q];
               }
             }
           } else if (t < NSUB + 1 + 4 * NSUB) {
@@ -400,7 +395,7 @@ __device__ __forceinline__ void fwd_head_loss_body(const FwdLossParams& p,
         for (int slot = 0; slot < SLOTS; ++slot) {
           const int g = slot / (4 * TN), q = (slot / TN) % 4, j = slot % TN;
           {
-            const float4 bq = bc[j][g];
+            const float4 bq = bn[j][g];
             const float bb = q == 0 ? bq.x : q == 1 ? bq.y : q == 2 ? bq.z : bq.w;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -421,6 +416,18 @@ __device__ __forceinline__ void fwd_head_loss_body(const FwdLossParams& p,
               af[(g + 1) & 1][i] = *reinterpret_cast<const float4*>(
                   As + (wm0 + 32 * i + l31) * LDK + 8 * (g + 1) + 4 * half);
           }
+#ifndef GA_ABL_NOFETCH
+          // this group's B registers are free: the next step's group g goes there
+          if constexpr (MORE) {
+            if (slot % (4 * TN) == 4 * TN - 1) {
+#pragma unroll
+              for (int jj = 0; jj < TN; ++jj)
+                bn[jj][g] = *reinterpret_cast<const float4*>(
+                    p.g.B + (wb_off + (uint32_t)(32 * jj) * (uint32_t)p.g.ldb +
+                             (uint32_t)(32 * (s + 1) + 8 * g)));
+            }
+          }
+#endif
           // side tasks from slot 1 on, one per slot
 #ifdef GA_ABL_NOPRODUCE
           if (slot - 1 == NSUB) side(slot - 1);
@@ -521,6 +528,11 @@ __device__ __forceinline__ void fwd_head_loss_body(const FwdLossParams& p,
 
   FT_STAMP(2);
   FT_MARK(1);
+  // this lane's output columns' biases (used when the accumulators are staged;
+  // fetched here rather than before the k-loop: one register less live through it)
+  float bcol[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) bcol[j] = p.g.bias[wn0 + 32 * j + (lane & 31)];
   // the sample of this lane's row (wave 0 computes the loss rows): loads issued
   // here, consumed three barriers later
   float act[8];
