@@ -15,7 +15,7 @@ python bench.py --dp --cpu-envs 0 --no-scan-c4 > $OUT/c3_dp.log 2>&1
 python bench.py --dp --no-overlap --cpu-envs 0 --no-scan-c4 > $OUT/c3_dp_serial.log 2>&1
 GARAGE_AMD_MERGED_PAIR=1 python bench.py --cpu-envs 0 --no-scan-c4 > $OUT/c3_merged.log 2>&1
 python bench.py --config c2 > $OUT/c2.log 2>&1
-python bench.py --config c5 --steps 3 --warmup 1 > $OUT/c5.log 2>&1
+python bench.py --config c5 --steps 5 --warmup 2 > $OUT/c5.log 2>&1
 python bench.py --config c1 > $OUT/c1.log 2>&1
 python bench.py --config c3mb64 --steps 3 --warmup 1 > $OUT/c3mb64.log 2>&1
 python bench.py --algo trpo > $OUT/trpo.log 2>&1
