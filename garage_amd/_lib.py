@@ -164,6 +164,8 @@ SIGNATURES = {
     'ga_reduce_adam_f32': (c_int, [ptr, c_i64, c_i64, ptr, ptr, ptr, ptr, c_i64,
                                    c_i64, c_f64, c_f64, c_f64, c_f64, c_int,
                                    ptr]),
+    'ga_optimizer_step_f32': (c_int, [c_int, ptr, ptr, ptr, ptr, ptr, c_i64,
+                                      c_i64, C.POINTER(c_f64), c_int, ptr]),
     'ga_adam_step_f32': (c_int, [ptr, ptr, ptr, ptr, c_i64, c_i64, c_f64,
                                  c_f64, c_f64, c_f64, ptr]),
     'ga_stats_f32': (c_int, [ptr, c_i64, c_int, ptr, ptr, ptr]),

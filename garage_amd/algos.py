@@ -628,6 +628,10 @@ class VPG:
             if opt.grad_hook is not None and getattr(opt, 'native_comm',
                                                      None) is None:
                 return False
+            # the native loops fuse torch's default-shaped Adam; any other
+            # torch.optim class steps from the per-minibatch loop
+            if not getattr(opt, 'default_adam', True):
+                return False
         return True
 
     def _update_args(self, opt, module, kind, batch, adv, returns, old_ll,
@@ -658,8 +662,12 @@ class VPG:
         a.ldo = net.ld_out
         a.slabs, a.max_splits = net._slabs.data_ptr(), int(net._splits)
         h = opt._hyper
-        a.lr, a.beta1, a.beta2, a.eps = (float(h['lr']), float(h['betas'][0]),
-                                         float(h['betas'][1]), float(h['eps']))
+        # (Adam's constants: unused by the gradients-only phase that every other
+        # torch.optim class takes)
+        betas = h.get('betas', (0.9, 0.999))
+        a.lr, a.beta1, a.beta2, a.eps = (float(h['lr']), float(betas[0]),
+                                         float(betas[1]),
+                                         float(h.get('eps', 1e-8)))
         a.learn_std = int(getattr(module, '_learn_std', True))
         a.X, a.ldx, a.S = (batch.obs_dev.data_ptr(), batch.obs_dev.stride(0),
                            S)
@@ -801,19 +809,22 @@ class VPG:
         a.grad_scales_host = None
         a.comm = None
         hook = opt.grad_hook
-        a.phase = 1 if hook is not None else 0
+        generic = not getattr(opt, 'default_adam', True)
+        a.phase = 1 if (hook is not None or generic) else 0
         if hook is not None:
             a.grad_scale = float(opt.dp_grad_scale
                                  if opt._cur_grad_scale is None
                                  else opt._cur_grad_scale)
+        elif generic:
+            a.grad_scale = 1.0
         loss = torch.empty(1, dtype=torch.float32, device=net.device)
         a.losses = loss.data_ptr()
         a.step0 = net.adam_steps
         call('ga_update_epoch', C.byref(a), stream_ptr())
         if hook is not None:
             hook(net.grads)
-            h = opt._hyper
-            net.adam_step(h['lr'], h['betas'], h['eps'])
+        if hook is not None or generic:
+            opt.apply_step()
         else:
             net.adam_steps += 1
         del keep
@@ -1008,6 +1019,7 @@ class TRPO(VPG):
         opt, vf = self._vf_optimizer, self._value_function
         native = (type(self)._train_value_function
                   is VPG._train_value_function
+                  and getattr(opt, 'default_adam', True)
                   and (opt.grad_hook is None
                        or getattr(opt, 'native_comm', None) is not None))
         if not native:

@@ -519,9 +519,9 @@ static int check_desc(const ga_mlp_desc* d, const char* who) {
   for (int l = 0; l < d->n_layers; ++l)
     GA_REQUIRE(d->w_off[l] % 4 == 0 && d->act_off[l] % 4 == 0,
                "%s: offsets of layer %d not 16-B aligned", who, l);
-  GA_REQUIRE(d->hidden_act >= 0 && d->hidden_act <= 2, "%s: hidden_act %d not in 0..2",
+  GA_REQUIRE(d->hidden_act >= 0 && d->hidden_act <= 6, "%s: hidden_act %d not in 0..6",
              who, d->hidden_act);
-  GA_REQUIRE(d->output_act >= 0 && d->output_act <= 2, "%s: output_act %d not in 0..2",
+  GA_REQUIRE(d->output_act >= 0 && d->output_act <= 6, "%s: output_act %d not in 0..6",
              who, d->output_act);
   if (d->layer_norm)
     for (int l = 0; l + 1 < d->n_layers; ++l)
@@ -967,8 +967,7 @@ __global__ __launch_bounds__(256) void act_slope_mul_kernel(float* dout, int64_t
   const int64_t i = e / N;
   const int j = (int)(e % N);
   const float o = out[i * ldo + j];
-  // (forward codes: 1 tanh, 2 relu)
-  dout[i * ldd + j] *= act == 1 ? 1.f - o * o : (act == 2 ? (o > 0.f ? 1.f : 0.f) : 1.f);
+  dout[i * ldd + j] *= act_slope_fwd(o, act);  // (forward codes, gemm_core.h)
 }
 }  // namespace
 
@@ -976,7 +975,7 @@ extern "C" int ga_act_slope_mul_f32(float* dout, int64_t ldd, const float* out,
                                     int64_t ldo, int64_t M, int N, int act,
                                     hipStream_t stream) {
   GA_REQUIRE(dout && out && M >= 0 && N >= 1 && ldd >= N && ldo >= N && act >= 0 &&
-                 act <= 2,
+                 act <= 6,
              "ga_act_slope_mul_f32: bad arguments");
   if (M == 0 || act == 0) return GA_OK;
   hipLaunchKernelGGL(act_slope_mul_kernel, dim3((unsigned)ga_ceil_div(M * N, 256)),

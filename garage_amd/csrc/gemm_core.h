@@ -24,17 +24,43 @@ __device__ __forceinline__ float tanh_fast(float x) {
   return ga_tanh(x);  // common.h
 }
 
-// Hidden activations.  Forward code (GemmParams::act): 0 none, 1 tanh, 2 relu.
+// Activations (the reference accepts any callable as hidden / output
+// nonlinearity, torch/modules/multi_headed_mlp_module.py:154-197; these are the ones
+// whose slope is a function of the OUTPUT, so that the backward pass needs no
+// pre-activation in memory).
+// Forward code (GemmParams::act, ga_mlp_desc::output_act): 0 none, 1 tanh, 2 relu,
+//   3 sigmoid, 4 elu (alpha 1), 5 leaky_relu (slope 0.01), 6 softplus (beta 1,
+//   threshold 20) -- torch.nn.functional's defaults.
 // Network code (ga_mlp_desc::hidden_act, GemmParams::hact): 0 tanh (what a zeroed
-// descriptor means), 1 relu, 2 none -- the slope is taken from the OUTPUT h.
+//   descriptor means), 1 relu, 2 none, 3 .. 6 as above.
 __device__ __forceinline__ float act_apply(float v, int act) {
-  return act == 1 ? tanh_fast(v) : (act == 2 ? fmaxf(v, 0.f) : v);
+  switch (act) {
+    case 1: return tanh_fast(v);
+    case 2: return fmaxf(v, 0.f);
+    case 3: return 1.f / (1.f + expf(-v));
+    case 4: return v > 0.f ? v : expm1f(v);
+    case 5: return v > 0.f ? v : 0.01f * v;
+    case 6: return v > 20.f ? v : log1pf(expf(v));
+    default: return v;
+  }
 }
 __device__ __forceinline__ float act_slope(float h, int hact) {
-  return hact == 0 ? 1.f - h * h : (hact == 1 ? (h > 0.f ? 1.f : 0.f) : 1.f);
+  switch (hact) {
+    case 0: return 1.f - h * h;
+    case 1: return h > 0.f ? 1.f : 0.f;
+    case 3: return h * (1.f - h);
+    case 4: return h > 0.f ? 1.f : h + 1.f;       // exp(x) = h + 1 for x <= 0
+    case 5: return h > 0.f ? 1.f : 0.01f;
+    case 6: return 1.f - expf(-h);                 // sigmoid(x) with h = log(1 + e^x)
+    default: return 1.f;
+  }
 }
-inline int act_forward_code(int hidden_act) {
-  return hidden_act == 0 ? 1 : (hidden_act == 1 ? 2 : 0);
+__host__ __device__ inline int act_forward_code(int hidden_act) {
+  return hidden_act == 0 ? 1 : (hidden_act == 1 ? 2 : (hidden_act == 2 ? 0 : hidden_act));
+}
+// slope of an OUTPUT activation given in forward code
+__device__ __forceinline__ float act_slope_fwd(float o, int act) {
+  return act_slope(o, act == 0 ? 2 : (act == 1 ? 0 : (act == 2 ? 1 : act)));
 }
 
 struct GemmParams {

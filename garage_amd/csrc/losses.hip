@@ -616,6 +616,98 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamParams a) {
   a.v[i] = v;
 }
 
+// ---------------------------------------------------------------------------
+// Optimizers other than the default Adam (make_optimizer, _functions.py:25-65,
+// builds any torch.optim class): elementwise steps over the flat parameter buffer
+// with torch's single-tensor arithmetic, one rounding per torch operation.
+//   kind 1  torch.optim.SGD      h = {lr, momentum, dampening, weight_decay};
+//                                flag bit 0 nesterov; s1 = momentum buffer
+//   kind 2  torch.optim.RMSprop  h = {lr, alpha, eps, weight_decay, momentum};
+//                                flag bit 0 centered; s1 = square_avg, s2 = momentum
+//                                buffer, s3 = grad_avg
+//   kind 3  torch.optim.Adam / AdamW beyond the defaults
+//                                h = {lr, beta1, beta2, eps, weight_decay};
+//                                flag bit 0 amsgrad, bit 1 decoupled decay (AdamW);
+//                                s1 = exp_avg, s2 = exp_avg_sq, s3 = max_exp_avg_sq
+struct OptParams {
+  float* p;
+  const float* g;
+  float* s1;
+  float* s2;
+  float* s3;
+  int64_t n;
+  int kind, flags, first;  // first: step == 1 (SGD initialises its buffer with g)
+  float lr, h1, h2, h3, h4;
+  float neg_step_size, bc2_sqrt;  // kind 3
+};
+
+__global__ __launch_bounds__(256) void optimizer_step_kernel(OptParams a) {
+#pragma clang fp contract(off)
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n) return;
+  float p = a.p[i], g = a.g[i];
+  if (a.kind == 1) {
+    const float momentum = a.h1, dampening = a.h2, wd = a.h3;
+    if (wd != 0.f) g = g + wd * p;                      // grad.add(param, alpha=wd)
+    if (momentum != 0.f) {
+      float buf;
+      if (a.first) {
+        buf = g;                                        // torch.clone(grad)
+      } else {
+        buf = a.s1[i] * momentum;                       // buf.mul_(momentum)
+        buf = buf + (1.f - dampening) * g;              //    .add_(grad, alpha=1-damp)
+      }
+      a.s1[i] = buf;
+      g = (a.flags & 1) ? g + momentum * buf : buf;     // nesterov
+    }
+    p = p + (-a.lr) * g;                                // param.add_(grad, alpha=-lr)
+  } else if (a.kind == 2) {
+    const float alpha = a.h1, eps = a.h2, wd = a.h3, momentum = a.h4;
+    if (wd != 0.f) g = g + wd * p;
+    float sq = a.s1[i] * alpha;                         // square_avg.mul_(alpha)
+    sq = sq + ((1.f - alpha) * g) * g;                  //    .addcmul_(g, g, 1-alpha)
+    a.s1[i] = sq;
+    float avg;
+    if (a.flags & 1) {
+      float ga = a.s3[i];
+      ga = fmaf(1.f - alpha, g - ga, ga);               // grad_avg.lerp_(g, 1-alpha)
+      a.s3[i] = ga;
+      avg = sqrtf(sq + (-1.f * ga) * ga);               // addcmul(ga, ga, -1).sqrt_()
+    } else {
+      avg = sqrtf(sq);
+    }
+    avg = avg + eps;
+    if (momentum > 0.f) {
+      float buf = a.s2[i] * momentum;                   // buf.mul_(momentum)
+      buf = buf + g / avg;                              //    .addcdiv_(grad, avg)
+      a.s2[i] = buf;
+      p = p + (-a.lr) * buf;
+    } else {
+      p = p + (-a.lr) * (g / avg);                      // addcdiv_(grad, avg, -lr)
+    }
+  } else {
+    const float beta1 = a.h1, beta2 = a.h2, eps = a.h3, wd = a.h4;
+    if (a.flags & 2) {
+      p = p * (1.f - a.lr * wd);                        // AdamW: param.mul_(1 - lr wd)
+    } else if (wd != 0.f) {
+      g = g + wd * p;
+    }
+    float m = a.s1[i], v = a.s2[i];
+    m = fmaf(1.f - beta1, g - m, m);                    // exp_avg.lerp_(grad, 1-beta1)
+    v = v * beta2 + ((1.f - beta2) * g) * g;
+    a.s1[i] = m;
+    a.s2[i] = v;
+    float vv = v;
+    if (a.flags & 1) {                                  // amsgrad
+      vv = fmaxf(a.s3[i], v);
+      a.s3[i] = vv;
+    }
+    const float denom = sqrtf(vv) / a.bc2_sqrt + eps;
+    p = p + (a.neg_step_size * m) / denom;
+  }
+  a.p[i] = p;
+}
+
 // reduce_slabs_kernel + adam_kernel in one launch (single process: nothing has
 // to happen between the slab sum and the optimizer step).  Same arithmetic and
 // the same summation order as the two separate kernels.
@@ -969,6 +1061,38 @@ extern "C" int ga_adam_step_f32(float* params, const float* grads, float* exp_av
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)ga_ceil_div(n, 256)), dim3(256), 0,
                      stream, a);
   GA_CHECK_LAUNCH("adam");
+  return GA_OK;
+}
+
+extern "C" int ga_optimizer_step_f32(int kind, float* params, const float* grads,
+                                     float* s1, float* s2, float* s3, int64_t n,
+                                     int64_t step, const double* h, int flags,
+                                     hipStream_t stream) {
+  GA_REQUIRE(params && grads && h, "ga_optimizer_step_f32: null pointer");
+  GA_REQUIRE(n > 0 && step >= 1 && kind >= 1 && kind <= 3,
+             "ga_optimizer_step_f32: bad n / step / kind");
+  OptParams a;
+  memset(&a, 0, sizeof(a));
+  a.p = params; a.g = grads; a.s1 = s1; a.s2 = s2; a.s3 = s3; a.n = n;
+  a.kind = kind; a.flags = flags; a.first = step == 1;
+  a.lr = (float)h[0]; a.h1 = (float)h[1]; a.h2 = (float)h[2]; a.h3 = (float)h[3];
+  a.h4 = (float)h[4];
+  if (kind == 1) {
+    GA_REQUIRE(h[1] == 0.0 || s1, "ga_optimizer_step_f32: SGD momentum buffer");
+  } else if (kind == 2) {
+    GA_REQUIRE(s1 && (h[4] <= 0.0 || s2) && (!(flags & 1) || s3),
+               "ga_optimizer_step_f32: RMSprop state buffers");
+  } else {
+    GA_REQUIRE(s1 && s2 && (!(flags & 1) || s3),
+               "ga_optimizer_step_f32: Adam state buffers");
+    const double bc1 = 1.0 - pow(h[1], (double)step);
+    const double bc2 = 1.0 - pow(h[2], (double)step);
+    a.neg_step_size = (float)(-(h[0] / bc1));
+    a.bc2_sqrt = (float)sqrt(bc2);
+  }
+  hipLaunchKernelGGL(optimizer_step_kernel, dim3((unsigned)ga_ceil_div(n, 256)),
+                     dim3(256), 0, stream, a);
+  GA_CHECK_LAUNCH("optimizer_step");
   return GA_OK;
 }
 

@@ -50,9 +50,11 @@ class FlatMLP:
     """
 
     # ga_mlp_desc.hidden_act
-    HIDDEN_ACTS = {'tanh': 0, 'relu': 1, 'none': 2}
+    HIDDEN_ACTS = {'tanh': 0, 'relu': 1, 'none': 2, 'sigmoid': 3, 'elu': 4,
+                   'leaky_relu': 5, 'softplus': 6}
     # ga_mlp_desc.output_act
-    OUTPUT_ACTS = {'none': 0, 'tanh': 1, 'relu': 2}
+    OUTPUT_ACTS = {'none': 0, 'tanh': 1, 'relu': 2, 'sigmoid': 3, 'elu': 4,
+                   'leaky_relu': 5, 'softplus': 6}
 
     def __init__(self, in_dim, out_dim, hidden_sizes, device, hidden_act='tanh',
                  output_act='none', layer_norm=False):
@@ -297,6 +299,24 @@ class FlatMLP:
         call('ga_reduce_slabs_f32', dptr(self._slabs), self._used_splits,
              self.n_flat, self.n_flat, float(scale), dptr(self.grads),
              stream_ptr())
+
+    def optimizer_step(self, hyper):
+        """One step of a torch.optim class other than the default Adam
+        (``optimizers._torch_optimizer_hyper``: SGD, RMSprop, Adam / AdamW with
+        weight decay or amsgrad) on ``self.grads``.  ``exp_avg`` / ``exp_avg_sq``
+        double as the first two state buffers (momentum buffer / square_avg, ...),
+        a third one (max_exp_avg_sq, grad_avg) is allocated on first use."""
+        import ctypes
+        self.adam_steps += 1
+        n1, n2, n3 = hyper['needs']
+        if n3 and getattr(self, 'opt_state3', None) is None:
+            self.opt_state3 = torch.zeros_like(self.params)
+        h = (ctypes.c_double * 5)(*[float(v) for v in hyper['h']])
+        call('ga_optimizer_step_f32', int(hyper['code']), dptr(self.params),
+             dptr(self.grads), dptr(self.exp_avg) if n1 else None,
+             dptr(self.exp_avg_sq) if n2 else None,
+             dptr(self.opt_state3) if n3 else None, self.n_flat,
+             self.adam_steps, h, int(hyper['flags']), stream_ptr())
 
     def adam_step(self, lr, betas=(0.9, 0.999), eps=1e-8):
         self.adam_steps += 1

@@ -48,14 +48,76 @@ def _parse_optimizer(optimizer):
         hyper = ConjugateGradientOptimizer(**kwargs).state
         hyper['kind'] = 'cg'
         return hyper
-    if name != 'Adam':
-        raise NotImplementedError(
-            'garage_amd fuses torch.optim.Adam; got {}'.format(name))
-    if kwargs.get('weight_decay', 0) or kwargs.get('amsgrad', False):
-        raise NotImplementedError('weight_decay / amsgrad are not supported')
-    return dict(kind='adam', lr=kwargs.get('lr', 1e-3),
-                betas=kwargs.get('betas', (0.9, 0.999)),
-                eps=kwargs.get('eps', 1e-8))
+    return _torch_optimizer_hyper(name, kwargs)
+
+
+def _torch_optimizer_hyper(name, kwargs):
+    """Settings of a ``torch.optim`` class as the kernels take them.  ``kind``
+    ``'adam'`` is torch's default-shaped Adam (no weight decay, no amsgrad): the
+    one fused into the native update loops.  Everything else is ``'generic'`` --
+    one elementwise launch per step (``ga_optimizer_step_f32``) behind the
+    per-minibatch Python loop -- with ``code`` / ``h`` / ``flags`` as the header
+    documents them.  Same keyword names and defaults as torch."""
+    kw = dict(kwargs)
+
+    def take(key, default):
+        return kw.pop(key, default)
+
+    if name in ('Adam', 'AdamW'):
+        lr = take('lr', 1e-3)
+        betas = tuple(take('betas', (0.9, 0.999)))
+        eps = take('eps', 1e-8)
+        wd = take('weight_decay', 1e-2 if name == 'AdamW' else 0)
+        amsgrad = bool(take('amsgrad', False))
+        for k in ('foreach', 'capturable', 'differentiable', 'fused'):
+            kw.pop(k, None)
+        if take('maximize', False) or kw:
+            raise NotImplementedError(
+                'torch.optim.{} option(s) {} are not supported'.format(
+                    name, sorted(kw) or ['maximize']))
+        if name == 'Adam' and not wd and not amsgrad:
+            return dict(kind='adam', lr=lr, betas=betas, eps=eps)
+        return dict(kind='generic', name=name, code=3, lr=lr, betas=betas,
+                    eps=eps, h=[lr, betas[0], betas[1], eps, wd],
+                    flags=int(amsgrad) | (2 if name == 'AdamW' else 0),
+                    needs=(True, True, amsgrad))
+    if name == 'SGD':
+        lr = take('lr', 1e-3)
+        momentum = take('momentum', 0)
+        dampening = take('dampening', 0)
+        wd = take('weight_decay', 0)
+        nesterov = bool(take('nesterov', False))
+        for k in ('foreach', 'differentiable', 'fused'):
+            kw.pop(k, None)
+        if take('maximize', False) or kw:
+            raise NotImplementedError(
+                'torch.optim.SGD option(s) {} are not supported'.format(
+                    sorted(kw) or ['maximize']))
+        if nesterov and (momentum <= 0 or dampening != 0):
+            raise ValueError('Nesterov momentum requires a momentum and zero '
+                             'dampening')  # torch/optim/sgd.py
+        return dict(kind='generic', name=name, code=1, lr=lr,
+                    h=[lr, momentum, dampening, wd, 0.0], flags=int(nesterov),
+                    needs=(momentum != 0, False, False))
+    if name == 'RMSprop':
+        lr = take('lr', 1e-2)
+        alpha = take('alpha', 0.99)
+        eps = take('eps', 1e-8)
+        wd = take('weight_decay', 0)
+        momentum = take('momentum', 0)
+        centered = bool(take('centered', False))
+        for k in ('foreach', 'capturable', 'differentiable'):
+            kw.pop(k, None)
+        if take('maximize', False) or kw:
+            raise NotImplementedError(
+                'torch.optim.RMSprop option(s) {} are not supported'.format(
+                    sorted(kw) or ['maximize']))
+        return dict(kind='generic', name=name, code=2, lr=lr,
+                    h=[lr, alpha, eps, wd, momentum], flags=int(centered),
+                    needs=(True, momentum > 0, centered))
+    raise NotImplementedError(
+        'garage_amd implements torch.optim.Adam / AdamW / SGD / RMSprop (and '
+        'garage\'s ConjugateGradientOptimizer); got {}'.format(name))
 
 
 def data_parallel_plan(counts, minibatch_size, rank):
@@ -211,10 +273,25 @@ class OptimizerWrapper:
     def zero_grad(self):
         self.net.grads.zero_()
 
+    @property
+    def default_adam(self):
+        """torch's default-shaped Adam: the optimizer fused into the native update
+        loops; anything else steps through ``FlatMLP.optimizer_step`` from the
+        per-minibatch Python loop."""
+        return self._hyper['kind'] == 'adam'
+
+    def apply_step(self):
+        """One optimizer step on ``net.grads`` (already reduced / exchanged)."""
+        h = self._hyper
+        if h['kind'] == 'adam':
+            self.net.adam_step(h['lr'], h['betas'], h['eps'])
+        else:
+            self.net.optimizer_step(h)
+
     def step(self, **closure):
-        """Reduce the gradient slabs, (all-reduce,) Adam."""
+        """Reduce the gradient slabs, (all-reduce,) optimizer step."""
         del closure
-        if self._hyper['kind'] != 'adam':
+        if self._hyper['kind'] == 'cg':
             raise NotImplementedError(
                 'the conjugate-gradient step is driven by garage_amd.algos.TRPO')
         scale = 1.0
@@ -226,5 +303,4 @@ class OptimizerWrapper:
             self.net.grads[0:1].zero_()
         if self.grad_hook is not None:
             self.grad_hook(self.net.grads)
-        self.net.adam_step(self._hyper['lr'], self._hyper['betas'],
-                           self._hyper['eps'])
+        self.apply_step()

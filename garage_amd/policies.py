@@ -38,9 +38,27 @@ def _hidden_act(hidden_nonlinearity):
         return 'tanh'
     if h in (torch.relu, 'relu', nn.ReLU, F.relu) or isinstance(h, nn.ReLU):
         return 'relu'
+    if h in (torch.sigmoid, 'sigmoid', nn.Sigmoid, F.sigmoid) or \
+            isinstance(h, nn.Sigmoid):
+        return 'sigmoid'
+    # parameterised activations: the kernels implement torch's DEFAULT settings
+    # (elu alpha = 1, leaky_relu negative_slope = 0.01, softplus beta = 1 /
+    # threshold = 20); the functional forms and the module CLASSES mean those
+    if h in (F.elu, 'elu', nn.ELU) or (isinstance(h, nn.ELU)
+                                      and h.alpha == 1.0):
+        return 'elu'
+    if h in (F.leaky_relu, 'leaky_relu', nn.LeakyReLU) or (
+            isinstance(h, nn.LeakyReLU) and h.negative_slope == 0.01):
+        return 'leaky_relu'
+    if h in (F.softplus, 'softplus', nn.Softplus) or (
+            isinstance(h, nn.Softplus) and h.beta in (1, 1.0)
+            and h.threshold in (20, 20.0)):
+        return 'softplus'
     raise NotImplementedError(
-        'garage_amd kernels implement tanh (the GaussianMLP* default), relu and '
-        'linear hidden layers; got {!r}'.format(hidden_nonlinearity))
+        'garage_amd kernels implement tanh (the GaussianMLP* default), relu, '
+        'sigmoid, elu, leaky_relu, softplus (torch defaults) and linear layers '
+        '-- activations whose slope is a function of their output; got '
+        '{!r}'.format(hidden_nonlinearity))
 
 
 def _check_supported(hidden_nonlinearity, output_nonlinearity,
@@ -219,6 +237,8 @@ class _GaussianMLP:
                           layer_norm=self.net.layer_norm)
             for k in ('params', 'grads', 'exp_avg', 'exp_avg_sq'):
                 getattr(net, k).copy_(getattr(self.net, k))
+            if getattr(self.net, 'opt_state3', None) is not None:
+                net.opt_state3 = self.net.opt_state3.to(device)
             net.adam_steps = self.net.adam_steps
             self.net, self.device = net, device
         return self
@@ -309,6 +329,9 @@ class _GaussianMLP:
         for k in ('params', 'exp_avg', 'exp_avg_sq'):
             state['_net_' + k] = getattr(self.net, k).cpu().numpy()
         state['_net_steps'] = self.net.adam_steps
+        if getattr(self.net, 'opt_state3', None) is not None:
+            # third state buffer of a non-default optimizer (amsgrad / centred)
+            state['_net_opt_state3'] = self.net.opt_state3.cpu().numpy()
         return state
 
     def __setstate__(self, state):
@@ -320,12 +343,15 @@ class _GaussianMLP:
         bufs = {k: state.pop('_net_' + k)
                 for k in ('params', 'exp_avg', 'exp_avg_sq')}
         steps = state.pop('_net_steps')
+        state3 = state.pop('_net_opt_state3', None)
         self.__dict__.update(state)
         self.device = require_gpu()
         self.net = FlatMLP(in_dim, out_dim, hidden, self.device, hidden_act=act,
                            output_act=out_act, layer_norm=layer_norm)
         for k, v in bufs.items():
             getattr(self.net, k).copy_(torch.from_numpy(v))
+        if state3 is not None:
+            self.net.opt_state3 = torch.from_numpy(state3).to(self.device)
         self.net.adam_steps = steps
 
 

@@ -309,6 +309,21 @@ int ga_reduce_adam_f32(const float* slabs, int64_t n_splits, int64_t slab_stride
 int ga_adam_step_f32(float* params, const float* grads, float* exp_avg,
                      float* exp_avg_sq, int64_t n, int64_t step, double lr,
                      double beta1, double beta2, double eps, ga_stream_t stream);
+/* make_optimizer (_functions.py:25-65) builds ANY torch.optim class; beyond the default
+ * Adam (fused into the update kernels) these run as one elementwise launch over the
+ * flat buffer, torch's single-tensor arithmetic:
+ *   kind 1 torch.optim.SGD      h = {lr, momentum, dampening, weight_decay, -};
+ *                               flags bit 0 nesterov; s1 = momentum buffer
+ *   kind 2 torch.optim.RMSprop  h = {lr, alpha, eps, weight_decay, momentum}; flags bit 0
+ *                               centered; s1 square_avg, s2 momentum buffer, s3 grad_avg
+ *   kind 3 torch.optim.Adam / AdamW with weight_decay / amsgrad
+ *                               h = {lr, beta1, beta2, eps, weight_decay}; flags bit 0
+ *                               amsgrad, bit 1 decoupled decay (AdamW); s1 exp_avg,
+ *                               s2 exp_avg_sq, s3 max_exp_avg_sq
+ * h: HOST pointer to 5 doubles; step counts from 1; unused state pointers may be NULL. */
+int ga_optimizer_step_f32(int kind, float* params, const float* grads, float* s1,
+                          float* s2, float* s3, int64_t n, int64_t step, const double* h,
+                          int flags, ga_stream_t stream);
 
 /* ---- advantage centring: VPG._compute_advantage (vpg.py:371-377)
  * stats = device double[4]: sum, count, sum of squared deviations, min.

@@ -47,7 +47,9 @@ class OraclePPO:
                  policy_lr=2.5e-4,
                  vf_lr=2.5e-4,
                  max_optimization_epochs=10,
-                 minibatch_size=64):
+                 minibatch_size=64,
+                 policy_optimizer=None,
+                 vf_optimizer=None):
         self.policy = OrderedDict(
             (k, v.clone().detach()) for k, v in policy_params.items())
         self.value = OrderedDict(
@@ -86,12 +88,21 @@ class OraclePPO:
         self.reg_entropy = entropy_method == 'regularized'
         self.epochs = max_optimization_epochs
         self.mb = minibatch_size
-        self.policy_opt = torch.optim.Adam(
-            [self.policy[k] for k in nets.trainable_keys(self.policy)],
-            lr=policy_lr)
-        self.vf_opt = torch.optim.Adam(
-            [self.value[k] for k in nets.trainable_keys(self.value)],
-            lr=vf_lr)
+        # make_optimizer (_functions.py:25-65): a torch.optim type or (type, kwargs);
+        # the default is what ppo.py:65-76 builds
+        def build(spec, params, lr):
+            if spec is None:
+                return torch.optim.Adam(params, lr=lr)
+            if isinstance(spec, tuple):
+                return spec[0](params, **spec[1])
+            return spec(params)
+
+        self.policy_opt = build(
+            policy_optimizer,
+            [self.policy[k] for k in nets.trainable_keys(self.policy)], policy_lr)
+        self.vf_opt = build(
+            vf_optimizer,
+            [self.value[k] for k in nets.trainable_keys(self.value)], vf_lr)
 
     @staticmethod
     def _snapshot(params):

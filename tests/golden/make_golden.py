@@ -647,6 +647,34 @@ def gen_policy_options():
         dict(tag='softplus_max_clamp', pol=dict(std_parameterization='softplus',
                                                 max_std=0.8, init_std=1.0)),
     ]
+    _policy_option_cases(cases, 'policy_options')
+
+
+def gen_policy_activations():
+    """Round 3: more ``hidden_nonlinearity`` / ``output_nonlinearity`` callables of
+    the reference's MLP modules (``NonLinearity``,
+    ``multi_headed_mlp_module.py:154-197``: any callable or ``nn.Module``) -- the
+    ones whose slope is a function of their output -- through two real PPO
+    iterations each, like ``gen_policy_options``."""
+    F = torch.nn.functional
+    cases = [
+        dict(tag='sigmoid', pol=dict(hidden_nonlinearity=torch.sigmoid),
+             vf=dict(hidden_nonlinearity=torch.sigmoid)),
+        dict(tag='elu', pol=dict(hidden_nonlinearity=F.elu),
+             vf=dict(hidden_nonlinearity=torch.nn.ELU)),
+        dict(tag='leaky_relu', pol=dict(hidden_nonlinearity=torch.nn.LeakyReLU),
+             vf=dict(hidden_nonlinearity=F.leaky_relu)),
+        dict(tag='softplus_hidden', pol=dict(hidden_nonlinearity=F.softplus),
+             vf=dict(hidden_nonlinearity=torch.nn.Softplus)),
+        dict(tag='out_sigmoid_elu_hidden',
+             pol=dict(output_nonlinearity=torch.sigmoid,
+                      hidden_nonlinearity=F.elu),
+             vf=dict(output_nonlinearity=F.softplus)),
+    ]
+    _policy_option_cases(cases, 'policy_activations')
+
+
+def _policy_option_cases(cases, name):
     out = {}
     for case in cases:
         tag = case['tag']
@@ -701,7 +729,76 @@ def gen_policy_options():
             out.update(state_arrays(pre + 'pol:', pol))
             out.update(state_arrays(pre + 'vf:', vf))
         out[tag + '_cfg'] = np.asarray([O, A, P, E, mb])
-    save('policy_options', **out)
+    save(name, **out)
+
+
+OPTIMIZER_CASES = [
+    # tag, torch.optim class name, kwargs (make_optimizer, _functions.py:25-65)
+    ('sgd_plain', 'SGD', dict(lr=5e-2)),
+    ('sgd_nesterov_wd', 'SGD', dict(lr=2e-2, momentum=0.9, nesterov=True,
+                                    weight_decay=1e-3)),
+    ('sgd_momentum_dampening', 'SGD', dict(lr=2e-2, momentum=0.8,
+                                           dampening=0.1)),
+    ('rmsprop', 'RMSprop', dict(lr=1e-3)),
+    ('rmsprop_centered_momentum', 'RMSprop', dict(lr=1e-3, alpha=0.9,
+                                                  momentum=0.5, centered=True,
+                                                  weight_decay=1e-3)),
+    ('adam_amsgrad_wd', 'Adam', dict(lr=2.5e-3, amsgrad=True,
+                                     weight_decay=1e-2)),
+    ('adamw', 'AdamW', dict(lr=2.5e-3, weight_decay=5e-2)),
+]
+
+
+def gen_train_once_optimizers():
+    """Round 3: ``OptimizerWrapper`` with torch.optim classes other than the
+    default Adam (``make_optimizer``, ``_functions.py:25-65``) through two real PPO
+    iterations each: logged scalars and post-update parameters."""
+    out = {}
+    for tag, cls_name, kw in OPTIMIZER_CASES:
+        O, A, P, hs = 4, 2, 8, (8, 8)
+        E, mb = 2, 5
+        spec = EnvSpec(akro.Box(-np.inf, np.inf, (O, )),
+                       akro.Box(-np.inf, np.inf, (A, )),
+                       max_episode_length=P)
+        torch.manual_seed(23)
+        rng = np.random.RandomState(23)
+        pol = GaussianMLPPolicy(spec, hidden_sizes=hs)
+        vf = GaussianMLPValueFunction(spec, hidden_sizes=hs)
+        with torch.no_grad():
+            for p in list(pol.parameters()) + list(vf.parameters()):
+                p.add_(torch.randn_like(p) * 0.1)
+        out.update(state_arrays(tag + '_pol0:', pol))
+        out.update(state_arrays(tag + '_vf0:', vf))
+        cls = getattr(torch.optim, cls_name)
+        algo = PPO(env_spec=spec, policy=pol, value_function=vf, sampler=None,
+                   policy_optimizer=OptimizerWrapper(
+                       (cls, dict(kw)), pol, max_optimization_epochs=E,
+                       minibatch_size=mb),
+                   vf_optimizer=OptimizerWrapper(
+                       (cls, dict(kw)), vf, max_optimization_epochs=E,
+                       minibatch_size=mb))
+        rec = ref.TabularRecorder()
+        vpg_mod.tabular = rec
+        gfun.tabular = rec
+        for it in range(2):
+            lens = [8, 3, 5, 8, 1, 6] if it == 0 else [2, 8, 7, 4]
+            eps = make_ragged_batch(rng, spec, lens, O, A)
+            np.random.seed(400 + it)
+            algo._train_once(it, eps)
+            pre = '%s_it%d_' % (tag, it)
+            out[pre + 'observations'] = eps.observations
+            out[pre + 'actions'] = eps.actions
+            out[pre + 'rewards'] = eps.rewards
+            out[pre + 'lengths'] = eps.lengths
+            out[pre + 'step_types'] = np.asarray(
+                [int(s) for s in eps.step_types])
+            out[pre + 'np_seed'] = np.asarray(400 + it)
+            for k, v in rec.values.items():
+                out[pre + 'log:' + k] = np.asarray(v)
+            out.update(state_arrays(pre + 'pol:', pol))
+            out.update(state_arrays(pre + 'vf:', vf))
+        out[tag + '_cfg'] = np.asarray([O, A, P, E, mb])
+    save('train_once_optimizers', **out)
 
 
 def gen_compute_advantage():
@@ -1055,6 +1152,8 @@ if __name__ == '__main__':
         sys.exit(0)
     gen_trpo()
     gen_policy_options()
+    gen_policy_activations()
+    gen_train_once_optimizers()
     gen_returns()
     gen_advantages()
     gen_padding_and_steptypes()

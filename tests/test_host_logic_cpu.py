@@ -173,15 +173,45 @@ def test_entropy_configuration_errors():
 
 
 def test_optimizer_wrapper_arguments():
-    """_functions.py:25-65 make_optimizer forms; only Adam is fused."""
+    """_functions.py:25-65 make_optimizer forms; the default-shaped Adam is the
+    fused one (other torch.optim classes: the test below)."""
     import torch
 
     from garage_amd.optimizers import _parse_optimizer
     assert _parse_optimizer(torch.optim.Adam)['lr'] == 1e-3
     h = _parse_optimizer((torch.optim.Adam, dict(lr=2.5e-4, eps=1e-5)))
-    assert h['lr'] == 2.5e-4 and h['eps'] == 1e-5
+    assert h['lr'] == 2.5e-4 and h['eps'] == 1e-5 and h['kind'] == 'adam'
     with pytest.raises(NotImplementedError):
-        _parse_optimizer(torch.optim.SGD)
+        _parse_optimizer(torch.optim.LBFGS)
+
+
+def test_optimizer_parsing_matches_torch_defaults():
+    """``make_optimizer`` accepts a type or ``(type, kwargs)`` (``_functions.py:
+    25-65``): the settings handed to the kernels carry torch's own defaults, the
+    default-shaped Adam is the fused one, unknown classes / options are refused."""
+    import torch
+
+    from garage_amd.optimizers import _parse_optimizer
+    h = _parse_optimizer(torch.optim.Adam)
+    assert h == dict(kind='adam', lr=1e-3, betas=(0.9, 0.999), eps=1e-8)
+    h = _parse_optimizer((torch.optim.Adam, dict(lr=3e-4, amsgrad=True)))
+    assert h['kind'] == 'generic' and h['code'] == 3 and h['flags'] == 1
+    assert h['h'] == [3e-4, 0.9, 0.999, 1e-8, 0] and h['needs'] == (True, True, True)
+    h = _parse_optimizer(torch.optim.AdamW)
+    assert h['flags'] == 2 and h['h'][4] == 1e-2  # torch's AdamW default decay
+    h = _parse_optimizer((torch.optim.SGD, dict(lr=0.1, momentum=0.9)))
+    assert h['code'] == 1 and h['h'] == [0.1, 0.9, 0, 0, 0.0]
+    assert h['needs'] == (True, False, False)
+    h = _parse_optimizer(torch.optim.RMSprop)
+    assert h['code'] == 2 and h['h'] == [1e-2, 0.99, 1e-8, 0, 0]
+    with pytest.raises(ValueError, match='Nesterov'):
+        _parse_optimizer((torch.optim.SGD, dict(nesterov=True)))
+    with pytest.raises(NotImplementedError):
+        _parse_optimizer(torch.optim.Adagrad)
+    with pytest.raises(NotImplementedError):
+        _parse_optimizer((torch.optim.SGD, dict(maximize=True)))
+    with pytest.raises(NotImplementedError):
+        _parse_optimizer((torch.optim.Adam, dict(bogus=1)))
 
 
 def test_numpy_minibatch_stream_equals_batchdataset_semantics():

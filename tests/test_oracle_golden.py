@@ -782,6 +782,114 @@ def test_golden_output_nonlinearity(golden, tag):
                 assert np.allclose(v, g[pre + 'vf:' + k], atol=1e-6), k
 
 
+# round 3: more callables of the reference's NonLinearity wrapper
+# (tests/golden/policy_activations.npz): tag -> (policy hidden, policy output,
+# value hidden, value output)
+MORE_ACTIVATION_CASES = {
+    'sigmoid': (torch.sigmoid, None, torch.sigmoid, None),
+    'elu': (torch.nn.functional.elu, None, torch.nn.functional.elu, None),
+    'leaky_relu': (torch.nn.functional.leaky_relu, None,
+                   torch.nn.functional.leaky_relu, None),
+    'softplus_hidden': (torch.nn.functional.softplus, None,
+                        torch.nn.functional.softplus, None),
+    'out_sigmoid_elu_hidden': (torch.nn.functional.elu, torch.sigmoid,
+                               torch.tanh, torch.nn.functional.softplus),
+}
+
+
+@pytest.mark.parametrize('tag', sorted(MORE_ACTIVATION_CASES))
+def test_golden_more_activations(golden, tag):
+    """sigmoid / elu / leaky_relu / softplus as ``hidden_nonlinearity`` or
+    ``output_nonlinearity`` (``multi_headed_mlp_module.py:154-197``): forward
+    outputs of freshly built real networks and two real PPO iterations."""
+    from oracle import networks as nets
+    g = golden('policy_activations')
+    O, A, P, E, mb = [int(v) for v in g[tag + '_cfg']]
+    ph, po, vh, vo = MORE_ACTIVATION_CASES[tag]
+    with nets.hidden_nonlinearity(policy=ph, value=vh), \
+            nets.output_nonlinearity(policy=po, value=vo):
+        pol0, vf0 = _params(g, tag + '_pol0:'), _params(g, tag + '_vf0:')
+        x = torch.from_numpy(g[tag + '_fwd_obs'])
+        with torch.no_grad():
+            assert np.allclose(nets.policy_forward(pol0, x)[0].mean.numpy(),
+                               g[tag + '_fwd_mean'], atol=1e-6)
+            assert np.allclose(nets.value_forward(vf0, x).numpy(),
+                               g[tag + '_fwd_value'], atol=1e-6)
+        algo = OraclePPO(pol0, vf0, max_episode_length=P,
+                         max_optimization_epochs=E, minibatch_size=mb,
+                         policy_lr=2.5e-3, vf_lr=2.5e-3)
+        for it in range(2):
+            pre = '%s_it%d_' % (tag, it)
+            lens = g[pre + 'lengths']
+            b = ob.OracleEpisodeBatch(
+                observations=g[pre + 'observations'],
+                last_observations=np.zeros((len(lens), O), np.float32),
+                actions=g[pre + 'actions'], rewards=g[pre + 'rewards'],
+                step_types=g[pre + 'step_types'], lengths=lens,
+                max_episode_length=P)
+            np.random.seed(int(g[pre + 'np_seed']))
+            out = algo.train_once(b)
+            for mine, theirs in LOG_KEYS.items():
+                assert np.isclose(out[mine], float(g[pre + 'log:' + theirs]),
+                                  atol=1e-5, rtol=1e-5), (mine, it)
+            pol, vf = algo.state()
+            for k, v in pol.items():
+                assert np.allclose(v, g[pre + 'pol:' + k], atol=1e-6), k
+            for k, v in vf.items():
+                assert np.allclose(v, g[pre + 'vf:' + k], atol=1e-6), k
+
+
+# round 3: torch.optim classes other than the default Adam through make_optimizer
+# (tests/golden/train_once_optimizers.npz)
+OPTIMIZER_CASES = {
+    'sgd_plain': (torch.optim.SGD, dict(lr=5e-2)),
+    'sgd_nesterov_wd': (torch.optim.SGD, dict(lr=2e-2, momentum=0.9,
+                                              nesterov=True, weight_decay=1e-3)),
+    'sgd_momentum_dampening': (torch.optim.SGD, dict(lr=2e-2, momentum=0.8,
+                                                     dampening=0.1)),
+    'rmsprop': (torch.optim.RMSprop, dict(lr=1e-3)),
+    'rmsprop_centered_momentum': (torch.optim.RMSprop,
+                                  dict(lr=1e-3, alpha=0.9, momentum=0.5,
+                                       centered=True, weight_decay=1e-3)),
+    'adam_amsgrad_wd': (torch.optim.Adam, dict(lr=2.5e-3, amsgrad=True,
+                                               weight_decay=1e-2)),
+    'adamw': (torch.optim.AdamW, dict(lr=2.5e-3, weight_decay=5e-2)),
+}
+
+
+@pytest.mark.parametrize('tag', sorted(OPTIMIZER_CASES))
+def test_golden_train_once_other_optimizers(golden, tag):
+    """``OptimizerWrapper((torch.optim.X, kwargs), module)`` for X other than the
+    default Adam (``make_optimizer``, ``_functions.py:25-65``): two real PPO
+    iterations, logged scalars and post-update parameters."""
+    g = golden('train_once_optimizers')
+    O, A, P, E, mb = [int(v) for v in g[tag + '_cfg']]
+    cls, kw = OPTIMIZER_CASES[tag]
+    pol0, vf0 = _params(g, tag + '_pol0:'), _params(g, tag + '_vf0:')
+    algo = OraclePPO(pol0, vf0, max_episode_length=P, max_optimization_epochs=E,
+                     minibatch_size=mb, policy_optimizer=(cls, dict(kw)),
+                     vf_optimizer=(cls, dict(kw)))
+    for it in range(2):
+        pre = '%s_it%d_' % (tag, it)
+        lens = g[pre + 'lengths']
+        b = ob.OracleEpisodeBatch(
+            observations=g[pre + 'observations'],
+            last_observations=np.zeros((len(lens), O), np.float32),
+            actions=g[pre + 'actions'], rewards=g[pre + 'rewards'],
+            step_types=g[pre + 'step_types'], lengths=lens,
+            max_episode_length=P)
+        np.random.seed(int(g[pre + 'np_seed']))
+        out = algo.train_once(b)
+        for mine, theirs in LOG_KEYS.items():
+            assert np.isclose(out[mine], float(g[pre + 'log:' + theirs]),
+                              atol=1e-5, rtol=1e-5), (mine, it)
+        pol, vf = algo.state()
+        for k, v in pol.items():
+            assert np.allclose(v, g[pre + 'pol:' + k], atol=1e-6), k
+        for k, v in vf.items():
+            assert np.allclose(v, g[pre + 'vf:' + k], atol=1e-6), k
+
+
 LAYER_NORM_CASES = {
     'layer_norm': (torch.tanh, torch.tanh),
     'layer_norm_relu': (torch.relu, torch.tanh),

@@ -740,6 +740,147 @@ def test_output_nonlinearity_matches_real_reference(golden, tag):
             assert np.allclose(v.numpy(), g[pre + 'vf:' + k], atol=2e-6), k
 
 
+# round 3 (tests/golden/policy_activations.npz): tag -> (policy kwargs, vf kwargs),
+# spelled differently from the generator where the reference accepts several forms
+MORE_ACTIVATION_CASES = {
+    'sigmoid': (dict(hidden_nonlinearity=torch.nn.Sigmoid),
+                dict(hidden_nonlinearity=torch.sigmoid)),
+    'elu': (dict(hidden_nonlinearity=torch.nn.functional.elu),
+            dict(hidden_nonlinearity=torch.nn.ELU())),
+    'leaky_relu': (dict(hidden_nonlinearity=torch.nn.LeakyReLU),
+                   dict(hidden_nonlinearity=torch.nn.functional.leaky_relu)),
+    'softplus_hidden': (dict(hidden_nonlinearity=torch.nn.functional.softplus),
+                        dict(hidden_nonlinearity=torch.nn.Softplus)),
+    'out_sigmoid_elu_hidden': (
+        dict(output_nonlinearity=torch.sigmoid,
+             hidden_nonlinearity=torch.nn.functional.elu),
+        dict(output_nonlinearity=torch.nn.functional.softplus)),
+}
+
+
+@pytest.mark.parametrize('tag', sorted(MORE_ACTIVATION_CASES))
+def test_more_nonlinearities_match_real_reference(golden, tag):
+    """sigmoid / elu / leaky_relu / softplus as hidden or output nonlinearity
+    (``NonLinearity``, ``torch/modules/multi_headed_mlp_module.py:154-197``):
+    forward outputs of the real networks and two real PPO iterations.  Their
+    slopes are functions of the OUTPUT (h (1 - h), h + 1, 0.01, 1 - exp(-h)), so
+    the backward pass reads the same activations as for tanh."""
+    from garage_amd.algos import PPO
+    from garage_amd.optimizers import OptimizerWrapper
+    from garage_amd.policies import GaussianMLPPolicy, GaussianMLPValueFunction
+    g = golden('policy_activations')
+    O, A, P, E, mb = [int(v) for v in g[tag + '_cfg']]
+    spec = _spec(O, A, P)
+    pkw, vkw = MORE_ACTIVATION_CASES[tag]
+    pol = GaussianMLPPolicy(spec, hidden_sizes=(8, 8), **pkw)
+    vf = GaussianMLPValueFunction(spec, hidden_sizes=(8, 8), **vkw)
+    pol.load_state_dict(_sd(g, tag + '_pol0:'))
+    vf.load_state_dict(_sd(g, tag + '_vf0:'))
+    x = torch.from_numpy(g[tag + '_fwd_obs'])
+    dist, _ = pol.forward(x)
+    assert np.allclose(dist.mean.cpu().numpy(), g[tag + '_fwd_mean'], atol=2e-6)
+    assert np.allclose(vf.forward(x).cpu().numpy().reshape(-1),
+                       g[tag + '_fwd_value'].reshape(-1), atol=2e-6)
+    algo = PPO(env_spec=spec, policy=pol, value_function=vf, sampler=None,
+               policy_optimizer=OptimizerWrapper(
+                   (torch.optim.Adam, dict(lr=2.5e-3)), pol,
+                   max_optimization_epochs=E, minibatch_size=mb),
+               vf_optimizer=OptimizerWrapper(
+                   (torch.optim.Adam, dict(lr=2.5e-3)), vf,
+                   max_optimization_epochs=E, minibatch_size=mb))
+    for it in range(2):
+        pre = '%s_it%d_' % (tag, it)
+        batch = _host_batch(spec, g, pre, O)
+        np.random.seed(int(g[pre + 'np_seed']))
+        algo._train_once(it, batch)
+        for mine, theirs in LOG_KEYS.items():
+            want = float(g[pre + 'log:' + theirs])
+            assert np.isclose(algo.last_tabular[mine], want, atol=1e-5,
+                              rtol=1e-5), (mine, it, algo.last_tabular[mine],
+                                           want)
+        for k, v in pol.state_dict().items():
+            assert np.allclose(v.numpy(), g[pre + 'pol:' + k], atol=2e-6), k
+        for k, v in vf.state_dict().items():
+            assert np.allclose(v.numpy(), g[pre + 'vf:' + k], atol=2e-6), k
+
+
+def test_unsupported_nonlinearities_are_refused():
+    """Parameterised activations away from torch's defaults, and callables whose
+    slope is not a function of their output, raise instead of silently computing
+    something else."""
+    from garage_amd.policies import GaussianMLPPolicy
+    spec = _spec(4, 2, 8)
+    for bad in (torch.nn.ELU(alpha=0.5), torch.nn.LeakyReLU(0.2),
+                torch.nn.Softplus(beta=2), torch.nn.functional.gelu, torch.sin):
+        with pytest.raises(NotImplementedError):
+            GaussianMLPPolicy(spec, hidden_sizes=(8, 8),
+                              hidden_nonlinearity=bad)
+
+
+OPTIMIZER_CASES = {
+    'sgd_plain': (torch.optim.SGD, dict(lr=5e-2)),
+    'sgd_nesterov_wd': (torch.optim.SGD, dict(lr=2e-2, momentum=0.9,
+                                              nesterov=True, weight_decay=1e-3)),
+    'sgd_momentum_dampening': (torch.optim.SGD, dict(lr=2e-2, momentum=0.8,
+                                                     dampening=0.1)),
+    'rmsprop': (torch.optim.RMSprop, dict(lr=1e-3)),
+    'rmsprop_centered_momentum': (torch.optim.RMSprop,
+                                  dict(lr=1e-3, alpha=0.9, momentum=0.5,
+                                       centered=True, weight_decay=1e-3)),
+    'adam_amsgrad_wd': (torch.optim.Adam, dict(lr=2.5e-3, amsgrad=True,
+                                               weight_decay=1e-2)),
+    'adamw': (torch.optim.AdamW, dict(lr=2.5e-3, weight_decay=5e-2)),
+}
+
+
+@pytest.mark.parametrize('tag', sorted(OPTIMIZER_CASES))
+def test_other_optimizers_match_real_reference(golden, tag):
+    """``make_optimizer`` (``_functions.py:25-65``) builds any torch.optim class:
+    SGD (momentum / dampening / nesterov / weight decay), RMSprop (centred,
+    momentum) and Adam / AdamW with weight decay or amsgrad step through
+    ``ga_optimizer_step_f32`` behind the per-minibatch loop -- two real PPO
+    iterations of the reference each (tests/golden/train_once_optimizers.npz),
+    then a pickle round trip that must carry the optimizer state."""
+    import pickle
+
+    from garage_amd.algos import PPO
+    from garage_amd.optimizers import OptimizerWrapper
+    from garage_amd.policies import GaussianMLPPolicy, GaussianMLPValueFunction
+    g = golden('train_once_optimizers')
+    O, A, P, E, mb = [int(v) for v in g[tag + '_cfg']]
+    spec = _spec(O, A, P)
+    cls, kw = OPTIMIZER_CASES[tag]
+    pol = GaussianMLPPolicy(spec, hidden_sizes=(8, 8))
+    vf = GaussianMLPValueFunction(spec, hidden_sizes=(8, 8))
+    pol.load_state_dict(_sd(g, tag + '_pol0:'))
+    vf.load_state_dict(_sd(g, tag + '_vf0:'))
+    algo = PPO(env_spec=spec, policy=pol, value_function=vf, sampler=None,
+               policy_optimizer=OptimizerWrapper((cls, dict(kw)), pol,
+                                                 max_optimization_epochs=E,
+                                                 minibatch_size=mb),
+               vf_optimizer=OptimizerWrapper((cls, dict(kw)), vf,
+                                             max_optimization_epochs=E,
+                                             minibatch_size=mb))
+    assert not algo._native_update_ok()
+    for it in range(2):
+        if it == 1:  # the second iteration runs on a restored copy
+            algo = pickle.loads(pickle.dumps(algo))
+            pol, vf = algo.policy, algo._value_function
+        pre = '%s_it%d_' % (tag, it)
+        batch = _host_batch(spec, g, pre, O)
+        np.random.seed(int(g[pre + 'np_seed']))
+        algo._train_once(it, batch)
+        for mine, theirs in LOG_KEYS.items():
+            want = float(g[pre + 'log:' + theirs])
+            assert np.isclose(algo.last_tabular[mine], want, atol=1e-5,
+                              rtol=1e-5), (mine, it, algo.last_tabular[mine],
+                                           want)
+        for k, v in pol.state_dict().items():
+            assert np.allclose(v.numpy(), g[pre + 'pol:' + k], atol=2e-6), k
+        for k, v in vf.state_dict().items():
+            assert np.allclose(v.numpy(), g[pre + 'vf:' + k], atol=2e-6), k
+
+
 def test_output_nonlinearity_python_loop_and_trpo_against_oracle():
     """The same option through the Python minibatch loop (``engine.backward``
     scales d(output)) and through TRPO's Fisher-vector product (tangent and seed
