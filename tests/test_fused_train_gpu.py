@@ -37,6 +37,12 @@ CASES = {
                                  'policy_ent_coeff': 0.01, 'center_adv': False,
                                  'stop_entropy_gradient': True}),
     'full_batch': (8, 2, (64, 64), None, False, {}),
+    # 17 .. 20 inputs at 256 units: the software-pipelined k-loop instantiation
+    # (c3_shape is one; these add the other input widths, ragged last tiles --
+    # the predicated-store variant -- and a one-output head)
+    'pipelined_obs18_ragged': (18, 6, (256, 256), 1000, False, {}),
+    'pipelined_obs19_vpg': (19, 3, (256, 256), 777, False, {'vpg': True}),
+    'pipelined_obs20_categorical': (20, 5, (256, 256), 2048, True, {}),
     # 2 x 32 / 2 x 64 networks: the whole step in one launch (narrow_step.hip)
     'narrow_32': (4, 2, (32, 32), 200, True, {}),
     'narrow_32_gaussian_wide_input': (32, 8, (32, 32), 333, False, {}),
@@ -299,3 +305,30 @@ def test_outputs_only_forward_matches_the_per_layer_forward(shape):
     assert lib.ga_mlp_forward_eval_supported(C.byref(relu._desc)) == 0
     y = relu.forward(X, M, keep_acts=False)
     assert torch.isfinite(y[:, :out_dim]).all()
+
+
+@pytest.mark.parametrize('case', ['c3_shape', 'pipelined_obs18_ragged',
+                                  'pipelined_obs20_categorical'])
+def test_pipelined_kloop_is_bit_identical_to_the_plain_loop(case):
+    """``fwd_head_loss_kernel<256,1,8,true,5>`` / ``mlp_eval_forward_kernel<256,1,8,5>``
+    issue the first-layer producer, the H1 spill and the weight prefetch between the
+    MFMAs of a k-step (round 3); every output element keeps its k order, so a whole
+    iteration -- several minibatches, ragged last tiles, the full-batch evaluation
+    passes -- must give the same BITS as the plain loop (``ga_set_pipelined_kloop(0)``)."""
+    from garage_amd import _lib
+    lib = _lib.load()
+    spec, batch = _problem(case)
+    opt = (torch.optim.Adam, dict(lr=1e-3))
+    res = []
+    try:
+        for on in (1, 0):
+            lib.ga_set_pipelined_kloop(on)
+            algo, pol, vf = _algo(case, spec, opt, epochs=2)
+            np.random.seed(11)
+            algo._train_once(0, batch)
+            res.append((pol.net.params.clone(), vf.net.params.clone(),
+                        pol.net.exp_avg_sq.clone(), dict(algo.last_tabular)))
+    finally:
+        lib.ga_set_pipelined_kloop(1)
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert torch.equal(res[0][2], res[1][2]) and res[0][3] == res[1][3]
