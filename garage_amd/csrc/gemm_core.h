@@ -33,27 +33,34 @@ __device__ __forceinline__ float tanh_fast(float x) {
 //   threshold 20) -- torch.nn.functional's defaults.
 // Network code (ga_mlp_desc::hidden_act, GemmParams::hact): 0 tanh (what a zeroed
 //   descriptor means), 1 relu, 2 none, 3 .. 6 as above.
-__device__ __forceinline__ float act_apply(float v, int act) {
+// (the codes beyond tanh / relu / none sit behind a wave-uniform branch and a call:
+// inlined into a select chain their exp / log expansions ran for EVERY element of
+// every epilogue -- C5's forward GEMM 230 -> 235 us)
+__device__ __attribute__((noinline)) float act_apply_more(float v, int act) {
   switch (act) {
-    case 1: return tanh_fast(v);
-    case 2: return fmaxf(v, 0.f);
     case 3: return 1.f / (1.f + expf(-v));
     case 4: return v > 0.f ? v : expm1f(v);
     case 5: return v > 0.f ? v : 0.01f * v;
-    case 6: return v > 20.f ? v : log1pf(expf(v));
-    default: return v;
+    default: return v > 20.f ? v : log1pf(expf(v));  // 6 softplus
   }
 }
-__device__ __forceinline__ float act_slope(float h, int hact) {
+__device__ __forceinline__ float act_apply(float v, int act) {
+  if (__builtin_expect(act <= 2, 1))
+    return act == 1 ? tanh_fast(v) : (act == 2 ? fmaxf(v, 0.f) : v);
+  return act_apply_more(v, act);
+}
+__device__ __attribute__((noinline)) float act_slope_more(float h, int hact) {
   switch (hact) {
-    case 0: return 1.f - h * h;
-    case 1: return h > 0.f ? 1.f : 0.f;
     case 3: return h * (1.f - h);
     case 4: return h > 0.f ? 1.f : h + 1.f;       // exp(x) = h + 1 for x <= 0
     case 5: return h > 0.f ? 1.f : 0.01f;
-    case 6: return 1.f - expf(-h);                 // sigmoid(x) with h = log(1 + e^x)
-    default: return 1.f;
+    default: return 1.f - expf(-h);                // 6: sigmoid(x), h = log(1 + e^x)
   }
+}
+__device__ __forceinline__ float act_slope(float h, int hact) {
+  if (__builtin_expect(hact <= 2, 1))
+    return hact == 0 ? 1.f - h * h : (hact == 1 ? (h > 0.f ? 1.f : 0.f) : 1.f);
+  return act_slope_more(h, hact);
 }
 __host__ __device__ inline int act_forward_code(int hidden_act) {
   return hidden_act == 0 ? 1 : (hidden_act == 1 ? 2 : (hidden_act == 2 ? 0 : hidden_act));
