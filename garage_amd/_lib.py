@@ -223,6 +223,7 @@ SIGNATURES = {
     'ga_set_narrow_step': (c_int, [c_int]),
     'ga_set_fused_first_layer': (c_int, [c_int]),
     'ga_set_pipelined_kloop': (c_int, [c_int]),
+    'ga_set_split_bf16': (c_int, [c_int]),
     'ga_update_epoch_pair': (c_int, [C.POINTER(UpdateArgs), ptr,
                                      C.POINTER(UpdateArgs), ptr]),
     'ga_set_allreduce_hook': (None, [ptr]),

@@ -112,4 +112,7 @@ int ga_reduce_regions_adam(const ga_fused_region* regions, int n_regions, float*
                            int do_adam, int zero_slot0, const double* lpart, int n_lpart,
                            int64_t M, const ga_fused_loss_args* loss, float* loss_out,
                            hipStream_t stream);
+/* 1 while the opt-in split-operand (3 x bf16) k-loops are selected
+ * (ga_set_split_bf16 / GARAGE_AMD_SPLIT_BF16=1). */
+int ga_split_bf16_enabled(void);
 }

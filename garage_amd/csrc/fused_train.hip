@@ -42,7 +42,9 @@
 // the two paths agree to rounding, not bit for bit.
 #include "common.h"
 #include <hip/hip_ext.h>
+#include <mutex>
 #include <type_traits>
+#include <vector>
 
 #include "prof.h"
 
@@ -86,6 +88,10 @@ struct FwdLossParams {
   int64_t l1_ldh;
   float* eval_out;       // EVAL: the head outputs [M][eval_ldo], nothing else is kept
   int64_t eval_ldo;
+  // SPLIT instantiation (opt-in, see "split-operand k-loop" below): W as three bf16
+  // planes in fragment order (split_planes_kernel), plane p at bplanes + p * bplane_stride
+  const uint16_t* bplanes;
+  int64_t bplane_stride;
   long long* dbg;        // developer hook: phase timestamps of one workgroup
 };
 
@@ -100,6 +106,12 @@ typedef const __attribute__((address_space(4))) float* ft_uniform_ptr;
 typedef float ft_f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int FT_W1_FLOATS = 5120;  // LDS floats for the first layer's weights
+
+#ifdef GA_SPLIT_NO_SETPRIO
+#define FT_SPLIT_PRIO(x)
+#else
+#define FT_SPLIT_PRIO(x) __builtin_amdgcn_s_setprio(x)
+#endif
 
 // MFMAs of one 32-deep k-step on k-contiguous LDS tiles (gemm_core.h: the
 // A_KC = B_KC = true case of gemm_mainloop's body)
@@ -148,12 +160,15 @@ __device__ __forceinline__ void ft_kstep(const float* As, const float* Bs,
 // the plain loop.
 // ft_tile / ft_tiles: this workgroup's 64-row tile and the number of tiles of ITS
 // network's minibatch (a pair launch carries the tiles of two networks in one grid)
-template <int BN, int WAVES_M, int WAVES_N, bool L1, bool EVAL, int KSC = 0>
+template <int BN, int WAVES_M, int WAVES_N, bool L1, bool EVAL, int KSC = 0,
+          bool SPLIT = false>
 __device__ __forceinline__ void fwd_head_loss_body(const FwdLossParams& p,
                                                    const int ft_tile,
                                                    const int ft_tiles) {
   static_assert(L1 || !EVAL, "the evaluation forward computes the first layer itself");
   static_assert(L1 || KSC == 0, "KSC belongs to the first-layer producer");
+  static_assert(!SPLIT || (L1 && KSC == 0 && WAVES_M * WAVES_N == 8),
+                "the split-operand loop: first layer in the kernel, 8 waves");
   constexpr int NT = 64 * WAVES_M * WAVES_N;
   constexpr int WM = FT_ROWS / WAVES_M, WN = BN / WAVES_N;
   constexpr int TM = WM / 32, TN = WN / 32;
@@ -208,9 +223,11 @@ __device__ __forceinline__ void fwd_head_loss_body(const FwdLossParams& p,
     const int ld0 = (in_w + 3) & ~3, KS = ld0 / 4;
     // two buffers for the produced A chunks; the B fragments never pass through LDS
     auto As2 = [&](int i) { return lds + (i & 1) * A_FLOATS; };
-    float* w1s = lds + 2 * A_FLOATS;
+    // (SPLIT: two buffers of three bf16 planes instead)
+    constexpr int OPER_FLOATS = SPLIT ? 2 * FT_ABUF_B / 4 : 2 * A_FLOATS;
+    float* w1s = lds + OPER_FLOATS;
     float* b1s = aux;
-    static_assert(2 * A_FLOATS + FT_W1_FLOATS <= TILE_FLOATS + EXTRA, "W1 fits");
+    static_assert(OPER_FLOATS + FT_W1_FLOATS <= TILE_FLOATS + EXTRA, "W1 fits");
     const int r16 = lane & 15, g4 = lane >> 4;
     const int half = lane >> 5, l31 = lane & 31;
     const int rt = wave & 3;  // row sub-tile (the same for both sub-tiles of a wave)
@@ -232,7 +249,7 @@ __device__ __forceinline__ void fwd_head_loss_body(const FwdLossParams& p,
           bn[j][g] = *reinterpret_cast<const float4*>(Wb + (int64_t)(32 * j) * p.g.ldb +
                                                       32 * s + 8 * g);
     };
-    fetch_b(0);
+    if constexpr (!SPLIT) fetch_b(0);
     float xa[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
@@ -281,6 +298,226 @@ __device__ __forceinline__ void fwd_head_loss_body(const FwdLossParams& p,
     };
     const int nk = K / BK;
     __syncthreads();  // W1 / b1 staged
+    if constexpr (SPLIT) {
+      // ---- split-operand k-loop (see ft_split3).  The first-layer producer runs its
+      // 16x16x4 products TRANSPOSED (A = W1 rows, B = observation rows: the same
+      // products in the same order), so that a lane holds four consecutive units k of
+      // one batch row: split, packed along k and written as 8 bytes per plane; H1 goes
+      // to memory from the same registers.  The W planes come straight from L2 as
+      // fragments (lane (n, half): 8 consecutive k), one step ahead, refilled in place.
+      static_assert(NSUB == 1, "one 16 x 16 sub-tile per wave and chunk");
+      char* apl = reinterpret_cast<char*>(lds);
+      const int ct = wave >> 2;
+      const bool full = m0 + FT_ROWS <= M;
+      float* h1_row = p.l1_H + (int64_t)(m0 + 16 * rt + r16) * p.l1_ldh + 16 * ct + 4 * g4;
+      const bool h1_ok = full || m0 + 16 * rt + r16 < M;
+      auto produce_split = [&](int c) {
+        const float* wrow = w1s + (32 * c + 16 * ct + r16) * ld0 + g4;
+        ft_f32x4 e4 = {0.f, 0.f, 0.f, 0.f}, o4 = {0.f, 0.f, 0.f, 0.f};
+        // (at most 20 inputs on this path: five groups of four, as in the loop below)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+          const float w = wrow[4 * min(k, KS - 1)], x = k < KS ? xa[k] : 0.f;
+          if (k & 1)
+            o4 = __builtin_amdgcn_mfma_f32_16x16x4f32(w, x, o4, 0, 0, 0);
+          else
+            e4 = __builtin_amdgcn_mfma_f32_16x16x4f32(w, x, e4, 0, 0, 0);
+        }
+        const float4 bq = *reinterpret_cast<const float4*>(b1s + 32 * c + 16 * ct + 4 * g4);
+        const float bb[4] = {bq.x, bq.y, bq.z, bq.w};
+        float hv[4];
+        uint32_t hi[4], mid[4], lo[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          hv[r] = tanh_fast(e4[r] + o4[r] + bb[r]);
+          ft_split3(hv[r], hi[r], mid[r], lo[r]);
+        }
+        char* dst = apl + (c & 1) * FT_ABUF_B + (16 * rt + r16) * FT_PLANE_ROW_B +
+                    (16 * ct + 4 * g4) * 2;
+        *reinterpret_cast<uint2*>(dst) =
+            make_uint2(ft_pack_hi16(hi[0], hi[1]), ft_pack_hi16(hi[2], hi[3]));
+        *reinterpret_cast<uint2*>(dst + FT_PLANE_B) =
+            make_uint2(ft_pack_hi16(mid[0], mid[1]), ft_pack_hi16(mid[2], mid[3]));
+        *reinterpret_cast<uint2*>(dst + 2 * FT_PLANE_B) =
+            make_uint2(ft_pack_hi16(lo[0], lo[1]), ft_pack_hi16(lo[2], lo[3]));
+        if constexpr (!EVAL) {
+          if (h1_ok)
+            *reinterpret_cast<float4*>(h1_row + 32 * c) =
+                make_float4(hv[0], hv[1], hv[2], hv[3]);
+        }
+      };
+      // W fragments of step s, group g (16 k), plane pl (split_planes_kernel's order)
+      const uint16_t* wpl = p.bplanes + ((wn0 / 32) * 64 + lane) * 8;
+      ft_u32x4 bw[TN][2][3];
+      auto fetch_planes = [&](int s, int g) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl)
+            bw[j][g][pl] = *reinterpret_cast<const ft_u32x4*>(
+                wpl + pl * p.bplane_stride + ((2 * s + g) * (BN / 32) + j) * 512);
+      };
+      fetch_planes(0, 0);
+      fetch_planes(0, 1);
+      produce_split(0);
+      __syncthreads();
+      FT_STAMP(1);
+      // One step = 24 MFMAs (2 groups of 16 k x 2 row blocks x 6 products), the row
+      // blocks alternating so that consecutive MFMAs never wait for each other's
+      // accumulator; the producer of the NEXT chunk is cut into pieces issued between
+      // them (the order is pinned: the pieces are chains of dependent instructions,
+      // each placed where its inputs have had an MFMA or more of time to arrive).
+#define FT_SB __builtin_amdgcn_sched_barrier(0)
+      // The producer is itself pipelined across steps: step s runs bias + tanh + split
+      // + LDS write of chunk s + 1 on first-layer products that step s - 1 issued (e4 /
+      // o4 live across the barrier), and issues the products of chunk s + 2 at its end:
+      // nothing in a step waits for something the same step started, except the A
+      // fragments of the step itself.
+      ft_f32x4 e4 = {0.f, 0.f, 0.f, 0.f}, o4 = {0.f, 0.f, 0.f, 0.f};
+      auto first_layer = [&](int c, const float (&wv)[5]) {
+        e4 = ft_f32x4{0.f, 0.f, 0.f, 0.f};
+        o4 = ft_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+          const float x = k < KS ? xa[k] : 0.f;
+          if (k & 1)
+            o4 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[k], x, o4, 0, 0, 0);
+          else
+            e4 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[k], x, e4, 0, 0, 0);
+        }
+      };
+      auto first_layer_weights = [&](int c, float (&wv)[5]) {
+        // (KS <= 5 on this path: the host checks it; slots beyond KS read a valid
+        // address and multiply a zero)
+        const float* wrow = w1s + (32 * c + 16 * ct + r16) * ld0 + g4;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) wv[k] = wrow[4 * min(k, KS - 1)];
+      };
+      if (nk > 1) {
+        float wv[5];
+        first_layer_weights(1, wv);
+        first_layer(1, wv);
+      }
+      auto step = [&](int s, auto more_tag, auto more2_tag) {
+        constexpr bool MORE = decltype(more_tag)::value;    // chunk s + 1 exists
+        constexpr bool MORE2 = decltype(more2_tag)::value;  // chunk s + 2 exists
+        const char* Ab = apl + (s & 1) * FT_ABUF_B;
+        const char* arow = Ab + (wm0 + l31) * FT_PLANE_ROW_B + 16 * half;
+        ft_u32x4 af[2][TM][3];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl)
+            af[0][i][pl] = *reinterpret_cast<const ft_u32x4*>(
+                arow + pl * FT_PLANE_B + 32 * i * FT_PLANE_ROW_B);
+        float wv[5];
+        float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (MORE)
+          bq = *reinterpret_cast<const float4*>(b1s + 32 * (s + 1) + 16 * ct + 4 * g4);
+        FT_SB;
+        // ga_tanh (common.h) in four stages over the four values: the same operations
+        // in the same order per value, a stage's four chains independent of each other
+        float tc[4], ex[4], dn[4], rc[4], hv[4];
+        uint32_t hi[4], mid[4], lo[4];
+        auto side = [&](int t) {
+          if constexpr (MORE) {
+            if (t == 1) {
+              const float bb[4] = {bq.x, bq.y, bq.z, bq.w};
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float t2 = 2.f * (e4[r] + o4[r] + bb[r]);
+                tc[r] = t2 > 80.f ? 80.f : t2;
+              }
+            } else if (t == 3) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) ex[r] = __expf(tc[r]);
+            } else if (t == 5) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                dn[r] = ex[r] + 1.f;
+                rc[r] = __builtin_amdgcn_rcpf(dn[r]);
+              }
+            } else if (t == 7) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float rr = fmaf(fmaf(-dn[r], rc[r], 1.f), rc[r], rc[r]);
+                hv[r] = fmaf(-2.f, rr, 1.f);
+              }
+            } else if (t == 9) {
+              ft_split3(hv[0], hi[0], mid[0], lo[0]);
+              ft_split3(hv[1], hi[1], mid[1], lo[1]);
+            } else if (t == 10) {
+              ft_split3(hv[2], hi[2], mid[2], lo[2]);
+              ft_split3(hv[3], hi[3], mid[3], lo[3]);
+            } else if (t == 12) {
+              char* dst = apl + ((s + 1) & 1) * FT_ABUF_B + (16 * rt + r16) * FT_PLANE_ROW_B +
+                          (16 * ct + 4 * g4) * 2;
+              *reinterpret_cast<uint2*>(dst) =
+                  make_uint2(ft_pack_hi16(hi[0], hi[1]), ft_pack_hi16(hi[2], hi[3]));
+              *reinterpret_cast<uint2*>(dst + FT_PLANE_B) =
+                  make_uint2(ft_pack_hi16(mid[0], mid[1]), ft_pack_hi16(mid[2], mid[3]));
+              *reinterpret_cast<uint2*>(dst + 2 * FT_PLANE_B) =
+                  make_uint2(ft_pack_hi16(lo[0], lo[1]), ft_pack_hi16(lo[2], lo[3]));
+            } else if (t == 13) {
+              if constexpr (!EVAL) {
+                if (h1_ok)
+                  *reinterpret_cast<float4*>(h1_row + 32 * (s + 1)) =
+                      make_float4(hv[0], hv[1], hv[2], hv[3]);
+              }
+            }
+          }
+          if constexpr (MORE2) {
+            if (t == 11) first_layer_weights(s + 2, wv);
+            if (t == 15) first_layer(s + 2, wv);
+          }
+        };
+        FT_SPLIT_PRIO(1);
+#pragma unroll
+        for (int slot = 0; slot < 24; ++slot) {
+          const int g = slot / 12, t = (slot % 12) / 2, i = slot % 2;
+          // products small to large, the A planes released early:
+          // (lo,hi) (mid,mid) (mid,hi) (hi,lo) (hi,mid) (hi,hi)
+          const int pa = t == 0 ? 2 : (t == 1 || t == 2) ? 1 : 0;
+          const int pb = t == 3 ? 2 : (t == 1 || t == 4) ? 1 : 0;
+#ifdef GA_ABL_NOMFMA
+          acc[i][0][slot & 15] += __uint_as_float(af[g][i][pa][0] ^ bw[0][g][pb][0]);
+#else
+          acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+              __builtin_bit_cast(ft_bf16x8, af[g][i][pa]),
+              __builtin_bit_cast(ft_bf16x8, bw[0][g][pb]), acc[i][0], 0, 0, 0);
+#endif
+          FT_SB;
+          // the second group's A planes, each as late as its first use allows (the
+          // first group's planes die in the order lo, mid, hi)
+          if (slot == 6 || slot == 8 || slot == 11) {
+            const int pl = slot == 6 ? 2 : slot == 8 ? 1 : 0;
+#pragma unroll
+            for (int ii = 0; ii < TM; ++ii)
+              af[1][ii][pl] = *reinterpret_cast<const ft_u32x4*>(
+                  arow + pl * FT_PLANE_B + 32 * ii * FT_PLANE_ROW_B + 32);
+          }
+#ifndef GA_ABL_NOFETCH
+          if constexpr (MORE) {
+            if (slot == 11) fetch_planes(s + 1, 0);
+            if (slot == 23) fetch_planes(s + 1, 1);
+          }
+#endif
+#ifndef GA_ABL_NOPRODUCE
+          side(slot);
+#endif
+          FT_SB;
+        }
+        FT_SPLIT_PRIO(0);
+#ifndef GA_ABL_NOBARRIER
+        __syncthreads();
+#endif
+      };
+#undef FT_SB
+      static_assert(TN == 1 && TM == 2, "the slot list is written for a 64 x 32 wave tile");
+      for (int s = 0; s + 2 < nk; ++s) step(s, std::true_type{}, std::true_type{});
+      if (nk > 1) step(nk - 2, std::true_type{}, std::false_type{});
+      step(nk - 1, std::false_type{}, std::false_type{});
+    } else {
     produce(0);
     __syncthreads();
     FT_STAMP(1);
@@ -515,6 +752,7 @@ __device__ __forceinline__ void fwd_head_loss_body(const FwdLossParams& p,
     }
 #endif
     }  // plain loop
+    }  // exact fp32 loops
   } else {
     float csum = 0.f;
     const bool full = m0 + FT_ROWS <= M;
@@ -794,6 +1032,57 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N,
                                                             (int)gridDim.x);
 }
 
+// the split-operand instantiation (opt-in; 256 units, first layer in the kernel)
+template <int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 4) void fwd_head_loss_split_kernel(
+    FwdLossParams p) {
+  fwd_head_loss_body<BN, WAVES_M, WAVES_N, true, false, 0, true>(p, (int)blockIdx.x,
+                                                                  (int)gridDim.x);
+}
+
+template <int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 4) void mlp_eval_forward_split_kernel(
+    FwdLossParams p) {
+  fwd_head_loss_body<BN, WAVES_M, WAVES_N, true, true, 0, true>(p, (int)blockIdx.x,
+                                                                 (int)gridDim.x);
+}
+
+// A weight matrix W [rows][ld] as the B operand B(k, n) of the split-operand loops,
+// three bf16 planes in FRAGMENT order: plane pl at out + pl * N * Kc; within a plane the
+// 16-byte fragment of lane l = (n % 32) + 32 * ((k / 8) % 2) of the 32-column block
+// n / 32 for the 16-deep k group k / 16 sits at ((k / 16) * (N / 32) + n / 32) * 64 + l
+// (in units of 8 bf16): one wave's load instruction reads 1 KB of consecutive bytes.
+//   fwd: B(k, n) = W[n * ld + k]   (N = rows, Kc = cols: n = unit of this layer)
+//   bwd: B(k, n) = W[k * ld + n]   (N = cols, Kc = rows: n = unit of the layer below)
+// BWD_ONLY = false: blocks [0, half) write fwd, [half, 2 half) write bwd.
+template <bool BWD_ONLY>
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ W,
+                                                           int64_t ld, int rows, int cols,
+                                                           uint16_t* __restrict__ fwd,
+                                                           uint16_t* __restrict__ bwd) {
+  const int64_t total = (int64_t)rows * cols;
+  const int64_t half_blocks = (total + 255) / 256;
+  const bool T = BWD_ONLY || (int64_t)blockIdx.x >= half_blocks;
+  const int64_t e =
+      ((int64_t)blockIdx.x - ((T && !BWD_ONLY) ? half_blocks : 0)) * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int N = T ? cols : rows;
+  // e enumerates the OUTPUT order (contiguous writes; the reads of bwd are strided:
+  // 64 K elements, nothing to optimise)
+  const int kk = (int)(e & 7);
+  const int l = (int)((e >> 3) & 63);
+  const int64_t blk = e >> 9;
+  const int nb = (int)(blk % (N / 32)), kg = (int)(blk / (N / 32));
+  const int n = 32 * nb + (l & 31);
+  const int k = 16 * kg + 8 * (l >> 5) + kk;
+  uint32_t hi, mid, lo;
+  ft_split3(T ? W[(int64_t)k * ld + n] : W[(int64_t)n * ld + k], hi, mid, lo);
+  uint16_t* out = T ? bwd : fwd;
+  out[e] = (uint16_t)(hi >> 16);
+  out[total + e] = (uint16_t)(mid >> 16);
+  out[2 * total + e] = (uint16_t)(lo >> 16);
+}
+
 // The pipelined k-loop is compiled for first layers of 17 .. 20 inputs (KSC = 5: the
 // HalfCheetah-shaped configuration the headline metric is quoted on) at 256 units;
 // every other shape takes the plain loop.  0 (or GARAGE_AMD_PIPELINED_KLOOP=0 in the
@@ -807,6 +1096,84 @@ bool pipelined_kloop_on() {
   return g_pipelined_kloop != 0;
 }
 
+// 1: the update kernels that have a split-operand instantiation use it (opt-in;
+// GARAGE_AMD_SPLIT_BF16=1 in the environment or ga_set_split_bf16(1)); default 0:
+// exact fp32 everywhere.
+int g_split_bf16 = -1;
+int g_split_parts = -1;  // developer knob: which kernels (1 forward, 2 data gradient,
+                         // 4 weight gradient, 8 evaluation forward); default all
+bool split_bf16_on(int part = 0) {
+  if (g_split_bf16 < 0) {
+    const char* e = getenv("GARAGE_AMD_SPLIT_BF16");
+    g_split_bf16 = (e && e[0] == '1') ? 1 : 0;
+  }
+  if (g_split_parts < 0) {
+    const char* e = getenv("GARAGE_AMD_SPLIT_PARTS");
+    g_split_parts = e ? atoi(e) : 15;
+  }
+  return g_split_bf16 != 0 && (part == 0 || (g_split_parts & part) != 0);
+}
+
+// Device buffers for the planes of a weight matrix, one per (matrix, orientation),
+// kept for the life of the process (a few 100 KB each); the planes are recomputed by
+// every launch that uses them (the weights change every optimizer step).
+struct PlaneBuf {
+  const float* W;
+  int rows, cols;       // W [rows][ld], cols valid
+  uint16_t* fwd;        // B(k = col, n = row): the forward kernel's operand
+  uint16_t* bwd;        // B(k = row, n = col): the data-gradient kernel's operand
+  hipStream_t bwd_stream;  // stream on which `bwd` was last refreshed, not yet consumed
+  bool bwd_fresh;
+};
+std::mutex g_plane_mu;
+std::vector<PlaneBuf> g_plane_bufs;
+// Both operands' planes of W [rows][ld] are written by ONE launch when the forward
+// kernel asks (want_bwd = false); the data-gradient launch of the same step -- same
+// stream, weights unchanged in between -- then finds its planes fresh and launches
+// nothing.  Any other order (a data-gradient launch on its own) recomputes.
+enum { PLANES_TRAIN_FWD = 0, PLANES_BWD = 1, PLANES_EVAL_FWD = 2 };
+const uint16_t* planes_for(const float* W, int64_t ld, int rows, int cols, int mode,
+                           hipStream_t stream) {
+  uint16_t *fwd = nullptr, *bwd = nullptr;
+  bool reuse = false;
+  {
+    std::lock_guard<std::mutex> lock(g_plane_mu);
+    PlaneBuf* pb = nullptr;
+    for (PlaneBuf& b : g_plane_bufs)
+      if (b.W == W && b.rows == rows && b.cols == cols) pb = &b;
+    if (!pb) {
+      uint16_t* buf = nullptr;
+      if (hipMalloc(&buf, 6 * (size_t)rows * cols * sizeof(uint16_t)) != hipSuccess)
+        return nullptr;
+      g_plane_bufs.push_back(
+          PlaneBuf{W, rows, cols, buf, buf + 3 * (size_t)rows * cols, nullptr, false});
+      pb = &g_plane_bufs.back();
+    }
+    if (mode == PLANES_BWD) {
+      reuse = pb->bwd_fresh && pb->bwd_stream == stream;
+      pb->bwd_fresh = false;
+    } else if (mode == PLANES_TRAIN_FWD) {
+      pb->bwd_fresh = true;
+      pb->bwd_stream = stream;
+    } else {
+      pb->bwd_fresh = false;
+    }
+    fwd = pb->fwd;
+    bwd = pb->bwd;
+  }
+  const unsigned blocks = (unsigned)(((int64_t)rows * cols + 255) / 256);
+  if (mode == PLANES_BWD) {
+    if (!reuse)
+      hipLaunchKernelGGL(split_planes_kernel<true>, dim3(blocks), dim3(256), 0, stream, W,
+                         ld, rows, cols, fwd, bwd);
+    return bwd;
+  }
+  hipLaunchKernelGGL(split_planes_kernel<false>,
+                     dim3(mode == PLANES_TRAIN_FWD ? 2 * blocks : blocks), dim3(256), 0,
+                     stream, W, ld, rows, cols, fwd, bwd);
+  return fwd;
+}
+
 // ---------------------------------------------------------------------------
 struct DgradWgrad0Params {
   GemmParams g;        // A = dZ2 [M][lda], B = W2 [K][ldb] (n contiguous), M, N = BN, K
@@ -817,12 +1184,18 @@ struct DgradWgrad0Params {
   const int32_t* idx;
   int in_w;            // <= 32
   float* wpart;        // [gx][BN * ld0 + BN]: dW1 [n][ld0], then db1 [n]
+  // SPLIT instantiation: W2 as the B operand B(k = unit of layer 2, n = unit of layer
+  // 1) in three bf16 planes, fragment order (split_planes_kernel<true>)
+  const uint16_t* bplanes;
+  int64_t bplane_stride;
   long long* dbg;      // developer hook: phase timestamps (FT_STAMP / FT_MARK)
 };
 
-template <int BN, int WAVES_M, int WAVES_N>
+template <int BN, int WAVES_M, int WAVES_N, bool SPLIT = false>
 __device__ __forceinline__ void dgrad_wgrad0_body(const DgradWgrad0Params& p,
                                                   const int ft_tile) {
+  static_assert(!SPLIT || (BN == 256 && WAVES_M == 1 && WAVES_N == 8),
+                "the split-operand loop is written for the 256-unit, 8-wave tile");
   constexpr int NT = 64 * WAVES_M * WAVES_N;
   constexpr int WM = FT_ROWS / WAVES_M, WN = BN / WAVES_N;
   constexpr int TM = WM / 32, TN = WN / 32;
@@ -873,7 +1246,101 @@ __device__ __forceinline__ void dgrad_wgrad0_body(const DgradWgrad0Params& p,
   // straight from L2 with the dZ2 tile double buffered in LDS and one barrier per
   // step -- 52.8 us; no LDS and no barrier at all, every wave fetching its own A and
   // B fragments -- 62.1 us; against 50.9 us for the two-barrier loop below)
-  {
+  if constexpr (SPLIT) {
+    // ---- split-operand k-loop (see ft_split3): the dZ2 tile is fetched as one 16-B
+    // quad per thread and 32-deep step, TWO steps ahead (it comes from HBM), split and
+    // written to three bf16 LDS planes one step ahead; the W2 planes come straight
+    // from L2 in fragment order, one step ahead, refilled in place; 24 MFMAs per step
+    // and wave, one barrier.
+    static_assert(TM == 2 && TN == 1 && NT == 512, "the slot list below");
+    char* apl = reinterpret_cast<char*>(lds);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int K = p.g.K, nk = K / BK;  // (K % 32 == 0: the host checks)
+    const int qrow = tid >> 3, qq = tid & 7;
+    const bool row_ok = m0 + qrow < M;
+    const float* arow_g = p.g.A + (int64_t)min(m0 + qrow, M - 1) * p.g.lda + 4 * qq;
+    auto load_quad = [&](int s) { return *reinterpret_cast<const float4*>(arow_g + 32 * s); };
+    auto store_quad = [&](int s, float4 v) {
+      if (!row_ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      uint32_t hi[4], mid[4], lo[4];
+      ft_split3(v.x, hi[0], mid[0], lo[0]);
+      ft_split3(v.y, hi[1], mid[1], lo[1]);
+      ft_split3(v.z, hi[2], mid[2], lo[2]);
+      ft_split3(v.w, hi[3], mid[3], lo[3]);
+      char* dst = apl + (s & 1) * FT_ABUF_B + qrow * FT_PLANE_ROW_B + qq * 8;
+      *reinterpret_cast<uint2*>(dst) =
+          make_uint2(ft_pack_hi16(hi[0], hi[1]), ft_pack_hi16(hi[2], hi[3]));
+      *reinterpret_cast<uint2*>(dst + FT_PLANE_B) =
+          make_uint2(ft_pack_hi16(mid[0], mid[1]), ft_pack_hi16(mid[2], mid[3]));
+      *reinterpret_cast<uint2*>(dst + 2 * FT_PLANE_B) =
+          make_uint2(ft_pack_hi16(lo[0], lo[1]), ft_pack_hi16(lo[2], lo[3]));
+    };
+    const uint16_t* wpl = p.bplanes + ((wn0 / 32) * 64 + lane) * 8;
+    ft_u32x4 bw[2][3];
+    auto fetch_planes = [&](int s, int g) {
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        bw[g][pl] = *reinterpret_cast<const ft_u32x4*>(
+            wpl + pl * p.bplane_stride + ((2 * s + g) * (BN / 32)) * 512);
+    };
+    fetch_planes(0, 0);
+    fetch_planes(0, 1);
+    float4 qc = load_quad(0);
+    float4 qn = nk > 1 ? load_quad(1) : qc;
+    store_quad(0, qc);
+    qc = qn;
+    __syncthreads();
+#define FT_SB __builtin_amdgcn_sched_barrier(0)
+    for (int s = 0; s < nk; ++s) {
+      const bool more = s + 1 < nk;
+      const char* arow = apl + (s & 1) * FT_ABUF_B + (wm0 + l31) * FT_PLANE_ROW_B + 16 * half;
+      ft_u32x4 af[2][TM][3];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          af[0][i][pl] = *reinterpret_cast<const ft_u32x4*>(arow + pl * FT_PLANE_B +
+                                                            32 * i * FT_PLANE_ROW_B);
+      if (s + 2 < nk) qn = load_quad(s + 2);
+      FT_SB;
+      FT_SPLIT_PRIO(1);
+#pragma unroll
+      for (int slot = 0; slot < 24; ++slot) {
+        const int g = slot / 12, t = (slot % 12) / 2, i = slot % 2;
+        const int pa = t == 0 ? 2 : (t == 1 || t == 2) ? 1 : 0;
+        const int pb = t == 3 ? 2 : (t == 1 || t == 4) ? 1 : 0;
+#ifdef GA_DABL_NOMFMA
+        acc[i][0][slot & 15] += __uint_as_float(af[g][i][pa][0] ^ bw[g][pb][0]);
+#else
+        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+            __builtin_bit_cast(ft_bf16x8, af[g][i][pa]),
+            __builtin_bit_cast(ft_bf16x8, bw[g][pb]), acc[i][0], 0, 0, 0);
+#endif
+        FT_SB;
+        if (slot == 6 || slot == 8 || slot == 11) {
+          const int pl = slot == 6 ? 2 : slot == 8 ? 1 : 0;
+#pragma unroll
+          for (int ii = 0; ii < TM; ++ii)
+            af[1][ii][pl] = *reinterpret_cast<const ft_u32x4*>(
+                arow + pl * FT_PLANE_B + 32 * ii * FT_PLANE_ROW_B + 32);
+        }
+        if (more) {
+#ifndef GA_DABL_NOSTORE
+          if (slot == 2) store_quad(s + 1, qc);
+#endif
+#ifndef GA_DABL_NOFETCH
+          if (slot == 11) fetch_planes(s + 1, 0);
+          if (slot == 23) fetch_planes(s + 1, 1);
+#endif
+        }
+        FT_SB;
+      }
+      FT_SPLIT_PRIO(0);
+      qc = qn;
+      __syncthreads();
+    }
+#undef FT_SB
+  } else {
     float csum = 0.f;
     const bool full = m0 + FT_ROWS <= M;
     if (full)
@@ -983,6 +1450,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N,
                              WAVES_M * WAVES_N == 8 ? 4 : 2) void dgrad_wgrad0_kernel(
     DgradWgrad0Params p) {
   dgrad_wgrad0_body<BN, WAVES_M, WAVES_N>(p, (int)blockIdx.x);
+}
+
+template <int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 4) void dgrad_wgrad0_split_kernel(
+    DgradWgrad0Params p) {
+  dgrad_wgrad0_body<BN, WAVES_M, WAVES_N, true>(p, (int)blockIdx.x);
 }
 
 struct DgradWgrad0Pair {
@@ -1178,6 +1651,45 @@ extern "C" int ga_set_pipelined_kloop(int on) {
   return 0;
 }
 
+extern "C" int ga_set_split_bf16(int on) {
+  g_split_bf16 = on != 0;
+  return 0;
+}
+
+// developer hook (tools/): a register-only MFMA loop on `stream`, mode 1 =
+// v_mfma_f32_32x32x16_bf16, 2 = v_mfma_f32_32x32x2_f32 -- a co-resident load with no
+// memory traffic at all
+namespace {
+__global__ __launch_bounds__(512, 4) void mfma_burn_kernel(int mode, int iters, float* sink) {
+  f32x16 acc[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+  ft_bf16x8 a8, b8;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { a8[i] = (__bf16)(0.01f * (threadIdx.x + i)); b8[i] = (__bf16)(0.02f * i); }
+  const float af = 0.01f * threadIdx.x, bf = 0.5f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      if (mode == 1)
+        acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, b8, acc[c], 0, 0, 0);
+      else
+        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[c], 0, 0, 0);
+    }
+  }
+  if (acc[0][0] + acc[1][0] == 12345.f) sink[0] = 1.f;
+}
+}  // namespace
+extern "C" int ga_debug_mfma_burn(int mode, int iters, int blocks, float* sink,
+                                  hipStream_t stream) {
+  hipLaunchKernelGGL(mfma_burn_kernel, dim3(blocks), dim3(512), 0, stream, mode, iters, sink);
+  return 0;
+}
+
+extern "C" int ga_split_bf16_enabled(void) { return split_bf16_on(4) ? 1 : 0; }
+
 extern "C" int ga_fused_width_ok(int width) {
   return width == 64 || width == 128 || width == 256;
 }
@@ -1317,7 +1829,13 @@ extern "C" int ga_fused_fwd_head_loss(const float* A, int64_t lda, const int32_t
   else if (first && width == 128)
     hipExtLaunchKernelGGL((fwd_head_loss_kernel<128, 1, 4, true>), grid, dim3(256), 0,
                           stream, e0, e1, 0, p);
-  else if (first && (first->in_w + 3) / 4 == 5 && pipelined_kloop_on())
+  else if (first && split_bf16_on(1) && K % 32 == 0 && first->in_w <= 20) {
+    p.bplanes = planes_for(W, ldw, width, K, PLANES_TRAIN_FWD, stream);
+    GA_REQUIRE(p.bplanes, "ga_fused_fwd_head_loss: no memory for the weight planes");
+    p.bplane_stride = (int64_t)width * K;
+    hipExtLaunchKernelGGL((fwd_head_loss_split_kernel<256, 1, 8>), grid, dim3(512), 0,
+                          stream, e0, e1, 0, p);
+  } else if (first && (first->in_w + 3) / 4 == 5 && pipelined_kloop_on())
     hipExtLaunchKernelGGL((fwd_head_loss_kernel<256, 1, 8, true, 5>), grid, dim3(512), 0,
                           stream, e0, e1, 0, p);
   else if (first)
@@ -1415,7 +1933,13 @@ extern "C" int ga_fused_eval_forward(const float* X, int64_t ldx, const int32_t*
   else if (width == 128)
     hipExtLaunchKernelGGL((mlp_eval_forward_kernel<128, 1, 4>), grid, dim3(256), 0, stream,
                           e0, e1, 0, p);
-  else if ((in_w + 3) / 4 == 5 && pipelined_kloop_on())
+  else if (split_bf16_on(8) && K % 32 == 0 && in_w <= 20) {
+    p.bplanes = planes_for(W2, p.g.ldb, width, K, PLANES_EVAL_FWD, stream);
+    GA_REQUIRE(p.bplanes, "ga_fused_eval_forward: no memory for the weight planes");
+    p.bplane_stride = (int64_t)width * K;
+    hipExtLaunchKernelGGL((mlp_eval_forward_split_kernel<256, 1, 8>), grid, dim3(512), 0,
+                          stream, e0, e1, 0, p);
+  } else if ((in_w + 3) / 4 == 5 && pipelined_kloop_on())
     hipExtLaunchKernelGGL((mlp_eval_forward_kernel<256, 1, 8, 5>), grid, dim3(512), 0,
                           stream, e0, e1, 0, p);
   else
@@ -1467,7 +1991,13 @@ extern "C" int ga_fused_dgrad_wgrad0(const float* dZ2, int64_t lddz, const float
   else if (width == 128)
     hipExtLaunchKernelGGL((dgrad_wgrad0_kernel<128, 1, 4>), grid, dim3(256), 0, stream,
                           e0, e1, 0, p);
-  else
+  else if (split_bf16_on(2) && K % 32 == 0) {
+    p.bplanes = planes_for(W2, ldw, K, width, PLANES_BWD, stream);
+    GA_REQUIRE(p.bplanes, "ga_fused_dgrad_wgrad0: no memory for the weight planes");
+    p.bplane_stride = (int64_t)width * K;
+    hipExtLaunchKernelGGL((dgrad_wgrad0_split_kernel<256, 1, 8>), grid, dim3(512), 0,
+                          stream, e0, e1, 0, p);
+  } else
     hipExtLaunchKernelGGL((dgrad_wgrad0_kernel<256, 1, 8>), grid, dim3(512), 0, stream,
                           e0, e1, 0, p);
   GA_CHECK_LAUNCH("dgrad_wgrad0");

@@ -304,6 +304,150 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_f32_pair_kernel(
     gemm_f32_body<BM, BN, WAVES_M, WAVES_N, A_KC, B_KC, BK, false>(pp.a, bid);
 }
 
+// ---- split-operand weight-gradient GEMM (opt-in, see ft_split3 in gemm_core.h):
+// C[m][n] = sum_k A(m, k) B(k, n) with BOTH operands row-contiguous in memory
+// (A(m, k) = A[k * lda + m]: k is the minibatch row).  v_mfma_f32_32x32x16_bf16 wants
+// 8 consecutive k per lane, so the loader pairs two consecutive rows: a thread loads
+// the same 16-B column quad of rows 2 t and 2 t + 1, splits the eight values and
+// writes, per plane, the four (row 2 t, row 2 t + 1) bf16 pairs as ONE 16-B LDS store
+// into [pair][column] dwords; a fragment is then four ds_read_b32 down the pairs.
+// 128 x 128 tiles, 8 waves (2 x 4, 64 x 32 each), 16 rows per step, operands fetched
+// three steps ahead (they come from HBM), double-buffered planes, one barrier per
+// step.  Interior shapes only (the host checks): M, N multiples of 128, no gathers.
+constexpr int NTS_LD = 136;                  // dwords per pair row: 128 + 8 (the two lane
+                                             // halves read rows 4 apart: 32 banks apart)
+constexpr int NTS_PLANE = 8 * NTS_LD;        // dwords per plane of a 16-row step
+constexpr int NTS_OPER = 3 * NTS_PLANE;      // hi, mid, lo
+constexpr int NTS_BUF = 2 * NTS_OPER;        // A and B
+
+__global__ __launch_bounds__(512, 4) void gemm_nt_split_kernel(GemmParams p) {
+  __shared__ __attribute__((aligned(16))) uint32_t lds[2 * NTS_BUF];
+  __shared__ __attribute__((aligned(16))) float cs_lds[8 * 128];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm0 = (wave / 4) * 64, wn0 = (wave % 4) * 32;
+  int bz, mem;
+  ga_xcd_group((int)blockIdx.x, p.gz, p.gx * p.gy, &bz, &mem);
+  const int bx = mem % p.gx, by = mem / p.gx;
+  const int m0 = bx * 128, n0 = by * 128;
+  const int kbeg = bz * p.k_per_split, kend = min(p.K, kbeg + p.k_per_split);
+  const int nk = (kend - kbeg + 15) / 16;
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  // loader: threads 0 .. 255 take A, 256 .. 511 take B; pair pi of the step, quad c4
+  const bool isb = tid >= 256;
+  const int lt = tid & 255, pi = lt >> 5, c4 = lt & 31;
+  const float* src = isb ? p.B + n0 + 4 * c4 : p.A + m0 + 4 * c4;
+  const int64_t ld = isb ? p.ldb : p.lda;
+  uint32_t* dst0 = lds + (isb ? NTS_OPER : 0) + pi * NTS_LD + 4 * c4;
+  float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto load2 = [&](int s, float4& v0, float4& v1) {
+    const int r0 = kbeg + 16 * s + 2 * pi;
+    v0 = *reinterpret_cast<const float4*>(src + (int64_t)min(r0, p.K - 1) * ld);
+    v1 = *reinterpret_cast<const float4*>(src + (int64_t)min(r0 + 1, p.K - 1) * ld);
+    if (r0 >= kend) v0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r0 + 1 >= kend) v1 = make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  auto store2 = [&](int s, const float4& v0, const float4& v1) {
+    const float a[4] = {v0.x, v0.y, v0.z, v0.w}, b[4] = {v1.x, v1.y, v1.z, v1.w};
+    uint32_t h[4], m[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      uint32_t ha, ma, la, hb, mb, lb;
+      ft_split3(a[j], ha, ma, la);
+      ft_split3(b[j], hb, mb, lb);
+      h[j] = ft_pack_hi16(ha, hb);
+      m[j] = ft_pack_hi16(ma, mb);
+      l[j] = ft_pack_hi16(la, lb);
+    }
+    uint32_t* d = dst0 + (s & 1) * NTS_BUF;
+    *reinterpret_cast<uint4*>(d) = make_uint4(h[0], h[1], h[2], h[3]);
+    *reinterpret_cast<uint4*>(d + NTS_PLANE) = make_uint4(m[0], m[1], m[2], m[3]);
+    *reinterpret_cast<uint4*>(d + 2 * NTS_PLANE) = make_uint4(l[0], l[1], l[2], l[3]);
+    if (!isb) {
+      csum.x += v0.x + v1.x; csum.y += v0.y + v1.y;
+      csum.z += v0.z + v1.z; csum.w += v0.w + v1.w;
+    }
+  };
+  // three steps in flight
+  float4 q0[3], q1[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    q0[d] = make_float4(0.f, 0.f, 0.f, 0.f);
+    q1[d] = q0[d];
+    if (d < nk) load2(d, q0[d], q1[d]);
+  }
+  if (nk > 0) store2(0, q0[0], q1[0]);
+  __syncthreads();
+
+  const int half = lane >> 5, l31 = lane & 31;
+  // fragment rows: pairs 4 half .. 4 half + 3 of the step
+  const uint32_t* fa = lds + 4 * half * NTS_LD + wm0 + l31;
+  const uint32_t* fb = lds + NTS_OPER + 4 * half * NTS_LD + wn0 + l31;
+  auto frag = [&](const uint32_t* base, int pl) {
+    ft_u32x4 v;
+    v[0] = base[pl * NTS_PLANE];
+    v[1] = base[pl * NTS_PLANE + NTS_LD];
+    v[2] = base[pl * NTS_PLANE + 2 * NTS_LD];
+    v[3] = base[pl * NTS_PLANE + 3 * NTS_LD];
+    return __builtin_bit_cast(ft_bf16x8, v);
+  };
+#pragma unroll 1
+  for (int s0 = 0; s0 < nk; s0 += 3) {
+    // (unrolled by the depth of the prefetch ring so that its registers are static)
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const int s = s0 + d;
+      if (s < nk) {
+        const uint32_t* ab = fa + (s & 1) * NTS_BUF;
+        const uint32_t* bb = fb + (s & 1) * NTS_BUF;
+        ft_bf16x8 a[2][3], b[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          a[0][pl] = frag(ab, pl);
+          a[1][pl] = frag(ab + 32, pl);
+          b[pl] = frag(bb, pl);
+        }
+        // the quads of step s + 1 are in registers since two steps ago: split them
+        // into the other buffer while this step's MFMAs run, then refill the slot
+        // with step s + 3
+        __builtin_amdgcn_s_setprio(1);
+        ft_mfma6(a[0], b, acc[0]);
+        ft_mfma6(a[1], b, acc[1]);
+        __builtin_amdgcn_s_setprio(0);
+        if (s + 1 < nk) store2(s + 1, q0[(d + 1) % 3], q1[(d + 1) % 3]);
+        if (s + 3 < nk) load2(s + 3, q0[d], q1[d]);
+        __syncthreads();
+      }
+    }
+  }
+
+  // ---- epilogue: the slab of this split; bias-gradient column sums of A
+  float* Cout = p.C + (int64_t)bz * p.c_split_stride;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
+      Cout[(int64_t)m * p.c_rs + (int64_t)(n0 + wn0 + l31) * p.c_cs] = acc[i][r];
+    }
+  if (p.colsum != nullptr && by == 0) {
+    if (!isb) *reinterpret_cast<float4*>(cs_lds + pi * 128 + 4 * c4) = csum;
+    __syncthreads();
+    if (tid < 128) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t += cs_lds[k * 128 + tid];
+      p.colsum[(int64_t)bz * p.colsum_split_stride + m0 + tid] = t;
+    }
+  }
+}
+
 static int g_small_m = 1;
 
 template <bool A_KC, bool B_KC>
@@ -352,6 +496,13 @@ int launch_gemm(const GemmParams& p_in, int splits, hipStream_t stream) {
     ga_prof_events(GA_PROF_GEMM_NT_128 + mode, flops, &e0, &e1);
     hipExtLaunchKernelGGL((gemm_f32_kernel<64, 64, 2, 2, A_KC, B_KC>), grid, dim3(256),
                           0, stream, e0, e1, 0, p);
+  } else if (!A_KC && !B_KC && ga_split_bf16_enabled() && p.M % 128 == 0 &&
+             p.N % 128 == 0 && !p.a_idx && !p.b_idx && p.epi == EPI_PLAIN && !p.accum &&
+             p.k_per_split % 16 == 0 && !p.colsum_of_b) {
+    p.gx = p.M / 128; p.gy = p.N / 128; p.gz = splits;
+    dim3 grid((unsigned)(p.gx * p.gy * p.gz));
+    ga_prof_events(GA_PROF_GEMM_NT_128 + mode, flops, &e0, &e1);
+    hipExtLaunchKernelGGL(gemm_nt_split_kernel, grid, dim3(512), 0, stream, e0, e1, 0, p);
   } else {
     p.gx = (int)ga_ceil_div(p.M, 128); p.gy = (int)ga_ceil_div(p.N, 128); p.gz = splits;
     dim3 grid((unsigned)(p.gx * p.gy * p.gz));

@@ -70,6 +70,45 @@ __device__ __forceinline__ float act_slope_fwd(float o, int act) {
   return act_slope(o, act == 0 ? 2 : (act == 1 ? 0 : (act == 2 ? 1 : act)));
 }
 
+// ---- split-operand k-loop (opt-in: ga_set_split_bf16 / GARAGE_AMD_SPLIT_BF16=1).
+// v_mfma_f32_32x32x2_f32 runs on the vector ALU's fp32 lanes (tools/mfma_valu_overlap:
+// every vector instruction beside it costs its full issue time, 64 cycles per
+// 32x32x2 on top); v_mfma_f32_32x32x16_bf16 is 16x the rate on the matrix unit proper
+// and vector work DOES issue beside it.  An fp32 value is split EXACTLY into three
+// bf16 terms x = hi + mid + lo (8 + 8 + 8 significant bits, each the truncation of
+// the remainder); a product a b is the six bf16 products a_i b_j with i + j <= 2
+// (the three dropped ones are below 2^-24 |a b|), accumulated in fp32 by the MFMA,
+// smallest terms first: 6 x 32 cycles for 16 k against 8 x 64 for exact fp32.
+typedef __bf16 ft_bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t ft_u32x4 __attribute__((ext_vector_type(4)));
+constexpr int FT_PLANE_ROW_B = 80;  // bytes per LDS plane row: 32 bf16 + 16 (conflict free)
+constexpr int FT_PLANE_B = 64 * FT_PLANE_ROW_B;  // 64-row tiles
+constexpr int FT_ABUF_B = 3 * FT_PLANE_B;  // hi, mid, lo of one 64 x 32 operand chunk
+
+// the bit patterns whose upper halves are the three terms of x
+__device__ __forceinline__ void ft_split3(float x, uint32_t& hi, uint32_t& mid,
+                                          uint32_t& lo) {
+  hi = __float_as_uint(x);
+  const float r1 = x - __uint_as_float(hi & 0xffff0000u);
+  mid = __float_as_uint(r1);
+  lo = __float_as_uint(r1 - __uint_as_float(mid & 0xffff0000u));
+}
+// (upper half of b) : (upper half of a) -- a is the lower k
+__device__ __forceinline__ uint32_t ft_pack_hi16(uint32_t a, uint32_t b) {
+  return __builtin_amdgcn_perm(b, a, 0x07060302u);
+}
+// the six products of one 32 x 32 x 16 block, small to large
+__device__ __forceinline__ void ft_mfma6(const ft_bf16x8 (&a)[3], const ft_bf16x8 (&b)[3],
+                                         f32x16& acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+}
+
+
 struct GemmParams {
   const float* A;
   int64_t lda;           // floats between consecutive memory lines of A

@@ -604,6 +604,13 @@ int ga_set_fused_first_layer(int on);
  * first layers of 17 .. 20 inputs at 256 units): 1 default, 0 the plain loop (also
  * GARAGE_AMD_PIPELINED_KLOOP=0).  Bit-identical results either way. */
 int ga_set_pipelined_kloop(int on);
+/* EXPERIMENT, off by default (also GARAGE_AMD_SPLIT_BF16=1): the k-loops of the fused
+ * update kernels that have such an instantiation (256-unit networks, first layer in
+ * the kernel) run on v_mfma_f32_32x32x16_bf16 with every fp32 operand split exactly
+ * into three bf16 terms and the six products i + j <= 2 accumulated in fp32
+ * (about 2^-22 relative error per product against 2^-24 of the exact fp32 MFMA).
+ * Results differ from the default in the last bits; the default stays exact fp32. */
+int ga_set_split_bf16(int on);
 /* The policy pass and the value-function pass of one epoch, minibatch by
  * minibatch alternately on two streams.  The reference runs them back to back
  * (vpg.py:244-248); they share no written state, so the results are identical
