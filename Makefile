@@ -39,10 +39,26 @@ mfma-peak: tools/mfma_peak.hip
 	@mkdir -p $(OUT)
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -Wno-unused-result $< -o $(OUT)/mfma_peak
 
-clean:
-	rm -rf $(OUT)/*.o $(OUT)/*.so $(OUT)/mfma_peak
+# developer tools: does vector work hide behind MFMAs (fp32: no, bf16: yes), and the
+# packed-fp32 / bf16-MFMA hazard reproducer
+mfma-tools: tools/mfma_valu_overlap.hip tools/mfma_valu_hazard.hip
+	@mkdir -p $(OUT)
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -Wno-unused-result -Wno-unused-value tools/mfma_valu_overlap.hip -o $(OUT)/mfma_valu_overlap
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -Wno-unused-result -Wno-unused-value tools/mfma_valu_hazard.hip -o $(OUT)/mfma_valu_hazard
 
-.PHONY: all clean mfma-peak
+# the library WITH hipcc's SLP vectorizer (packed fp32, the hazardous form included):
+# only for tools/hazard_repro_backward.py
+slp-variant:
+	@mkdir -p $(OUT)/variants/slp
+	for f in $(HIPS); do $(HIPCC) $(FLAGS) -fslp-vectorize -c $(CSRC)/$$f.hip -o $(OUT)/variants/slp/$$f.o || exit 1; done
+	for f in $(CPPS); do $(HIPCC) $(FLAGS) -fslp-vectorize -x hip -c $(CSRC)/$$f.cpp -o $(OUT)/variants/slp/$$f.o || exit 1; done
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(OUT)/variants/slp/*.o -ldl -o $(OUT)/variants/lib_slp.so
+	rm -rf $(OUT)/variants/slp
+
+clean:
+	rm -rf $(OUT)/*.o $(OUT)/*.so $(OUT)/mfma_peak $(OUT)/mfma_valu_overlap $(OUT)/mfma_valu_hazard $(OUT)/variants
+
+.PHONY: all clean mfma-peak mfma-tools slp-variant
 
 # Host-side epoch / rollout loops under AddressSanitizer + UBSan on the CPU, with
 # every kernel entry point replaced by a recording fake (tests/host/).

@@ -486,6 +486,9 @@ def main():
     ap.add_argument('--no-overlap', action='store_true',
                     help='run the policy and value-function passes one after '
                     'the other on one stream (isolated per-kernel timings)')
+    ap.add_argument('--no-split-variant', action='store_true',
+                    help='skip the extra timed steps with the opt-in split-operand '
+                    '(3 x bf16) k-loops that fill value_split_bf16')
     args = ap.parse_args()
 
     if args.config in SCAN_CONFIGS:
@@ -569,6 +572,41 @@ def main():
         if not args.no_overlap:
             algo.overlap_updates = True
             rows_ovl = roofline_pass(algo, sampler, pol, S, itr)
+    # The opt-in experiment (include/garage_amd.h: ga_set_split_bf16), reported under
+    # its own keys: the SAME iteration with the k-loops of the update kernels on
+    # v_mfma_f32_32x32x16_bf16 (every fp32 operand as three bf16 terms, six products,
+    # fp32 accumulation).  The headline `value` above is exact fp32 and stays so.
+    split = None
+    if (args.config == 'c3' and args.algo == 'ppo' and not args.no_split_variant
+            and not os.environ.get('GARAGE_AMD_SPLIT_BF16')):
+        from garage_amd import _lib
+        lib = _lib.load()
+        lib.ga_set_split_bf16(1)
+        try:
+            # (a second engine: the number of split-K slabs is chosen when the
+            # workspaces are built, and differs with the faster kernel)
+            algo, sampler, pol, S = build_engine(cfg, comm, algo_name=args.algo)
+            algo.fuse_head = bool(args.fuse_head)
+            algo.overlap_updates = not args.no_overlap
+            one_iteration(algo, sampler, pol, S, itr)
+            itr += 1
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                one_iteration(algo, sampler, pol, S, itr)
+                itr += 1
+            sync()
+            el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64,
+                              device='cuda')
+            if comm is not None:
+                comm.all_reduce(el, 'max')
+            split = {'elapsed': float(el.item()), 'rows': None}
+            if not args.no_roofline:
+                algo.overlap_updates = False
+                split['rows'] = roofline_pass(algo, sampler, pol, S, itr)
+                itr += 1
+        finally:
+            lib.ga_set_split_bf16(0)
     if rank != 0:
         return
     ms_per_step = elapsed / args.steps * 1e3
@@ -700,6 +738,25 @@ def main():
                         'Cache): inputs from HBM, outputs to HBM'.format(
                             sets, sets * nb4 / 1e6),
             }
+    if os.environ.get('GARAGE_AMD_SPLIT_BF16') == '1':
+        line['dtype'] = ('f32 in memory; update-kernel operands as 3 x bf16 (split), '
+                         'fp32 accumulate (GARAGE_AMD_SPLIT_BF16=1: opt-in experiment)')
+    if split is not None:
+        line['value_split_bf16'] = S * world * args.steps / split['elapsed']
+        line['ms_per_step_split_bf16'] = split['elapsed'] / args.steps * 1e3
+        line['dtype_split_bf16'] = (
+            'f32 in memory; operands of the three update kernels (and of the '
+            'evaluation forward) split into 3 bf16 terms each, 6 products on '
+            'v_mfma_f32_32x32x16_bf16, fp32 accumulation -- opt-in experiment '
+            '(ga_set_split_bf16), gradients as close to fp64 as the exact kernels\' '
+            '(profiles/r03_split_error_histogram.json); `value` is exact fp32')
+        if split['rows'] is not None:
+            line['kernels_split_bf16'] = [
+                dict(kernel=r['kernel'], launches=r['launches'],
+                     total_ms=round(r['total_ms'], 3),
+                     avg_us=round(r['total_ms'] * 1e3 / max(1, r['launches']), 2))
+                for r in split['rows'] if r['launches'] > 0
+            ]
     if args.cpu_envs > 0 and world == 1 and args.algo == 'ppo':
         line['cpu_baseline'] = cpu_baseline(cfg, min(args.cpu_envs,
                                                      cfg['n_envs']))

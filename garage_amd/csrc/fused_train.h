@@ -114,5 +114,6 @@ int ga_reduce_regions_adam(const ga_fused_region* regions, int n_regions, float*
                            hipStream_t stream);
 /* 1 while the opt-in split-operand (3 x bf16) k-loops are selected
  * (ga_set_split_bf16 / GARAGE_AMD_SPLIT_BF16=1). */
-int ga_split_bf16_enabled(void);
+int ga_split_bf16_enabled(void); /* ... for the weight-gradient GEMM */
+int ga_split_bf16_any(void);     /* ... for any kernel */
 }

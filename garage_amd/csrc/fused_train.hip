@@ -326,20 +326,16 @@ __device__ __forceinline__ void fwd_head_loss_body(const FwdLossParams& p,
         const float4 bq = *reinterpret_cast<const float4*>(b1s + 32 * c + 16 * ct + 4 * g4);
         const float bb[4] = {bq.x, bq.y, bq.z, bq.w};
         float hv[4];
-        uint32_t hi[4], mid[4], lo[4];
+        uint32_t hi[2], mid[2], lo[2];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          hv[r] = tanh_fast(e4[r] + o4[r] + bb[r]);
-          ft_split3(hv[r], hi[r], mid[r], lo[r]);
-        }
+        for (int r = 0; r < 4; ++r) hv[r] = tanh_fast(e4[r] + o4[r] + bb[r]);
+        ft_split3_pair(hv[0], hv[1], hi[0], mid[0], lo[0]);
+        ft_split3_pair(hv[2], hv[3], hi[1], mid[1], lo[1]);
         char* dst = apl + (c & 1) * FT_ABUF_B + (16 * rt + r16) * FT_PLANE_ROW_B +
                     (16 * ct + 4 * g4) * 2;
-        *reinterpret_cast<uint2*>(dst) =
-            make_uint2(ft_pack_hi16(hi[0], hi[1]), ft_pack_hi16(hi[2], hi[3]));
-        *reinterpret_cast<uint2*>(dst + FT_PLANE_B) =
-            make_uint2(ft_pack_hi16(mid[0], mid[1]), ft_pack_hi16(mid[2], mid[3]));
-        *reinterpret_cast<uint2*>(dst + 2 * FT_PLANE_B) =
-            make_uint2(ft_pack_hi16(lo[0], lo[1]), ft_pack_hi16(lo[2], lo[3]));
+        *reinterpret_cast<uint2*>(dst) = make_uint2(hi[0], hi[1]);
+        *reinterpret_cast<uint2*>(dst + FT_PLANE_B) = make_uint2(mid[0], mid[1]);
+        *reinterpret_cast<uint2*>(dst + 2 * FT_PLANE_B) = make_uint2(lo[0], lo[1]);
         if constexpr (!EVAL) {
           if (h1_ok)
             *reinterpret_cast<float4*>(h1_row + 32 * c) =
@@ -418,7 +414,7 @@ __device__ __forceinline__ void fwd_head_loss_body(const FwdLossParams& p,
         // ga_tanh (common.h) in four stages over the four values: the same operations
         // in the same order per value, a stage's four chains independent of each other
         float tc[4], ex[4], dn[4], rc[4], hv[4];
-        uint32_t hi[4], mid[4], lo[4];
+        uint32_t hi[2], mid[2], lo[2];
         auto side = [&](int t) {
           if constexpr (MORE) {
             if (t == 1) {
@@ -444,20 +440,15 @@ __device__ __forceinline__ void fwd_head_loss_body(const FwdLossParams& p,
                 hv[r] = fmaf(-2.f, rr, 1.f);
               }
             } else if (t == 9) {
-              ft_split3(hv[0], hi[0], mid[0], lo[0]);
-              ft_split3(hv[1], hi[1], mid[1], lo[1]);
+              ft_split3_pair(hv[0], hv[1], hi[0], mid[0], lo[0]);
             } else if (t == 10) {
-              ft_split3(hv[2], hi[2], mid[2], lo[2]);
-              ft_split3(hv[3], hi[3], mid[3], lo[3]);
+              ft_split3_pair(hv[2], hv[3], hi[1], mid[1], lo[1]);
             } else if (t == 12) {
               char* dst = apl + ((s + 1) & 1) * FT_ABUF_B + (16 * rt + r16) * FT_PLANE_ROW_B +
                           (16 * ct + 4 * g4) * 2;
-              *reinterpret_cast<uint2*>(dst) =
-                  make_uint2(ft_pack_hi16(hi[0], hi[1]), ft_pack_hi16(hi[2], hi[3]));
-              *reinterpret_cast<uint2*>(dst + FT_PLANE_B) =
-                  make_uint2(ft_pack_hi16(mid[0], mid[1]), ft_pack_hi16(mid[2], mid[3]));
-              *reinterpret_cast<uint2*>(dst + 2 * FT_PLANE_B) =
-                  make_uint2(ft_pack_hi16(lo[0], lo[1]), ft_pack_hi16(lo[2], lo[3]));
+              *reinterpret_cast<uint2*>(dst) = make_uint2(hi[0], hi[1]);
+              *reinterpret_cast<uint2*>(dst + FT_PLANE_B) = make_uint2(mid[0], mid[1]);
+              *reinterpret_cast<uint2*>(dst + 2 * FT_PLANE_B) = make_uint2(lo[0], lo[1]);
             } else if (t == 13) {
               if constexpr (!EVAL) {
                 if (h1_ok)
@@ -929,15 +920,18 @@ __device__ __forceinline__ void fwd_head_loss_body(const FwdLossParams& p,
   // workgroup of the single generation reaching them within a microsecond of the
   // others) spread over twice the window, and the two workgroups of a CU do not
   // contend for the same unit at the same time
-  auto phase_dz = [&]() {
+  // E5 / E6 take only the head rows that exist (j < A; JN = 1, 4 or 8 compiled): rows
+  // of W_head and entries of dout beyond A are zero and add nothing -- the value
+  // function's head has ONE row, 7 of 8 products were multiplications by zero
+  auto phase_dz = [&](auto jn_tag) {
   // ---- E5: dZ = (dout W_head) (1 - H^2) -> global (the only [M x BN] store).  A
   //      thread's column quad is the same for all its rows: its W_head values are
-  //      read once; rows of W_head and entries of dout beyond A are zero, so all HN
-  //      terms are taken without a branch (and without a wait inside one)
+  //      read once
+  constexpr int JN = decltype(jn_tag)::value;
   static_assert(NT % (BN / 4) == 0, "one column quad per thread");
-  float4 w8[HN];
+  float4 w8[JN];
 #pragma unroll
-  for (int j = 0; j < HN; ++j)
+  for (int j = 0; j < JN; ++j)
     w8[j] = *reinterpret_cast<const float4*>(aux + j * BN + 4 * (tid % (BN / 4)));
 #pragma unroll
   for (int q = 0; q < FT_ROWS * (BN / 4) / NT; ++q) {
@@ -945,11 +939,12 @@ __device__ __forceinline__ void fwd_head_loss_body(const FwdLossParams& p,
     const int rr = e / (BN / 4), c4 = e % (BN / 4);
     const float4 h = *reinterpret_cast<const float4*>(stage + rr * LDC + 4 * c4);
     const float4 d0 = *reinterpret_cast<const float4*>(doutl + rr * HN);
-    const float4 d1 = *reinterpret_cast<const float4*>(doutl + rr * HN + 4);
+    float4 d1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (JN > 4) d1 = *reinterpret_cast<const float4*>(doutl + rr * HN + 4);
     const float dd[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
     float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int j = 0; j < HN; ++j) {
+    for (int j = 0; j < JN; ++j) {
       z.x = fmaf(dd[j], w8[j].x, z.x); z.y = fmaf(dd[j], w8[j].y, z.y);
       z.z = fmaf(dd[j], w8[j].z, z.z); z.w = fmaf(dd[j], w8[j].w, z.w);
     }
@@ -959,19 +954,25 @@ __device__ __forceinline__ void fwd_head_loss_body(const FwdLossParams& p,
       *reinterpret_cast<float4*>(p.dZ + (int64_t)(m0 + rr) * p.lddz + 4 * c4) = z;
   }
   };
-  auto phase_head_grad = [&]() {
+  auto phase_head_grad = [&](auto jn_tag) {
   // ---- E6: this workgroup's share of dW_head[j][c] = sum_r dout[r][j] H[r][c]
   //      (rows beyond M carry dout = 0) and of db_head
   {
+    constexpr int JN = decltype(jn_tag)::value;
     constexpr int GROUPS = NT / BN, JPG = HN / GROUPS;
     const int c = tid % BN, j0 = (tid / BN) * JPG;
     float g[JPG];
 #pragma unroll
     for (int jj = 0; jj < JPG; ++jj) g[jj] = 0.f;
-    for (int r = 0; r < FT_ROWS; ++r) {
-      const float h = stage[r * LDC + c];
+    // (j0 is wave-uniform: a whole wave skips the rows its group does not have; within
+    // a group `jj < JN` may keep a zero row or two -- they add exact zeros)
+    if (j0 < JN) {
+      for (int r = 0; r < FT_ROWS; ++r) {
+        const float h = stage[r * LDC + c];
 #pragma unroll
-      for (int jj = 0; jj < JPG; ++jj) g[jj] = fmaf(doutl[r * HN + j0 + jj], h, g[jj]);
+        for (int jj = 0; jj < JPG; ++jj)
+          if (jj < JN) g[jj] = fmaf(doutl[r * HN + j0 + jj], h, g[jj]);
+      }
     }
     float* hp = p.hpart + (int64_t)ft_tile * (HN * BN + HN);
 #pragma unroll
@@ -983,15 +984,23 @@ __device__ __forceinline__ void fwd_head_loss_body(const FwdLossParams& p,
     }
   }
   };
-  if (ft_tile >= (ft_tiles + 1) / 2) {
-    phase_head_grad();
-    FT_STAMP(7);
-    phase_dz();
-  } else {
-    phase_dz();
-    FT_STAMP(7);
-    phase_head_grad();
-  }
+  auto two_phases = [&](auto jn_tag) {
+    if (ft_tile >= (ft_tiles + 1) / 2) {
+      phase_head_grad(jn_tag);
+      FT_STAMP(7);
+      phase_dz(jn_tag);
+    } else {
+      phase_dz(jn_tag);
+      FT_STAMP(7);
+      phase_head_grad(jn_tag);
+    }
+  };
+  if (L.A == 1)
+    two_phases(std::integral_constant<int, 1>{});
+  else if (L.A <= 4)
+    two_phases(std::integral_constant<int, 4>{});
+  else
+    two_phases(std::integral_constant<int, 8>{});
   FT_STAMP(8);
   FT_MARK(2);
 }
@@ -1058,29 +1067,32 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 4) void mlp_eval_forward_sp
 template <bool BWD_ONLY>
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ W,
                                                            int64_t ld, int rows, int cols,
-                                                           uint16_t* __restrict__ fwd,
-                                                           uint16_t* __restrict__ bwd) {
-  const int64_t total = (int64_t)rows * cols;
-  const int64_t half_blocks = (total + 255) / 256;
+                                                           uint32_t* __restrict__ fwd,
+                                                           uint32_t* __restrict__ bwd) {
+  // one thread per PAIR of consecutive k (one dword of every plane)
+  const int64_t pairs = (int64_t)rows * cols / 2;
+  const int64_t half_blocks = (pairs + 255) / 256;
   const bool T = BWD_ONLY || (int64_t)blockIdx.x >= half_blocks;
   const int64_t e =
       ((int64_t)blockIdx.x - ((T && !BWD_ONLY) ? half_blocks : 0)) * 256 + threadIdx.x;
-  if (e >= total) return;
+  if (e >= pairs) return;
   const int N = T ? cols : rows;
   // e enumerates the OUTPUT order (contiguous writes; the reads of bwd are strided:
   // 64 K elements, nothing to optimise)
-  const int kk = (int)(e & 7);
-  const int l = (int)((e >> 3) & 63);
-  const int64_t blk = e >> 9;
+  const int kk = 2 * (int)(e & 3);
+  const int l = (int)((e >> 2) & 63);
+  const int64_t blk = e >> 8;
   const int nb = (int)(blk % (N / 32)), kg = (int)(blk / (N / 32));
   const int n = 32 * nb + (l & 31);
   const int k = 16 * kg + 8 * (l >> 5) + kk;
+  const float x0 = T ? W[(int64_t)k * ld + n] : W[(int64_t)n * ld + k];
+  const float x1 = T ? W[(int64_t)(k + 1) * ld + n] : W[(int64_t)n * ld + k + 1];
   uint32_t hi, mid, lo;
-  ft_split3(T ? W[(int64_t)k * ld + n] : W[(int64_t)n * ld + k], hi, mid, lo);
-  uint16_t* out = T ? bwd : fwd;
-  out[e] = (uint16_t)(hi >> 16);
-  out[total + e] = (uint16_t)(mid >> 16);
-  out[2 * total + e] = (uint16_t)(lo >> 16);
+  ft_split3_pair(x0, x1, hi, mid, lo);
+  uint32_t* out = T ? bwd : fwd;
+  out[e] = hi;
+  out[pairs + e] = mid;
+  out[2 * pairs + e] = lo;
 }
 
 // The pipelined k-loop is compiled for first layers of 17 .. 20 inputs (KSC = 5: the
@@ -1161,16 +1173,18 @@ const uint16_t* planes_for(const float* W, int64_t ld, int rows, int cols, int m
     fwd = pb->fwd;
     bwd = pb->bwd;
   }
-  const unsigned blocks = (unsigned)(((int64_t)rows * cols + 255) / 256);
+  const unsigned blocks = (unsigned)(((int64_t)rows * cols / 2 + 255) / 256);
+  uint32_t* fwd32 = reinterpret_cast<uint32_t*>(fwd);
+  uint32_t* bwd32 = reinterpret_cast<uint32_t*>(bwd);
   if (mode == PLANES_BWD) {
     if (!reuse)
       hipLaunchKernelGGL(split_planes_kernel<true>, dim3(blocks), dim3(256), 0, stream, W,
-                         ld, rows, cols, fwd, bwd);
+                         ld, rows, cols, fwd32, bwd32);
     return bwd;
   }
   hipLaunchKernelGGL(split_planes_kernel<false>,
                      dim3(mode == PLANES_TRAIN_FWD ? 2 * blocks : blocks), dim3(256), 0,
-                     stream, W, ld, rows, cols, fwd, bwd);
+                     stream, W, ld, rows, cols, fwd32, bwd32);
   return fwd;
 }
 
@@ -1262,18 +1276,13 @@ __device__ __forceinline__ void dgrad_wgrad0_body(const DgradWgrad0Params& p,
     auto load_quad = [&](int s) { return *reinterpret_cast<const float4*>(arow_g + 32 * s); };
     auto store_quad = [&](int s, float4 v) {
       if (!row_ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-      uint32_t hi[4], mid[4], lo[4];
-      ft_split3(v.x, hi[0], mid[0], lo[0]);
-      ft_split3(v.y, hi[1], mid[1], lo[1]);
-      ft_split3(v.z, hi[2], mid[2], lo[2]);
-      ft_split3(v.w, hi[3], mid[3], lo[3]);
+      uint32_t hi[2], mid[2], lo[2];
+      ft_split3_pair(v.x, v.y, hi[0], mid[0], lo[0]);
+      ft_split3_pair(v.z, v.w, hi[1], mid[1], lo[1]);
       char* dst = apl + (s & 1) * FT_ABUF_B + qrow * FT_PLANE_ROW_B + qq * 8;
-      *reinterpret_cast<uint2*>(dst) =
-          make_uint2(ft_pack_hi16(hi[0], hi[1]), ft_pack_hi16(hi[2], hi[3]));
-      *reinterpret_cast<uint2*>(dst + FT_PLANE_B) =
-          make_uint2(ft_pack_hi16(mid[0], mid[1]), ft_pack_hi16(mid[2], mid[3]));
-      *reinterpret_cast<uint2*>(dst + 2 * FT_PLANE_B) =
-          make_uint2(ft_pack_hi16(lo[0], lo[1]), ft_pack_hi16(lo[2], lo[3]));
+      *reinterpret_cast<uint2*>(dst) = make_uint2(hi[0], hi[1]);
+      *reinterpret_cast<uint2*>(dst + FT_PLANE_B) = make_uint2(mid[0], mid[1]);
+      *reinterpret_cast<uint2*>(dst + 2 * FT_PLANE_B) = make_uint2(lo[0], lo[1]);
     };
     const uint16_t* wpl = p.bplanes + ((wn0 / 32) * 64 + lane) * 8;
     ft_u32x4 bw[2][3];
@@ -1689,6 +1698,7 @@ extern "C" int ga_debug_mfma_burn(int mode, int iters, int blocks, float* sink,
 }
 
 extern "C" int ga_split_bf16_enabled(void) { return split_bf16_on(4) ? 1 : 0; }
+extern "C" int ga_split_bf16_any(void) { return split_bf16_on() ? 1 : 0; }
 
 extern "C" int ga_fused_width_ok(int width) {
   return width == 64 || width == 128 || width == 256;

@@ -357,14 +357,7 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_split_kernel(GemmParams p) {
     const float a[4] = {v0.x, v0.y, v0.z, v0.w}, b[4] = {v1.x, v1.y, v1.z, v1.w};
     uint32_t h[4], m[4], l[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      uint32_t ha, ma, la, hb, mb, lb;
-      ft_split3(a[j], ha, ma, la);
-      ft_split3(b[j], hb, mb, lb);
-      h[j] = ft_pack_hi16(ha, hb);
-      m[j] = ft_pack_hi16(ma, mb);
-      l[j] = ft_pack_hi16(la, lb);
-    }
+    for (int j = 0; j < 4; ++j) ft_split3_pair(a[j], b[j], h[j], m[j], l[j]);
     uint32_t* d = dst0 + (s & 1) * NTS_BUF;
     *reinterpret_cast<uint4*>(d) = make_uint4(h[0], h[1], h[2], h[3]);
     *reinterpret_cast<uint4*>(d + NTS_PLANE) = make_uint4(m[0], m[1], m[2], m[3]);
@@ -794,12 +787,17 @@ extern "C" int64_t ga_mlp_backward_splits(const ga_mlp_desc* d, int64_t M) {
     const int64_t t = ga_ceil_div(d->dims[l + 1], 128) * ga_ceil_div(d->dims[l], 128);
     tiles = t > tiles ? t : tiles;
   }
-  static int64_t target = -1;  // workgroups of the widest layer's weight gradient
-  if (target < 0) {
+  static int64_t target_env = -1;  // workgroups of the widest layer's weight gradient
+  if (target_env < 0) {
     const char* e = getenv("GARAGE_AMD_WGRAD_WORKGROUPS");  // developer sweep
-    target = e ? atoll(e) : 1024;
-    if (target < 1) target = 1024;
+    target_env = e ? atoll(e) : 0;
+    if (target_env < 1) target_env = 0;
   }
+  // (the split-operand weight-gradient kernel is three times faster per row: half the
+  // workgroups and half the slabs -- 64 splits at C3 -- are the better trade there,
+  // measured 82.3 -> 79.8 ms per iteration; an engine keeps the split count it was
+  // built with)
+  const int64_t target = target_env ? target_env : (ga_split_bf16_enabled() ? 256 : 1024);
   const int64_t by_tiles = ga_ceil_div(target, tiles);
   if (!small && s > by_tiles) s = by_tiles;
   if (s < 1) s = 1;

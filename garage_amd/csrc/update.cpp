@@ -754,7 +754,9 @@ extern "C" int ga_update_epoch_pair(const ga_update_args* a, ga_stream_t stream_
     return -1;
   }
   const int64_t na = n_minibatches(a), nb = n_minibatches(b);
-  if (merged_pair_on() && na == nb) {
+  // (the pair kernels have no split-operand instantiation: with that experiment on the
+  // two-stream schedule runs, so that one switch decides the arithmetic of every step)
+  if (merged_pair_on() && na == nb && !ga_split_bf16_any()) {
     bool all = true;
     for (int64_t k = 0; k < na && all; ++k) all = merged_ok(a, b, k);
     if (all) {

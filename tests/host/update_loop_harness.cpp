@@ -233,6 +233,7 @@ int ga_reduce_regions_adam(const ga_fused_region* r, int n, float*, float*, floa
   return 0;
 }
 // ---- pair launches (two networks per grid): the fakes write the same extents
+int ga_split_bf16_any(void) { return 0; }
 int ga_fused_pair_supported(int width, int K, int in_w) {
   return width == 256 && K <= 256 && ga_fused_first_layer_ok(in_w, K);
 }

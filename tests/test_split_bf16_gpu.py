@@ -1,0 +1,173 @@
+"""The opt-in split-operand k-loops (``ga_set_split_bf16`` / GARAGE_AMD_SPLIT_BF16=1,
+include/garage_amd.h): the fused forward + loss, data-gradient, weight-gradient and
+evaluation-forward kernels of 256-unit networks on ``v_mfma_f32_32x32x16_bf16`` with
+every fp32 operand as three bf16 terms.  The default stays exact fp32; these tests hold
+the experiment to the SAME parity bars as the exact kernels (oracle iteration at 1e-6
+with linear Adam, bitwise two-stream schedules) and to the fp64 error of the exact
+kernels."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def split_mode():
+    from garage_amd import _lib
+    lib = _lib.load()
+    lib.ga_set_split_bf16(1)
+    try:
+        yield lib
+    finally:
+        lib.ga_set_split_bf16(0)
+
+
+def test_split_results_are_close_to_exact_but_not_the_same_bits():
+    """One iteration (2 epochs x several minibatches) at the C3 network shape: the
+    split kernels are actually taken (the bits differ) and the scalars agree to
+    rounding."""
+    from garage_amd import _lib
+    import test_fused_train_gpu as T
+    lib = _lib.load()
+    spec, batch = T._problem('c3_shape')
+    res = []
+    try:
+        for on in (0, 1):
+            lib.ga_set_split_bf16(on)
+            # Adam with beta1 = beta2 = 0, eps = 1: the update is linear in small
+            # gradients, so the parameters expose the gradients of every step
+            algo, pol, vf = T._algo('c3_shape', spec,
+                                    (torch.optim.Adam, dict(lr=1e-2, betas=(0.0, 0.0),
+                                                            eps=1.0)), epochs=2)
+            np.random.seed(11)
+            algo._train_once(0, batch)
+            res.append((pol.net.params.clone(), vf.net.params.clone(),
+                        dict(algo.last_tabular)))
+    finally:
+        lib.ga_set_split_bf16(0)
+    for i in (0, 1):
+        assert not torch.equal(res[0][i], res[1][i])
+        assert float((res[0][i] - res[1][i]).abs().max()) < 1e-6
+    for k, v in res[0][2].items():
+        assert np.isclose(res[1][2][k], v, rtol=2e-6, atol=2e-7), (k, v, res[1][2][k])
+
+
+def test_split_c3_iteration_matches_the_oracle_at_the_exact_kernels_bar(split_mode):
+    """``tests/test_configs_gpu.py``'s linear-Adam C3 iteration against the oracle, at
+    its unchanged 1e-6 bound, with the split kernels."""
+    import test_configs_gpu as TC
+    TC._oracle_iterations('c3', 16, 2, 16 * 256 // 4, 1, 1e-6, linear_adam=True)
+
+
+def test_split_gradient_error_against_fp64_is_the_exact_kernels(split_mode):
+    """Gradients of one optimizer step over 4096 rows against the oracle's loss in
+    float64 (autograd).  Weight matrices: the split kernels' rms error is within 1.5x
+    the exact kernels' (+ 1e-8 of the tensor's largest gradient); every tensor: no
+    element further than 2e-6 of the tensor's largest gradient from fp64 (the exact
+    kernels: 1e-6).  (Bias gradients are 256-element column sums: theirs scatter between
+    0.6x and 4x the exact kernels' error, profiles/r03_split_error_histogram.json.)"""
+    import bench
+    import test_configs_gpu as TC
+    from oracle import networks as nets
+    from oracle.ppo import OraclePPO
+    lib = split_mode
+    cfg = bench.CONFIGS['c3']
+    n, T = 16, cfg['T']
+    S = n * T
+    got, ref = {}, None
+    for mode in ('exact', 'split'):
+        lib.ga_set_split_bf16(1 if mode == 'split' else 0)
+        algo, sampler, pol, vf = TC._build(cfg, n, 1, S)
+        sd_p, sd_v = pol.state_dict(), vf.state_dict()
+        eps = sampler.obtain_samples(0, S, None)
+        np.random.seed(40)
+        algo._train_once(0, eps)
+        g = {}
+        for name, mod in (('policy', pol), ('vf', vf)):
+            for key, view in mod.net.named_views(mod.net.grads):
+                g[name + '/' + key] = view.detach().cpu().double().clone()
+        got[mode] = g
+        if ref is None:
+            adv = algo.last_tensors['advantages'].cpu().double()
+            ret = algo.last_tensors['returns'].cpu().double()
+            obs = torch.from_numpy(np.asarray(eps.observations)).double()
+            act = torch.from_numpy(np.asarray(eps.actions)).double()
+            o = OraclePPO({k: v.double() for k, v in sd_p.items()},
+                          {k: v.double() for k, v in sd_v.items()},
+                          max_episode_length=T, max_optimization_epochs=1,
+                          minibatch_size=S)
+            o._policy_loss(obs, act, adv).backward()
+            nets.value_loss(o.value, obs, ret).backward()
+            ref = {}
+            for name, params, mod in (('policy', o.policy, pol), ('vf', o.value, vf)):
+                for key, _ in mod.net.named_views():
+                    full = [k for k in params
+                            if k.endswith('init_std' if key == '_init_std' else key)]
+                    grad = params[full[0]].grad
+                    if grad is not None:
+                        ref[name + '/' + key] = grad.clone()
+    checked = 0
+    for key, r in ref.items():
+        scale = float(r.abs().max())
+        if scale == 0.0 or r.numel() < 64:
+            continue
+        e = {m: float(((got[m][key] - r) ** 2).mean().sqrt()) / scale
+             for m in ('exact', 'split')}
+        worst = {m: float((got[m][key] - r).abs().max()) / scale
+                 for m in ('exact', 'split')}
+        if r.numel() >= 1024:
+            assert e['split'] <= 1.5 * e['exact'] + 1e-8, (key, e)
+        assert worst['exact'] <= 1e-6 and worst['split'] <= 2e-6, (key, worst)
+        checked += 1
+    assert checked >= 8
+
+
+def test_split_trpo_two_stream_schedule_equals_serial_bitwise(split_mode):
+    """The value function's split kernels on the side stream next to the policy step's
+    exact kernels: same bits as one after the other.  (Before the library was built
+    without packed fp32 this failed: ``v_pk_fma_f32 ... op_sel:[0,1,0]`` in the policy's
+    first-layer weight-gradient kernel misread an operand whenever a bf16 MFMA ran on
+    the same SIMD -- tools/mfma_valu_hazard.hip.)"""
+    import bench
+    cfg = bench.CONFIGS['c3']
+    algo, sampler, pol, S = bench.build_engine(cfg, None, seed=2, algo_name='trpo')
+    vf = algo._value_function
+    eps = sampler.obtain_samples(0, S, None)
+    s0 = (pol.net.params.clone(), vf.net.params.clone(), vf.net.exp_avg.clone(),
+          vf.net.exp_avg_sq.clone(), vf.net.adam_steps, algo._vf_optimizer._draws,
+          algo._old_policy.params.clone())
+    results = []
+    for overlap in (True, False, True):
+        pol.net.params.copy_(s0[0])
+        vf.net.params.copy_(s0[1])
+        vf.net.exp_avg.copy_(s0[2])
+        vf.net.exp_avg_sq.copy_(s0[3])
+        vf.net.adam_steps = s0[4]
+        algo._vf_optimizer._draws = s0[5]
+        algo._old_policy.params.copy_(s0[6])
+        algo.overlap_updates = overlap
+        algo._train_once(0, eps)
+        torch.cuda.synchronize()
+        results.append((pol.net.params.clone(), vf.net.params.clone()))
+    for got in results[1:]:
+        assert torch.equal(got[0], results[0][0])
+        assert torch.equal(got[1], results[0][1])
+
+
+def test_split_evaluation_forward_matches_the_exact_one(split_mode):
+    from garage_amd.engine import FlatMLP
+    lib = split_mode
+    dev = torch.device('cuda')
+    torch.manual_seed(5)
+    net = FlatMLP(17, 6, (256, 256), dev)
+    net.params.copy_(0.05 * torch.randn(net.params.numel(), device=dev))
+    M = 70000  # ragged last tile, above the outputs-only threshold
+    X = torch.randn(M, 20, device=dev)
+    X[:, 17:] = 0
+    lib.ga_set_split_bf16(0)
+    want = net.forward(X, M, keep_acts=False)[:, :6].clone()
+    lib.ga_set_split_bf16(1)
+    got = net.forward(X, M, keep_acts=False)[:, :6].clone()
+    assert not torch.equal(got, want)
+    assert float((got - want).abs().max()) < 2e-6 * max(1.0, float(want.abs().max()))

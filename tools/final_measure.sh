@@ -21,10 +21,20 @@ python bench.py --config c3mb64 --steps 3 --warmup 1 > $OUT/c3mb64.log 2>&1
 python bench.py --algo trpo > $OUT/trpo.log 2>&1
 python bench.py --config c3scan > $OUT/c3scan.log 2>&1
 python bench.py --config c4scan > $OUT/c4scan.log 2>&1
+# the opt-in split-operand experiment: whole runs in that mode, its error against fp64,
+# the two microbenchmarks behind it and the hazard seen from the library
+GARAGE_AMD_SPLIT_BF16=1 python bench.py --cpu-envs 0 --no-scan-c4 > $OUT/c3_split.log 2>&1
+GARAGE_AMD_SPLIT_BF16=1 python bench.py --no-overlap --cpu-envs 0 --no-scan-c4 > $OUT/c3_split_serial.log 2>&1
+python tools/split_error_histogram.py > $OUT/split_error_histogram.json 2> $OUT/split_error_histogram.err
+garage_amd/_C/mfma_valu_overlap > $OUT/mfma_valu_overlap.txt 2>&1
+garage_amd/_C/mfma_valu_hazard > $OUT/mfma_valu_hazard.txt 2>&1
+python tools/hazard_repro_backward.py > $OUT/hazard_repro_backward_default_build.txt 2>&1
+GA_VARIANT_LIB=garage_amd/_C/variants/lib_slp.so python tools/hazard_repro_backward.py > $OUT/hazard_repro_backward_slp_build.txt 2>&1
 echo benches done
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof_no -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-envs 0 --no-overlap > $R/$OUT/prof_no.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof_ov -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-envs 0 > $R/$OUT/prof_ov.log 2>&1
+GARAGE_AMD_SPLIT_BF16=1 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof_split_no -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-envs 0 --no-overlap > $R/$OUT/prof_split_no.log 2>&1
 echo kernel stats done
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/$OUT/pmc_fetch -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-envs 0 --no-roofline --no-overlap > $R/$OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/$OUT/pmc_write -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-envs 0 --no-roofline --no-overlap > $R/$OUT/pmc_write.log 2>&1

@@ -9,12 +9,15 @@ op_sel:[0,1,0]``) change in ~60 000 of 655 360 elements under the bf16 loop and 
 there.
 
     python tools/hazard_repro_backward.py
+    GA_VARIANT_LIB=garage_amd/_C/variants/lib_slp.so python tools/hazard_repro_backward.py
 """
 import os, sys, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np
 import bench
 from garage_amd import _lib
+if os.environ.get('GA_VARIANT_LIB'):  # make slp-variant
+    _lib.LIB_PATH = os.path.abspath(os.environ['GA_VARIANT_LIB'])
 lib = _lib.load()
 cfg = bench.CONFIGS['c3']
 algo, sampler, pol, S = bench.build_engine(cfg, None, seed=2, algo_name='trpo')
