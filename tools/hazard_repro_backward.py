@@ -62,6 +62,9 @@ cnt = ne.view(ne.shape[0], 256, 20).sum(dim=0)   # [c][j]
 print('differences by narrow column j (sum over splits and c):', cnt.sum(dim=0).tolist())
 print('differences by wide column c %% 16:', cnt.sum(dim=1).view(16, 16).sum(dim=0).tolist())
 print('differences by wide column c // 64 (column block):', cnt.sum(dim=1).view(4, 64).sum(dim=1).tolist())
+if not bool(ne.any()):
+    print('(no differences: nothing to detail)')
+    sys.exit(0)
 sp = int(ne.any(dim=1).nonzero()[0].item())
 idx = ne[sp].nonzero().flatten()[:12]
 for i in idx.tolist():
