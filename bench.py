@@ -577,7 +577,7 @@ def main():
     # v_mfma_f32_32x32x16_bf16 (every fp32 operand as three bf16 terms, six products,
     # fp32 accumulation).  The headline `value` above is exact fp32 and stays so.
     split = None
-    if (args.config == 'c3' and args.algo == 'ppo' and not args.no_split_variant
+    if (args.config in ('c3', 'c5') and args.algo == 'ppo' and not args.no_split_variant
             and not os.environ.get('GARAGE_AMD_SPLIT_BF16')):
         from garage_amd import _lib
         lib = _lib.load()
@@ -745,8 +745,8 @@ def main():
         line['value_split_bf16'] = S * world * args.steps / split['elapsed']
         line['ms_per_step_split_bf16'] = split['elapsed'] / args.steps * 1e3
         line['dtype_split_bf16'] = (
-            'f32 in memory; operands of the three update kernels (and of the '
-            'evaluation forward) split into 3 bf16 terms each, 6 products on '
+            'f32 in memory; operands of the update kernels / wide-layer GEMMs (and of '
+            'the evaluation forward) split into 3 bf16 terms each, 6 products on '
             'v_mfma_f32_32x32x16_bf16, fp32 accumulation -- opt-in experiment '
             '(ga_set_split_bf16), gradients as close to fp64 as the exact kernels\' '
             '(profiles/r03_split_error_histogram.json); `value` is exact fp32')

@@ -116,4 +116,12 @@ int ga_reduce_regions_adam(const ga_fused_region* regions, int n_regions, float*
  * (ga_set_split_bf16 / GARAGE_AMD_SPLIT_BF16=1). */
 int ga_split_bf16_enabled(void); /* ... for the weight-gradient GEMM */
 int ga_split_bf16_any(void);     /* ... for any kernel */
+int ga_split_bf16_gemm(void);    /* ... for the per-layer forward / data-gradient GEMMs */
+/* W [rows][ld] (cols valid) as the B operand of a split-operand k-loop: three bf16
+ * planes in fragment order (fused_train.hip: split_planes_kernel), both dimensions
+ * padded to multiples of 32; bwd = 0: B(k, n) = W[n][k], 1: B(k, n) = W[k][n].
+ * Recomputed by every call, on `stream`; plane pl at + pl * round32(rows) *
+ * round32(cols). */
+const uint16_t* ga_weight_planes(const float* W, int64_t ld, int rows, int cols, int bwd,
+                                 hipStream_t stream);
 }

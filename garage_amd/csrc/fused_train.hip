@@ -1069,24 +1069,29 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
                                                            int64_t ld, int rows, int cols,
                                                            uint32_t* __restrict__ fwd,
                                                            uint32_t* __restrict__ bwd) {
-  // one thread per PAIR of consecutive k (one dword of every plane)
-  const int64_t pairs = (int64_t)rows * cols / 2;
+  // one thread per PAIR of consecutive k (one dword of every plane); both dimensions
+  // are padded to multiples of 32 in the planes, the padding is zero
+  const int rows_p = (rows + 31) & ~31, cols_p = (cols + 31) & ~31;
+  const int64_t pairs = (int64_t)rows_p * cols_p / 2;
   const int64_t half_blocks = (pairs + 255) / 256;
   const bool T = BWD_ONLY || (int64_t)blockIdx.x >= half_blocks;
   const int64_t e =
       ((int64_t)blockIdx.x - ((T && !BWD_ONLY) ? half_blocks : 0)) * 256 + threadIdx.x;
   if (e >= pairs) return;
-  const int N = T ? cols : rows;
+  const int N = T ? cols_p : rows_p;
   // e enumerates the OUTPUT order (contiguous writes; the reads of bwd are strided:
-  // 64 K elements, nothing to optimise)
+  // a few 100 K elements, nothing to optimise)
   const int kk = 2 * (int)(e & 3);
   const int l = (int)((e >> 2) & 63);
   const int64_t blk = e >> 8;
   const int nb = (int)(blk % (N / 32)), kg = (int)(blk / (N / 32));
   const int n = 32 * nb + (l & 31);
   const int k = 16 * kg + 8 * (l >> 5) + kk;
-  const float x0 = T ? W[(int64_t)k * ld + n] : W[(int64_t)n * ld + k];
-  const float x1 = T ? W[(int64_t)(k + 1) * ld + n] : W[(int64_t)n * ld + k + 1];
+  // W row / column of the two elements
+  const int r0 = T ? k : n, c0 = T ? n : k;
+  const int r1 = T ? k + 1 : n, c1 = T ? n : k + 1;
+  const float x0 = (r0 < rows && c0 < cols) ? W[(int64_t)r0 * ld + c0] : 0.f;
+  const float x1 = (r1 < rows && c1 < cols) ? W[(int64_t)r1 * ld + c1] : 0.f;
   uint32_t hi, mid, lo;
   ft_split3_pair(x0, x1, hi, mid, lo);
   uint32_t* out = T ? bwd : fwd;
@@ -1113,7 +1118,8 @@ bool pipelined_kloop_on() {
 // exact fp32 everywhere.
 int g_split_bf16 = -1;
 int g_split_parts = -1;  // developer knob: which kernels (1 forward, 2 data gradient,
-                         // 4 weight gradient, 8 evaluation forward); default all
+                         // 4 weight gradient, 8 evaluation forward, 16 the per-layer forward / data-gradient
+                         // GEMMs of wide layers); default all
 bool split_bf16_on(int part = 0) {
   if (g_split_bf16 < 0) {
     const char* e = getenv("GARAGE_AMD_SPLIT_BF16");
@@ -1121,7 +1127,7 @@ bool split_bf16_on(int part = 0) {
   }
   if (g_split_parts < 0) {
     const char* e = getenv("GARAGE_AMD_SPLIT_PARTS");
-    g_split_parts = e ? atoi(e) : 15;
+    g_split_parts = e ? atoi(e) : 31;
   }
   return g_split_bf16 != 0 && (part == 0 || (g_split_parts & part) != 0);
 }
@@ -1155,10 +1161,9 @@ const uint16_t* planes_for(const float* W, int64_t ld, int rows, int cols, int m
       if (b.W == W && b.rows == rows && b.cols == cols) pb = &b;
     if (!pb) {
       uint16_t* buf = nullptr;
-      if (hipMalloc(&buf, 6 * (size_t)rows * cols * sizeof(uint16_t)) != hipSuccess)
-        return nullptr;
-      g_plane_bufs.push_back(
-          PlaneBuf{W, rows, cols, buf, buf + 3 * (size_t)rows * cols, nullptr, false});
+      const size_t padded = (size_t)((rows + 31) & ~31) * ((cols + 31) & ~31);
+      if (hipMalloc(&buf, 6 * padded * sizeof(uint16_t)) != hipSuccess) return nullptr;
+      g_plane_bufs.push_back(PlaneBuf{W, rows, cols, buf, buf + 3 * padded, nullptr, false});
       pb = &g_plane_bufs.back();
     }
     if (mode == PLANES_BWD) {
@@ -1173,7 +1178,8 @@ const uint16_t* planes_for(const float* W, int64_t ld, int rows, int cols, int m
     fwd = pb->fwd;
     bwd = pb->bwd;
   }
-  const unsigned blocks = (unsigned)(((int64_t)rows * cols / 2 + 255) / 256);
+  const unsigned blocks = (unsigned)(
+      ((int64_t)((rows + 31) & ~31) * ((cols + 31) & ~31) / 2 + 255) / 256);
   uint32_t* fwd32 = reinterpret_cast<uint32_t*>(fwd);
   uint32_t* bwd32 = reinterpret_cast<uint32_t*>(bwd);
   if (mode == PLANES_BWD) {
@@ -1698,6 +1704,11 @@ extern "C" int ga_debug_mfma_burn(int mode, int iters, int blocks, float* sink,
 }
 
 extern "C" int ga_split_bf16_enabled(void) { return split_bf16_on(4) ? 1 : 0; }
+extern "C" int ga_split_bf16_gemm(void) { return split_bf16_on(16) ? 1 : 0; }
+extern "C" const uint16_t* ga_weight_planes(const float* W, int64_t ld, int rows, int cols,
+                                            int bwd, hipStream_t stream) {
+  return planes_for(W, ld, rows, cols, bwd ? PLANES_BWD : PLANES_EVAL_FWD, stream);
+}
 extern "C" int ga_split_bf16_any(void) { return split_bf16_on() ? 1 : 0; }
 
 extern "C" int ga_fused_width_ok(int width) {

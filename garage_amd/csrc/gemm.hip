@@ -100,9 +100,118 @@ __device__ __forceinline__ void head_on_staged_rows(const GemmParams& p,
   }
 }
 
+// Split-operand k-loop of a 128 x 128 tile (opt-in, gemm_core.h: ft_split3_pair): the A
+// operand -- k-contiguous rows of activations -- is fetched as two 16-B quads per thread
+// and 32-deep step, two steps ahead, split into three bf16 planes in LDS one step ahead
+// (two buffers); the B operand -- a weight matrix -- comes as fragments straight from
+// its planes in L2 (p.bplanes), one step ahead, refilled in place; 24 MFMAs per step
+// and wave (v_mfma_f32_32x32x16_bf16), one barrier.  K % 4 == 0; rows beyond M and k
+// beyond K are zero in the planes.
+__device__ __forceinline__ void gemm_mainloop_split(const GemmParams& p, float* lds,
+                                                    f32x16 (&acc)[2][1], int m0, int n0,
+                                                    int wm0, int wn0) {
+  constexpr int PLANE_B = 128 * FT_PLANE_ROW_B, ABUF_B = 3 * PLANE_B;
+  char* apl = reinterpret_cast<char*>(lds);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int K = p.K, nk = (K + 31) / 32;
+  const int qq = tid & 7;
+  const float* arow[2];
+  bool row_ok[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = (tid >> 3) + 64 * i;
+    const int m = min(m0 + r, p.M - 1);
+    const int64_t line = p.a_idx ? (int64_t)p.a_idx[m] : (int64_t)m;
+    arow[i] = p.A + line * p.lda;
+    row_ok[i] = m0 + r < p.M;
+  }
+  auto load_quads = [&](int s, float4 (&v)[2]) {
+    const int kq = min(32 * s + 4 * qq, K - 4);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) v[i] = *reinterpret_cast<const float4*>(arow[i] + kq);
+  };
+  auto store_quads = [&](int s, const float4 (&v)[2]) {
+    const bool k_ok = 32 * s + 4 * qq < K;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float4 x = v[i];
+      if (!row_ok[i] || !k_ok) x = make_float4(0.f, 0.f, 0.f, 0.f);
+      uint32_t hi[2], mid[2], lo[2];
+      ft_split3_pair(x.x, x.y, hi[0], mid[0], lo[0]);
+      ft_split3_pair(x.z, x.w, hi[1], mid[1], lo[1]);
+      char* dst = apl + (s & 1) * ABUF_B + ((tid >> 3) + 64 * i) * FT_PLANE_ROW_B + qq * 8;
+      *reinterpret_cast<uint2*>(dst) = make_uint2(hi[0], hi[1]);
+      *reinterpret_cast<uint2*>(dst + PLANE_B) = make_uint2(mid[0], mid[1]);
+      *reinterpret_cast<uint2*>(dst + 2 * PLANE_B) = make_uint2(lo[0], lo[1]);
+    }
+  };
+  const uint16_t* wpl = p.bplanes + (((n0 + wn0) / 32) * 64 + lane) * 8;
+  ft_u32x4 bw[2][3];
+  auto fetch_planes = [&](int s, int g) {
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+      bw[g][pl] = *reinterpret_cast<const ft_u32x4*>(
+          wpl + pl * p.bplane_stride + (int64_t)((2 * s + g) * p.bplane_nblk) * 512);
+  };
+  if (nk <= 0) return;
+  fetch_planes(0, 0);
+  fetch_planes(0, 1);
+  float4 qc[2], qn[2];
+  load_quads(0, qc);
+  if (nk > 1) load_quads(1, qn);
+  store_quads(0, qc);
+  qc[0] = qn[0]; qc[1] = qn[1];
+  __syncthreads();
+#define GS_SB __builtin_amdgcn_sched_barrier(0)
+  for (int s = 0; s < nk; ++s) {
+    const bool more = s + 1 < nk;
+    const char* arow_l =
+        apl + (s & 1) * ABUF_B + (wm0 + l31) * FT_PLANE_ROW_B + 16 * half;
+    ft_u32x4 af[2][2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        af[0][i][pl] = *reinterpret_cast<const ft_u32x4*>(arow_l + pl * PLANE_B +
+                                                          32 * i * FT_PLANE_ROW_B);
+    if (s + 2 < nk) load_quads(s + 2, qn);
+    GS_SB;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int slot = 0; slot < 24; ++slot) {
+      const int g = slot / 12, t = (slot % 12) / 2, i = slot % 2;
+      const int pa = t == 0 ? 2 : (t == 1 || t == 2) ? 1 : 0;
+      const int pb = t == 3 ? 2 : (t == 1 || t == 4) ? 1 : 0;
+      acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+          __builtin_bit_cast(ft_bf16x8, af[g][i][pa]),
+          __builtin_bit_cast(ft_bf16x8, bw[g][pb]), acc[i][0], 0, 0, 0);
+      GS_SB;
+      if (slot == 6 || slot == 8 || slot == 11) {
+        const int pl = slot == 6 ? 2 : slot == 8 ? 1 : 0;
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+          af[1][ii][pl] = *reinterpret_cast<const ft_u32x4*>(
+              arow_l + pl * PLANE_B + 32 * ii * FT_PLANE_ROW_B + 32);
+      }
+      if (more) {
+        if (slot == 2) store_quads(s + 1, qc);
+        if (slot == 11) fetch_planes(s + 1, 0);
+        if (slot == 23) fetch_planes(s + 1, 1);
+      }
+      GS_SB;
+    }
+    __builtin_amdgcn_s_setprio(0);
+    qc[0] = qn[0]; qc[1] = qn[1];
+    __syncthreads();
+  }
+#undef GS_SB
+}
+
 // bid: the workgroup's linear id within ITS problem (a pair launch carries two)
+// SPLIT: the opt-in split-operand k-loop above (128 x 128 tiles, A_KC, weights as planes)
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KC, bool B_KC, int BKT,
-          bool HEAD>
+          bool HEAD, bool SPLIT = false>
 __device__ __forceinline__ void gemm_f32_body(const GemmParams& p, const int bid) {
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int TM = WM / 32, TN = WN / 32;
@@ -116,7 +225,13 @@ __device__ __forceinline__ void gemm_f32_body(const GemmParams& p, const int bid
       A_FLOATS + B_FLOATS > STAGE_FLOATS ? A_FLOATS + B_FLOATS : STAGE_FLOATS;
   // HEAD: + the waves' partial head sums, [<= 4 planes][64 rows][8]
   constexpr int HEAD_PLANES = WAVES_M * WAVES_N < 4 ? WAVES_M * WAVES_N : 4;
-  constexpr int LDS_FLOATS = TILE_FLOATS + (HEAD ? HEAD_PLANES * 64 * 8 : 0);
+  // (SPLIT: two buffers of three bf16 planes of the 128-row A tile)
+  constexpr int SPLIT_FLOATS = SPLIT ? 2 * 3 * 128 * FT_PLANE_ROW_B / 4 : 0;
+  constexpr int LDS_FLOATS = (TILE_FLOATS > SPLIT_FLOATS ? TILE_FLOATS : SPLIT_FLOATS) +
+                             (HEAD ? HEAD_PLANES * 64 * 8 : 0);
+  static_assert(!SPLIT || (BM == 128 && BN == 128 && WAVES_M == 2 && WAVES_N == 4 && A_KC &&
+                           !HEAD),
+                "the split-operand loop: 128 x 128 tiles, 8 waves, k-contiguous A");
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
 
   const int lane = threadIdx.x & 63;
@@ -158,7 +273,10 @@ __device__ __forceinline__ void gemm_f32_body(const GemmParams& p, const int bid
   // interior workgroups (every one at the C3 shapes, all but the last row / column
   // block and the last split otherwise) take the mask-free loader
   const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N) && kend > kbeg;
-  if (full)
+  if constexpr (SPLIT) {
+    gemm_mainloop_split(p, lds, acc, m0, n0, wm0, wn0);
+    __syncthreads();  // (the epilogue stages output rows over the planes)
+  } else if (full)
     gemm_mainloop<BM, BN, WAVES_M, WAVES_N, A_KC, B_KC, BKT, true>(
         p, lds, acc, csum, do_colsum, m0, n0, kbeg, kend, wm0, wn0);
   else
@@ -286,6 +404,10 @@ __attribute__((amdgpu_waves_per_eu(GA_GEMM_WAVES_PER_EU, 8)))
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_f32_kernel(
     GemmParams p) {
   gemm_f32_body<BM, BN, WAVES_M, WAVES_N, A_KC, B_KC, BKT, HEAD>(p, (int)blockIdx.x);
+}
+
+__global__ __launch_bounds__(512, 4) void gemm_kc_split_kernel(GemmParams p) {
+  gemm_f32_body<128, 128, 2, 4, true, true, BK, false, true>(p, (int)blockIdx.x);
 }
 
 // Two problems of the same shape in one grid (the policy's and the value function's
@@ -489,6 +611,22 @@ int launch_gemm(const GemmParams& p_in, int splits, hipStream_t stream) {
     ga_prof_events(GA_PROF_GEMM_NT_128 + mode, flops, &e0, &e1);
     hipExtLaunchKernelGGL((gemm_f32_kernel<64, 64, 2, 2, A_KC, B_KC>), grid, dim3(256),
                           0, stream, e0, e1, 0, p);
+  } else if (A_KC && ga_split_bf16_gemm() && splits == 1 && p.N >= 128 && p.K >= 128 &&
+             p.K % 4 == 0 && p.M >= 1024 && !p.b_idx && !p.accum && !p.colsum &&
+             !p.head_W && p.c_cs == 1) {
+    // wide layers: forward (B(k, n) = W[n][k]) and data gradient (B(k, n) = W[k][n]);
+    // B_KC tells which orientation the weight planes are needed in
+    p.bplanes = B_KC ? ga_weight_planes(p.B, p.ldb, p.N, p.K, 0, stream)
+                     : ga_weight_planes(p.B, p.ldb, p.K, p.N, 1, stream);
+    GA_REQUIRE(p.bplanes, "gemm: no memory for the weight planes");
+    const int np = (p.N + 31) & ~31, kp = (p.K + 31) & ~31;
+    p.bplane_stride = (int64_t)np * kp;
+    p.bplane_nblk = np / 32;
+    p.gx = (int)ga_ceil_div(p.M, 128); p.gy = (int)ga_ceil_div(p.N, 128); p.gz = 1;
+    p.k_per_split = (int)ga_ceil_div(p.K, BK) * BK;
+    dim3 grid((unsigned)(p.gx * p.gy));
+    ga_prof_events(GA_PROF_GEMM_NT_128 + mode, flops, &e0, &e1);
+    hipExtLaunchKernelGGL(gemm_kc_split_kernel, grid, dim3(512), 0, stream, e0, e1, 0, p);
   } else if (!A_KC && !B_KC && ga_split_bf16_enabled() && p.M % 128 == 0 &&
              p.N % 128 == 0 && !p.a_idx && !p.b_idx && p.epi == EPI_PLAIN && !p.accum &&
              p.k_per_split % 16 == 0 && !p.colsum_of_b) {
@@ -798,7 +936,10 @@ extern "C" int64_t ga_mlp_backward_splits(const ga_mlp_desc* d, int64_t M) {
   // measured 82.3 -> 79.8 ms per iteration; an engine keeps the split count it was
   // built with)
   const int64_t target = target_env ? target_env : (ga_split_bf16_enabled() ? 256 : 1024);
-  const int64_t by_tiles = ga_ceil_div(target, tiles);
+  int64_t by_tiles = ga_ceil_div(target, tiles);
+  // (never below 64 splits on that account: the streaming weight-gradient kernels of the
+  // narrow layers take one workgroup per split and column block)
+  if (!target_env && ga_split_bf16_enabled() && by_tiles < 64) by_tiles = 64;
   if (!small && s > by_tiles) s = by_tiles;
   if (s < 1) s = 1;
   if (s > 128) s = 128;

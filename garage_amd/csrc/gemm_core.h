@@ -152,6 +152,12 @@ struct GemmParams {
   int head_n;
   float* head_out;
   int64_t head_ld;
+  // split-operand instantiation (opt-in): the B operand as three bf16 planes in
+  // fragment order (fused_train.h: ga_weight_planes), plane pl at + pl * stride,
+  // bplane_nblk = round32(N) / 32 column blocks per 16-deep k group
+  const uint16_t* bplanes;
+  int64_t bplane_stride;
+  int bplane_nblk;
 };
 
 // One [BR x BK] operand tile: global -> registers -> LDS.

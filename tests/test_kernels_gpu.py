@@ -306,6 +306,10 @@ def test_small_m_gemm_dispatch_is_bit_identical(dev, shape):
     same bits, for ragged and gathered row counts."""
     from garage_amd import _lib
     from garage_amd.engine import FlatMLP, pad_rows
+    import os
+    if os.environ.get('GARAGE_AMD_SPLIT_BF16') == '1':
+        pytest.skip('compares two EXACT tile shapes bit for bit; with the opt-in '
+                    'split-operand k-loops the 128 x 128 side is not an exact kernel')
     lib = _lib.load()
     O, A, hs = shape
     rng = np.random.RandomState(7)

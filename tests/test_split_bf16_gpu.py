@@ -171,3 +171,60 @@ def test_split_evaluation_forward_matches_the_exact_one(split_mode):
     got = net.forward(X, M, keep_acts=False)[:, :6].clone()
     assert not torch.equal(got, want)
     assert float((got - want).abs().max()) < 2e-6 * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.parametrize('shape', [(376, 17, (512, 512, 512), 5000),
+                                   (40, 3, (128, 384), 8193)])
+def test_split_wide_layers_forward_and_backward_match_the_exact_gemms(split_mode, shape):
+    """Layers of 128 units and more take the per-layer GEMMs; with the experiment on
+    their forward and data-gradient launches run ``gemm_kc_split_kernel`` (ragged row
+    tiles, K = 376 -- not a multiple of 32 --, N = 384 -- three column tiles) and the
+    128-aligned weight gradients ``gemm_nt_split_kernel``.  Outputs and gradients against
+    the exact kernels; a float64 torch reference bounds both."""
+    from garage_amd.engine import FlatMLP
+    lib = split_mode
+    in_dim, out_dim, hidden, M = shape
+    dev = torch.device('cuda')
+    torch.manual_seed(7)
+    net = FlatMLP(in_dim, out_dim, hidden, dev)
+    for key, view in net.named_views():
+        view.copy_(torch.randn(view.shape, device=dev) / (view.shape[-1] ** 0.5))
+    ldx = (in_dim + 3) // 4 * 4
+    X = torch.zeros(M, ldx, device=dev)
+    X[:, :in_dim] = torch.randn(M, in_dim, device=dev)
+    got = {}
+    for mode in (0, 1):
+        lib.ga_set_split_bf16(mode)
+        out = net.forward(X, M, keep_acts=True)[:, :out_dim].clone()
+        d = net.dout_view(M)
+        d.zero_()
+        torch.manual_seed(9)
+        d[:, :out_dim] = torch.randn(M, out_dim, device=dev) / M
+        net.backward(X, M, d)
+        net.reduce_grads(scale=1.0)
+        got[mode] = (out, {k: v.clone() for k, v in net.named_views(net.grads)})
+    # float64 reference
+    h = X[:, :in_dim].double()
+    params = {k: v.double().requires_grad_(True) for k, v in net.named_views()}
+    names = [k for k in params if k.endswith('weight')]
+    for i, w in enumerate(names):
+        b = w[:-len('weight')] + 'bias'
+        h = h @ params[w].t() + params[b]
+        if i + 1 < len(names):
+            h = torch.tanh(h)
+    torch.manual_seed(9)
+    dref = (torch.randn(M, out_dim, device=dev) / M).double()
+    (h * dref).sum().backward()
+    assert not torch.equal(got[0][0], got[1][0])
+    oscale = float(h.abs().max())
+    for mode in (0, 1):
+        assert float((got[mode][0].double() - h).abs().max()) < 3e-6 * oscale
+    for k, p in params.items():
+        if p.grad is None:
+            continue
+        scale = float(p.grad.abs().max())
+        e = [float((got[m][1][k].double() - p.grad).abs().max()) / scale for m in (0, 1)]
+        assert e[0] < 5e-6 and e[1] < 5e-6, (k, e)
+        # (weight matrices: the exact kernels' error; bias gradients -- column sums of a
+        # split-operand product -- up to 3x, DESIGN.md section 5)
+        assert e[1] < (3.0 if k.endswith('bias') else 2.0) * e[0] + 5e-7, (k, e)
