@@ -577,8 +577,9 @@ def main():
     # v_mfma_f32_32x32x16_bf16 (every fp32 operand as three bf16 terms, six products,
     # fp32 accumulation).  The headline `value` above is exact fp32 and stays so.
     split = None
+    # (one GPU only: the N > 1 runs are the driver's scaling measurement of the exact path)
     if (args.config in ('c3', 'c5') and args.algo == 'ppo' and not args.no_split_variant
-            and not os.environ.get('GARAGE_AMD_SPLIT_BF16')):
+            and world == 1 and not os.environ.get('GARAGE_AMD_SPLIT_BF16')):
         from garage_amd import _lib
         lib = _lib.load()
         lib.ga_set_split_bf16(1)
