@@ -2,7 +2,8 @@
 // SIMD run v_mfma_f32_32x32x16_bf16 at the same time?  Half of the waves of every
 // workgroup run a long chain of fp32 vector arithmetic (plain and packed FMAs / adds,
 // LDS round trips) whose result depends on every instruction; the other half either
-// idle (reference run) or issue bf16 (mode 1) / fp32 (mode 2) MFMAs back to back.  The
+// idle (reference run) or issue bf16 (mode 1) / fp32 (mode 2) / f16 (mode 3) 32x32 MFMAs or
+// bf16 16x16x32 MFMAs (mode 4) back to back.  The
 // vector results of the three runs must be the same bits.
 //   hipcc --offload-arch=gfx950 -O3 tools/mfma_valu_hazard.hip -o garage_amd/_C/mfma_valu_hazard
 #include <hip/hip_runtime.h>
@@ -13,6 +14,8 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 __global__ __launch_bounds__(512) void hazard(int mode, int iters, float* out, float* sink, int victim) {
   __shared__ float sh[8][64 * 4];
@@ -95,8 +98,12 @@ __global__ __launch_bounds__(512) void hazard(int mode, int iters, float* out, f
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
     bf16x8 a8, b8;
+    f16x8 h8a, h8b;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { a8[i] = (__bf16)(0.01f * (lane + i)); b8[i] = (__bf16)(0.02f * i); }
+    for (int i = 0; i < 8; ++i) {
+      a8[i] = (__bf16)(0.01f * (lane + i)); b8[i] = (__bf16)(0.02f * i);
+      h8a[i] = (_Float16)(0.01f * (lane + i)); h8b[i] = (_Float16)(0.02f * i);
+    }
     const float af = 0.01f * lane, bf = 0.5f;
     // (about as long as the vector waves' loop)
     for (int it = 0; it < iters * 3; ++it) {
@@ -104,8 +111,15 @@ __global__ __launch_bounds__(512) void hazard(int mode, int iters, float* out, f
       for (int c = 0; c < 4; ++c) {
         if (mode == 1)
           acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, b8, acc[c], 0, 0, 0);
-        else
+        else if (mode == 2)
           acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[c], 0, 0, 0);
+        else if (mode == 3)
+          acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8a, h8b, acc[c], 0, 0, 0);
+        else {
+          f4v t = {acc[c][0], acc[c][1], acc[c][2], acc[c][3]};
+          t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, b8, t, 0, 0, 0);
+          acc[c][0] = t[0]; acc[c][1] = t[1]; acc[c][2] = t[2]; acc[c][3] = t[3];
+        }
       }
     }
     float s = 0.f;
@@ -135,7 +149,7 @@ int main() {
   hipLaunchKernelGGL(hazard, dim3(grid), dim3(512), 0, 0, 0, iters, out, sink, victim);
   hipDeviceSynchronize();
   hipMemcpy(ref, out, n * sizeof(float), hipMemcpyDeviceToHost);
-  for (int mode = 0; mode <= 2; ++mode)
+  for (int mode = 0; mode <= 4; ++mode)
     for (int rep = 0; rep < (mode == 1 ? 2 : 1); ++rep) {
       hipMemset(out, 0, n * sizeof(float));
       hipLaunchKernelGGL(hazard, dim3(grid), dim3(512), 0, 0, mode, iters, out, sink, victim);
@@ -145,7 +159,7 @@ int main() {
       for (size_t i = 0; i < n; ++i)
         if (memcmp(&got[i], &ref[i], 4) != 0) { if (!bad) first = i; ++bad; }
       printf("other waves %s, run %d: %zu of %zu vector results differ from the idle run",
-             mode == 0 ? "idle" : mode == 1 ? "bf16 MFMA" : "fp32 MFMA", rep, bad, n / 2);
+             mode == 0 ? "idle" : mode == 1 ? "bf16 MFMA" : mode == 2 ? "fp32 MFMA" : mode == 3 ? "f16 MFMA 32x32x16" : "bf16 MFMA 16x16x32", rep, bad, n / 2);
       if (bad)
         printf(" (first: block %zu thread %zu value %zu: %.9g vs %.9g)", first / (512 * 16),
                (first / 16) % 512, first % 16, got[first], ref[first]);
