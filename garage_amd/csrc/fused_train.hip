@@ -1149,7 +1149,9 @@ std::vector<PlaneBuf> g_plane_bufs;
 // kernel asks (want_bwd = false); the data-gradient launch of the same step -- same
 // stream, weights unchanged in between -- then finds its planes fresh and launches
 // nothing.  Any other order (a data-gradient launch on its own) recomputes.
-enum { PLANES_TRAIN_FWD = 0, PLANES_BWD = 1, PLANES_EVAL_FWD = 2 };
+// PLANES_BWD: the fused data-gradient launch of the step whose forward launch asked with
+// PLANES_TRAIN_FWD (may reuse); PLANES_BWD_ALWAYS: anybody else (always recomputes)
+enum { PLANES_TRAIN_FWD = 0, PLANES_BWD = 1, PLANES_EVAL_FWD = 2, PLANES_BWD_ALWAYS = 3 };
 const uint16_t* planes_for(const float* W, int64_t ld, int rows, int cols, int mode,
                            hipStream_t stream) {
   uint16_t *fwd = nullptr, *bwd = nullptr;
@@ -1166,8 +1168,8 @@ const uint16_t* planes_for(const float* W, int64_t ld, int rows, int cols, int m
       g_plane_bufs.push_back(PlaneBuf{W, rows, cols, buf, buf + 3 * padded, nullptr, false});
       pb = &g_plane_bufs.back();
     }
-    if (mode == PLANES_BWD) {
-      reuse = pb->bwd_fresh && pb->bwd_stream == stream;
+    if (mode == PLANES_BWD || mode == PLANES_BWD_ALWAYS) {
+      reuse = mode == PLANES_BWD && pb->bwd_fresh && pb->bwd_stream == stream;
       pb->bwd_fresh = false;
     } else if (mode == PLANES_TRAIN_FWD) {
       pb->bwd_fresh = true;
@@ -1182,7 +1184,7 @@ const uint16_t* planes_for(const float* W, int64_t ld, int rows, int cols, int m
       ((int64_t)((rows + 31) & ~31) * ((cols + 31) & ~31) / 2 + 255) / 256);
   uint32_t* fwd32 = reinterpret_cast<uint32_t*>(fwd);
   uint32_t* bwd32 = reinterpret_cast<uint32_t*>(bwd);
-  if (mode == PLANES_BWD) {
+  if (mode == PLANES_BWD || mode == PLANES_BWD_ALWAYS) {
     if (!reuse)
       hipLaunchKernelGGL(split_planes_kernel<true>, dim3(blocks), dim3(256), 0, stream, W,
                          ld, rows, cols, fwd32, bwd32);
@@ -1707,7 +1709,7 @@ extern "C" int ga_split_bf16_enabled(void) { return split_bf16_on(4) ? 1 : 0; }
 extern "C" int ga_split_bf16_gemm(void) { return split_bf16_on(16) ? 1 : 0; }
 extern "C" const uint16_t* ga_weight_planes(const float* W, int64_t ld, int rows, int cols,
                                             int bwd, hipStream_t stream) {
-  return planes_for(W, ld, rows, cols, bwd ? PLANES_BWD : PLANES_EVAL_FWD, stream);
+  return planes_for(W, ld, rows, cols, bwd ? PLANES_BWD_ALWAYS : PLANES_EVAL_FWD, stream);
 }
 extern "C" int ga_split_bf16_any(void) { return split_bf16_on() ? 1 : 0; }
 
