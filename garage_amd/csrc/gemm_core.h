@@ -179,6 +179,13 @@ struct TileLoader {
   float4 regs[NV];
   int32_t cur[NV];  // memory line (after the optional gather) of each vector
   int32_t nxt[NV];
+  // KC = false without a gather: a vector's address advances by BKT lines per step --
+  // a pointer per vector set up once (init_linear) and ONE 64-bit add per load replace
+  // the per-step line clamps and the 64-bit line * ld products (two quarter-rate 32-bit
+  // multiplies and a mad per vector: on this chip every vector instruction beside an
+  // fp32 MFMA is matrix time lost)
+  const float* lin_ptr[NV];
+  bool lin;
 
   // lines of the first tile (KC: the rows, fixed for the whole kernel)
   __device__ __forceinline__ void init(const int32_t* __restrict__ idx, int r0,
@@ -200,10 +207,25 @@ struct TileLoader {
     }
   }
 
+  // (FULL, KC = false, no gather) pointers of the first tile; `base` + r0 as in load()
+  __device__ __forceinline__ void init_linear(const float* __restrict__ base, int64_t ld,
+                                              const int32_t* __restrict__ idx, int r0,
+                                              int kbeg) {
+    lin = FULL && !KC && idx == nullptr;
+    if (!lin) return;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int f = tid + NT * i;
+      lin_ptr[i] = base + (int64_t)(kbeg + f / VPL) * ld + r0 + 4 * (f % VPL);
+    }
+  }
+
   // KC = false only: lines of the tile that starts at k0 (one tile ahead)
   __device__ __forceinline__ void prefetch_lines(const int32_t* __restrict__ idx,
                                                  int k0, int kend) {
     if (KC) return;
+    if (FULL && lin && k0 + BKT < kend) return;  // the linear path needs no line numbers
     const int tid = threadIdx.x;
     if (idx) {
 #pragma unroll
@@ -227,8 +249,15 @@ struct TileLoader {
   // FULL loader still clamps / masks there, so only the tile's row range has to
   // be interior for the fast path, not its k range
   __device__ __forceinline__ void load(const float* __restrict__ base, int64_t ld,
-                                       int r0, int k0, int span, bool tail) {
+                                       int r0, int k0, int span, bool tail, int kbeg = 0) {
     const int tid = threadIdx.x;
+    if (FULL && !KC && lin && !tail) {
+      const int64_t off = (int64_t)(k0 - kbeg) * ld;  // wave-uniform
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+        regs[i] = *reinterpret_cast<const float4*>(lin_ptr[i] + off);
+      return;
+    }
     const int last = max(((span + 3) & ~3) - 4, 0);  // last in-bounds vector
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -299,9 +328,11 @@ __device__ __forceinline__ void gemm_mainloop(const GemmParams& p, float* lds,
   if (nk > 0) {
     la.init(p.a_idx, m0, p.M, kbeg, kend);
     lb.init(p.b_idx, n0, p.N, kbeg, kend);
+    la.init_linear(p.A, p.lda, p.a_idx, m0, kbeg);
+    lb.init_linear(p.B, p.ldb, p.b_idx, n0, kbeg);
     const bool t0 = nk == 1;
-    la.load(p.A, p.lda, m0, kbeg, a_span, t0);
-    lb.load(p.B, p.ldb, n0, kbeg, b_span, t0);
+    la.load(p.A, p.lda, m0, kbeg, a_span, t0, kbeg);
+    lb.load(p.B, p.ldb, n0, kbeg, b_span, t0, kbeg);
     la.prefetch_lines(p.a_idx, kbeg + BKT, kend);
     lb.prefetch_lines(p.b_idx, kbeg + BKT, kend);
     la.store(As, m0, p.M, kbeg, kend, t0);
@@ -317,8 +348,8 @@ __device__ __forceinline__ void gemm_mainloop(const GemmParams& p, float* lds,
     if (more) {
       la.rotate();
       lb.rotate();
-      la.load(p.A, p.lda, m0, k_next, a_span, tail);
-      lb.load(p.B, p.ldb, n0, k_next, b_span, tail);
+      la.load(p.A, p.lda, m0, k_next, a_span, tail, kbeg);
+      lb.load(p.B, p.ldb, n0, k_next, b_span, tail, kbeg);
       la.prefetch_lines(p.a_idx, k_next + BKT, kend);
       lb.prefetch_lines(p.b_idx, k_next + BKT, kend);
     }
