@@ -228,3 +228,44 @@ def test_split_wide_layers_forward_and_backward_match_the_exact_gemms(split_mode
         # (weight matrices: the exact kernels' error; bias gradients -- column sums of a
         # split-operand product -- up to 3x)
         assert e[1] < (3.0 if k.endswith('bias') else 2.0) * e[0] + 5e-7, (k, e)
+
+
+def test_backward_pass_keeps_its_bits_next_to_bf16_mfmas():
+    """The hazard of ``tools/mfma_valu_hazard.hip`` seen from the library: a forward +
+    backward pass of a C3-shaped network (first-layer weight gradient on the streaming
+    kernel hipcc used to vectorize into ``v_pk_fma_f32 ... op_sel:[0,1,0]``) while a
+    second stream runs a register-only bf16 MFMA loop must give the bits it gives alone.
+    Built with the SLP vectorizer this changed ~60 000 of 655 360 slab elements."""
+    import ctypes as C
+    from garage_amd import _lib
+    from garage_amd.engine import FlatMLP
+    lib = _lib.load()
+    dev = torch.device('cuda')
+    torch.manual_seed(3)
+    net = FlatMLP(17, 6, (256, 256), dev)
+    for key, view in net.named_views():
+        view.copy_(torch.randn(view.shape, device=dev) / (view.shape[-1] ** 0.5))
+    M = 262144
+    X = torch.zeros(M, 20, device=dev)
+    X[:, :17] = torch.randn(M, 17, device=dev)
+    net.forward(X, M, keep_acts=True)
+    d = net.dout_view(M)
+    d.copy_(torch.randn(d.shape, device=dev) * 0.01)
+
+    def slabs():
+        net.backward(X, M, d)
+        return net._slabs.clone()
+
+    ref = slabs()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    sink = torch.zeros(16, device=dev)
+    burn = lib.ga_debug_mfma_burn
+    burn.restype = C.c_int
+    for mode in (2, 1):  # fp32 MFMAs, then bf16 MFMAs, on the other stream
+        for _ in range(3):
+            burn(C.c_int(mode), C.c_int(40000), C.c_int(512), C.c_void_p(sink.data_ptr()),
+                 C.c_void_p(side.cuda_stream))
+            got = slabs()
+            torch.cuda.synchronize()
+            assert torch.equal(got, ref), mode
