@@ -124,4 +124,10 @@ int ga_split_bf16_gemm(void);    /* ... for the per-layer forward / data-gradien
  * round32(cols). */
 const uint16_t* ga_weight_planes(const float* W, int64_t ld, int rows, int cols, int bwd,
                                  hipStream_t stream);
+/* The next ga_reduce_regions_adam of this thread also rewrites the planes of the
+ * [rows][cols] weight matrix at flat index flat_beg (the step's forward launch used
+ * them); ga_planes_epoch_begin: planes written that way are trusted only until the
+ * epoch call that wrote them returns. */
+void ga_reduce_planes_hint(int64_t flat_beg, int rows, int cols);
+void ga_planes_epoch_begin(void);
 }

@@ -1142,6 +1142,10 @@ struct PlaneBuf {
   uint16_t* bwd;        // B(k = row, n = col): the data-gradient kernel's operand
   hipStream_t bwd_stream;  // stream on which `bwd` was last refreshed, not yet consumed
   bool bwd_fresh;
+  // both operands were rewritten by the optimizer launch (reduce_regions_adam_kernel)
+  // that last changed W, on this stream, inside the epoch call that is still running
+  hipStream_t adam_stream;
+  bool adam_fresh;
 };
 std::mutex g_plane_mu;
 std::vector<PlaneBuf> g_plane_bufs;
@@ -1168,17 +1172,22 @@ const uint16_t* planes_for(const float* W, int64_t ld, int rows, int cols, int m
       g_plane_bufs.push_back(PlaneBuf{W, rows, cols, buf, buf + 3 * padded, nullptr, false});
       pb = &g_plane_bufs.back();
     }
+    bool from_adam = false;
     if (mode == PLANES_BWD || mode == PLANES_BWD_ALWAYS) {
       reuse = mode == PLANES_BWD && pb->bwd_fresh && pb->bwd_stream == stream;
       pb->bwd_fresh = false;
     } else if (mode == PLANES_TRAIN_FWD) {
+      // (the previous step's optimizer launch wrote both operands already)
+      from_adam = pb->adam_fresh && pb->adam_stream == stream;
       pb->bwd_fresh = true;
       pb->bwd_stream = stream;
     } else {
       pb->bwd_fresh = false;
     }
+    pb->adam_fresh = false;
     fwd = pb->fwd;
     bwd = pb->bwd;
+    if (from_adam) return fwd;
   }
   const unsigned blocks = (unsigned)(
       ((int64_t)((rows + 31) & ~31) * ((cols + 31) & ~31) / 2 + 255) / 256);
@@ -1531,6 +1540,13 @@ struct FtNet {
   int64_t M;
   LossRowArgs loss;
   float* loss_out;
+  // split-operand experiment: the planes of ONE weight matrix (rows x cols, ld = cols, at
+  // flat index pl_beg) are rewritten with the updated values, so that the next step's
+  // forward launch needs no plane launch (null: nothing)
+  uint32_t* pl_fwd;
+  uint32_t* pl_bwd;
+  int64_t pl_beg;
+  int pl_rows, pl_cols;
 };
 struct ReduceRegionsParams {
   FtRegion r[FT_MAX_REGIONS];
@@ -1644,6 +1660,41 @@ __global__ __launch_bounds__(256) void reduce_regions_adam_kernel(ReduceRegionsP
     *reinterpret_cast<float4*>(N.a.p + i) = make_float4(pp[0], pp[1], pp[2], pp[3]);
     *reinterpret_cast<float4*>(N.a.m + i) = make_float4(mm[0], mm[1], mm[2], mm[3]);
     *reinterpret_cast<float4*>(N.a.v + i) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    if (N.pl_fwd && i >= N.pl_beg && i < N.pl_beg + (int64_t)N.pl_rows * N.pl_cols) {
+      // this quad = W[n][k .. k + 3]; the layout of split_planes_kernel (rows and cols
+      // are multiples of 32 here)
+      const int64_t e0 = i - N.pl_beg;
+      const int n = (int)(e0 / N.pl_cols), k = (int)(e0 % N.pl_cols);
+      const int64_t total = (int64_t)N.pl_rows * N.pl_cols;
+      uint32_t hi[2], mid[2], lo[2];
+      ft_split3_pair(pp[0], pp[1], hi[0], mid[0], lo[0]);
+      ft_split3_pair(pp[2], pp[3], hi[1], mid[1], lo[1]);
+      {  // forward operand: B(k, n) = W[n][k], pairs along k: two adjacent dwords
+        const int64_t blk = (int64_t)(k >> 4) * (N.pl_rows / 32) + (n >> 5);
+        const int l = (n & 31) + 32 * ((k >> 3) & 1);
+        uint32_t* o = N.pl_fwd + (blk * 64 + l) * 4 + ((k & 7) >> 1);
+        *reinterpret_cast<uint2*>(o) = make_uint2(hi[0], hi[1]);
+        *reinterpret_cast<uint2*>(o + total / 2) = make_uint2(mid[0], mid[1]);
+        *reinterpret_cast<uint2*>(o + total) = make_uint2(lo[0], lo[1]);
+      }
+      {  // data-gradient operand: B(kk = n, nn = k): single bf16 values, 8 per fragment
+        uint16_t* b16 = reinterpret_cast<uint16_t*>(N.pl_bwd);
+        const uint32_t h4[4] = {hi[0] & 0xffffu, hi[0] >> 16, hi[1] & 0xffffu, hi[1] >> 16};
+        const uint32_t m4[4] = {mid[0] & 0xffffu, mid[0] >> 16, mid[1] & 0xffffu,
+                                mid[1] >> 16};
+        const uint32_t l4[4] = {lo[0] & 0xffffu, lo[0] >> 16, lo[1] & 0xffffu, lo[1] >> 16};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int nn = k + j;
+          const int64_t blk = (int64_t)(n >> 4) * (N.pl_cols / 32) + (nn >> 5);
+          const int l = (nn & 31) + 32 * ((n >> 3) & 1);
+          const int64_t o = (blk * 64 + l) * 8 + (n & 7);
+          b16[o] = (uint16_t)h4[j];
+          b16[total + o] = (uint16_t)m4[j];
+          b16[2 * total + o] = (uint16_t)l4[j];
+        }
+      }
+    }
   }
 }
 
@@ -2103,6 +2154,35 @@ static int reduce_add_net(ReduceRegionsParams& p, int net, const ga_fused_region
   return GA_OK;
 }
 
+// The next ga_reduce_regions_adam call of this thread (with do_adam) also rewrites the
+// planes of W = params + flat_beg ([rows][cols], ld = cols); update.cpp asks for it when
+// the step's forward launch ran the split-operand kernel.
+static thread_local struct { int64_t beg; int rows, cols; bool set; } t_planes_hint = {0, 0, 0, false};
+// developer / test switch: 0 = every forward launch computes its planes itself again
+static int g_adam_planes = -1;
+static bool adam_planes_on() {
+  if (g_adam_planes < 0) {
+    const char* e = getenv("GARAGE_AMD_SPLIT_ADAM_PLANES");
+    g_adam_planes = (e && e[0] == '0') ? 0 : 1;
+  }
+  return g_adam_planes != 0;
+}
+extern "C" int ga_set_split_adam_planes(int on) {
+  g_adam_planes = on != 0;
+  return 0;
+}
+extern "C" void ga_reduce_planes_hint(int64_t flat_beg, int rows, int cols) {
+  if (!adam_planes_on()) return;
+  t_planes_hint.beg = flat_beg; t_planes_hint.rows = rows; t_planes_hint.cols = cols;
+  t_planes_hint.set = true;
+}
+// trust in optimizer-written planes never outlives an epoch call (anything may write
+// the parameters between two calls)
+extern "C" void ga_planes_epoch_begin(void) {
+  std::lock_guard<std::mutex> lock(g_plane_mu);
+  for (PlaneBuf& b : g_plane_bufs) b.adam_fresh = false;
+}
+
 extern "C" int ga_reduce_regions_adam(const ga_fused_region* regions, int n_regions,
                                       float* params, float* grads, float* exp_avg,
                                       float* exp_avg_sq, int64_t step, double lr,
@@ -2118,6 +2198,27 @@ extern "C" int ga_reduce_regions_adam(const ga_fused_region* regions, int n_regi
                                 zero_slot0, lpart, n_lpart, M, loss, loss_out);
   if (rc) return rc;
   p.n_nets = 1;
+  PlaneBuf* written = nullptr;
+  if (t_planes_hint.set) {
+    t_planes_hint.set = false;
+    const int rows = t_planes_hint.rows, cols = t_planes_hint.cols;
+    if (do_adam && split_bf16_on(1) && rows % 32 == 0 && cols % 32 == 0) {
+      const float* W = params + t_planes_hint.beg;
+      std::lock_guard<std::mutex> lock(g_plane_mu);
+      for (PlaneBuf& b : g_plane_bufs)
+        if (b.W == W && b.rows == rows && b.cols == cols) written = &b;
+      if (written) {  // (the forward launch of this step created it)
+        p.net[0].pl_fwd = reinterpret_cast<uint32_t*>(written->fwd);
+        p.net[0].pl_bwd = reinterpret_cast<uint32_t*>(written->bwd);
+        p.net[0].pl_beg = t_planes_hint.beg;
+        p.net[0].pl_rows = rows;
+        p.net[0].pl_cols = cols;
+        written->adam_fresh = true;
+        written->adam_stream = stream;
+        written->bwd_fresh = false;
+      }
+    }
+  }
   const unsigned blocks = (unsigned)p.n_virtual + 1;  // + the loss block
   hipLaunchKernelGGL(reduce_regions_adam_kernel, dim3(blocks), dim3(256), 0, stream, p);
   GA_CHECK_LAUNCH("reduce_regions_adam");

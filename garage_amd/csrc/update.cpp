@@ -389,6 +389,11 @@ int run_minibatch_fused(const ga_update_args* a, const FusedPlan& f, int64_t k,
   }
   const bool exchange = a->comm && a->phase != 1;
   const bool do_adam = !exchange && a->phase != 1;
+  // (split-operand experiment: the optimizer launch rewrites the planes of the last
+  // hidden layer's weights, the next step's forward launch then needs no plane launch)
+  if (f.first && L == 3 && do_adam && ga_split_bf16_any() && d->dims[2] == 256 &&
+      d->dims[1] % 32 == 0)
+    ga_reduce_planes_hint(d->w_off[1], d->dims[2], d->dims[1]);
   rc = ga_reduce_regions_adam(reg, nr, a->params, a->grads, a->exp_avg, a->exp_avg_sq,
                               a->step0 + k + 1, a->lr, a->beta1, a->beta2, a->eps,
                               step_scale(a, k), do_adam ? 1 : 0, !a->learn_std, lpart,
@@ -558,6 +563,7 @@ extern "C" int64_t ga_minibatch_range(int64_t S, int64_t mb, int64_t n_mb, int h
 }
 
 extern "C" int ga_update_epoch(const ga_update_args* a, ga_stream_t stream) {
+  ga_planes_epoch_begin();
   int rc = check_args(a);
   if (rc) return rc;
   const int64_t n_mb = n_minibatches(a);
@@ -744,6 +750,7 @@ hipEvent_t g_merge_events[2] = {nullptr, nullptr};
 
 extern "C" int ga_update_epoch_pair(const ga_update_args* a, ga_stream_t stream_a,
                                     const ga_update_args* b, ga_stream_t stream_b) {
+  ga_planes_epoch_begin();
   int rc = check_args(a);
   if (rc) return rc;
   rc = check_args(b);

@@ -234,6 +234,8 @@ int ga_reduce_regions_adam(const ga_fused_region* r, int n, float*, float*, floa
 }
 // ---- pair launches (two networks per grid): the fakes write the same extents
 int ga_split_bf16_any(void) { return 0; }
+void ga_reduce_planes_hint(int64_t, int, int) {}
+void ga_planes_epoch_begin(void) {}
 int ga_fused_pair_supported(int width, int K, int in_w) {
   return width == 256 && K <= 256 && ga_fused_first_layer_ok(in_w, K);
 }

@@ -269,3 +269,27 @@ def test_backward_pass_keeps_its_bits_next_to_bf16_mfmas():
             got = slabs()
             torch.cuda.synchronize()
             assert torch.equal(got, ref), mode
+
+
+def test_planes_written_by_the_optimizer_launch_are_the_plane_launchs(split_mode):
+    """Inside an epoch call the reduction + Adam launch rewrites the bf16 planes of the
+    weights it just updated, so that the next step's forward launch needs no plane
+    launch (``ga_reduce_planes_hint``); with that off every forward launch computes
+    them again.  Same planes, same bits."""
+    import test_fused_train_gpu as T
+    lib = split_mode
+    spec, batch = T._problem('c3_shape')
+    opt = (torch.optim.Adam, dict(lr=1e-3))
+    res = []
+    try:
+        for on in (1, 0):
+            lib.ga_set_split_adam_planes(on)
+            algo, pol, vf = T._algo('c3_shape', spec, opt, epochs=2)
+            np.random.seed(11)
+            algo._train_once(0, batch)
+            res.append((pol.net.params.clone(), vf.net.params.clone(),
+                        pol.net.exp_avg_sq.clone(), dict(algo.last_tabular)))
+    finally:
+        lib.ga_set_split_adam_planes(1)
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert torch.equal(res[0][2], res[1][2]) and res[0][3] == res[1][3]
