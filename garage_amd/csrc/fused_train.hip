@@ -519,9 +519,11 @@ __device__ __forceinline__ void fwd_head_loss_body(const FwdLossParams& p,
       // after a barrier all waves of the workgroup produce at once -- a workgroup
       // alone on its CU keeps the pipe busy about half the time.  Here every piece
       // of the producer (and the H1 spill, and the next step's B fragments) is issued
-      // BETWEEN the step's MFMAs, in their shadow: a v_mfma_f32_32x32x2_f32 occupies
-      // the pipe for 64 cycles and the wave may issue ~15 independent vector / LDS
-      // instructions meanwhile.  The order below is pinned with sched_barrier(0);
+      // BETWEEN the step's MFMAs: LDS / memory latencies and the producer's dependent
+      // chains then no longer stall the wave's MFMA issue.  (Vector instructions do NOT
+      // execute in an fp32 MFMA's shadow on this chip -- tools/mfma_valu_overlap.hip: the
+      // fp32 MFMA runs on the vector ALU's lanes; the interleave saves stalls, not issue
+      // time.)  The order below is pinned with sched_barrier(0);
       // the number of first-layer k groups is the compile-time KSC so that the
       // producer has no branches.  Same arithmetic in the same order per output
       // element as the plain loop: bit-identical results.
