@@ -175,7 +175,9 @@ __device__ __forceinline__ void gemm_mainloop_split(const GemmParams& p, float* 
       for (int pl = 0; pl < 3; ++pl)
         af[0][i][pl] = *reinterpret_cast<const ft_u32x4*>(arow_l + pl * PLANE_B +
                                                           32 * i * FT_PLANE_ROW_B);
+#ifndef GA_GABL_NOLOAD
     if (s + 2 < nk) load_quads(s + 2, qn);
+#endif
     GS_SB;
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -183,9 +185,13 @@ __device__ __forceinline__ void gemm_mainloop_split(const GemmParams& p, float* 
       const int g = slot / 12, t = (slot % 12) / 2, i = slot % 2;
       const int pa = t == 0 ? 2 : (t == 1 || t == 2) ? 1 : 0;
       const int pb = t == 3 ? 2 : (t == 1 || t == 4) ? 1 : 0;
+#ifdef GA_GABL_NOMFMA
+      acc[i][0][slot & 15] += __uint_as_float(af[g][i][pa][0] ^ bw[g][pb][0]);
+#else
       acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
           __builtin_bit_cast(ft_bf16x8, af[g][i][pa]),
           __builtin_bit_cast(ft_bf16x8, bw[g][pb]), acc[i][0], 0, 0, 0);
+#endif
       GS_SB;
       if (slot == 6 || slot == 8 || slot == 11) {
         const int pl = slot == 6 ? 2 : slot == 8 ? 1 : 0;
@@ -195,9 +201,13 @@ __device__ __forceinline__ void gemm_mainloop_split(const GemmParams& p, float* 
               arow_l + pl * PLANE_B + 32 * ii * FT_PLANE_ROW_B + 32);
       }
       if (more) {
+#ifndef GA_GABL_NOSTORE
         if (slot == 2) store_quads(s + 1, qc);
+#endif
+#ifndef GA_GABL_NOFETCH
         if (slot == 11) fetch_planes(s + 1, 0);
         if (slot == 23) fetch_planes(s + 1, 1);
+#endif
       }
       GS_SB;
     }
