@@ -252,9 +252,16 @@ def test_backward_pass_keeps_its_bits_next_to_bf16_mfmas():
     d = net.dout_view(M)
     d.copy_(torch.randn(d.shape, device=dev) * 0.01)
 
+    dval = d.clone()
+
     def slabs():
+        # (forward too: the first layer's streaming kernel keeps packed FMAs with the
+        # swizzles that tested clean, and this holds them to it)
+        out = net.forward(X, M, keep_acts=True).clone()
+        acts = net._acts[:2 * M * 256].clone()
+        d.copy_(dval)
         net.backward(X, M, d)
-        return net._slabs.clone()
+        return torch.cat([net._slabs.flatten(), out.flatten(), acts])
 
     ref = slabs()
     torch.cuda.synchronize()
