@@ -41,10 +41,11 @@ mfma-peak: tools/mfma_peak.hip
 
 # developer tools: does vector work hide behind MFMAs (fp32: no, bf16: yes), and the
 # packed-fp32 / bf16-MFMA hazard reproducer
-mfma-tools: tools/mfma_valu_overlap.hip tools/mfma_valu_hazard.hip
+mfma-tools: tools/mfma_valu_overlap.hip tools/mfma_valu_hazard.hip tools/mfma_rounding.hip
 	@mkdir -p $(OUT)
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -Wno-unused-result -Wno-unused-value tools/mfma_valu_overlap.hip -o $(OUT)/mfma_valu_overlap
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -Wno-unused-result -Wno-unused-value tools/mfma_valu_hazard.hip -o $(OUT)/mfma_valu_hazard
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -Wno-unused-result -Wno-unused-value tools/mfma_rounding.hip -o $(OUT)/mfma_rounding
 
 # the library WITH hipcc's SLP vectorizer (packed fp32, the hazardous form included):
 # only for tools/hazard_repro_backward.py
@@ -56,7 +57,7 @@ slp-variant:
 	rm -rf $(OUT)/variants/slp
 
 clean:
-	rm -rf $(OUT)/*.o $(OUT)/*.so $(OUT)/mfma_peak $(OUT)/mfma_valu_overlap $(OUT)/mfma_valu_hazard $(OUT)/variants
+	rm -rf $(OUT)/*.o $(OUT)/*.so $(OUT)/mfma_peak $(OUT)/mfma_valu_overlap $(OUT)/mfma_valu_hazard $(OUT)/mfma_rounding $(OUT)/variants
 
 .PHONY: all clean mfma-peak mfma-tools slp-variant
 
