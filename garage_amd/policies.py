@@ -481,6 +481,12 @@ class CategoricalMLPPolicy(_GaussianMLP):
     cast to float for the update exactly like ``torch.Tensor(eps.actions)``
     (``vpg.py:163``).  Parameter names reuse the Gaussian module's scheme
     (``_module._mean_module._layers.{i}.linear.{weight,bias}`` ...).
+
+    Parity: pinned against the reference's ``CategoricalCNNPolicy`` configured as
+    an MLP (one 1 x 1 convolution over a ``(O, 1, 1)`` observation is a dense
+    layer) through two real ``PPO`` / ``VPG._train_once`` iterations per case
+    (``tests/golden/train_once_categorical.npz``,
+    ``tests/test_ppo_gpu.py::test_categorical_train_once_matches_real_reference``).
     """
 
     kind = 'categorical'

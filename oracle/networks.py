@@ -177,7 +177,10 @@ def categorical_dist(params, prefix, x, double_softmax=True):
     The only torch categorical policies in the reference feed
     ``softmax(net(x))`` to ``Categorical(logits=...)``
     (``categorical_cnn_policy.py:138-139``); ``double_softmax=True`` keeps that
-    convention, ``False`` treats the MLP output as logits.
+    convention, ``False`` treats the MLP output as logits.  Pinned by the
+    real ``CategoricalCNNPolicy`` configured as an MLP
+    (``tests/golden/train_once_categorical.npz``,
+    ``tests/test_oracle_golden.py::test_golden_categorical_train_once``).
     """
     out = mlp_mean(params, prefix, x)
     if double_softmax:

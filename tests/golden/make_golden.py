@@ -493,6 +493,137 @@ def gen_train_once():
     save('train_once', **out)
 
 
+def _ref_categorical_policy(O, n_act, P, hs):
+    """The reference's only torch categorical policy, ``CategoricalCNNPolicy``
+    (``torch/policies/categorical_cnn_policy.py``), over a ``(O, 1, 1)`` "image"
+    with ONE 1 x 1 convolution of ``hs[0]`` channels followed by its MLP with
+    the remaining hidden sizes: a 1 x 1 convolution of a 1 x 1 image is a dense
+    layer, so this real class IS a tanh MLP(hs) with the reference's head
+    (``Categorical(logits=softmax(scores))``, ``:138-139``)."""
+    from garage.torch.policies import CategoricalCNNPolicy
+    spec = EnvSpec(akro.Box(-np.inf, np.inf, (O, 1, 1)), akro.Discrete(n_act),
+                   max_episode_length=P)
+    pol = CategoricalCNNPolicy(spec, image_format='NCHW', kernel_sizes=(1, ),
+                               hidden_channels=(hs[0], ), strides=1,
+                               hidden_sizes=tuple(hs[1:]))
+    return spec, pol
+
+
+def _categorical_batch(rng, spec, lens, O, n_act):
+    S = int(np.sum(lens))
+    st = []
+    for L in lens:
+        t = [StepType.MID] * L
+        t[0] = StepType.FIRST
+        t[-1] = (StepType.TIMEOUT
+                 if L == spec.max_episode_length else StepType.TERMINAL)
+        st += t
+    # observations travel FLAT ((S, O): the value function's input, accepted by
+    # check_timestep_batch through the flat dimension, _dtypes.py:980-999); the
+    # policy reshapes them itself (categorical_cnn_policy.py:133-134)
+    return EpisodeBatch(
+        env_spec=spec, episode_infos={},
+        observations=rng.randn(S, O).astype(np.float32),
+        last_observations=rng.randn(len(lens), O).astype(np.float32),
+        actions=rng.randint(0, n_act, size=S).astype(np.int64),
+        rewards=rng.randn(S),
+        env_infos={}, agent_infos={},
+        step_types=np.asarray(st, dtype=StepType),
+        lengths=np.asarray(lens, dtype='l'))
+
+
+def gen_train_once_categorical():
+    """The categorical head through the REAL ``PPO`` / ``VPG._train_once`` with
+    the REAL ``CategoricalCNNPolicy`` configured as an MLP (see
+    ``_ref_categorical_policy``), plus its forward distribution at fixed inputs.
+    (``entropy_method='max'`` is not a case: the reference adds the (N*P,)
+    entropies of this policy to (N, P) rewards, ``vpg.py:158-160``, and raises.)"""
+    cases = [
+        dict(tag='ppo', algo='ppo', kw={}, O=4, n_act=2, hs=(8, 8)),
+        dict(tag='ppo_reg', algo='ppo', O=4, n_act=2, hs=(8, 8),
+             kw=dict(entropy_method='regularized', policy_ent_coeff=0.02)),
+        dict(tag='ppo_pos3', algo='ppo', kw=dict(positive_adv=True),
+             O=5, n_act=3, hs=(16, 12)),
+        dict(tag='vpg', algo='vpg', kw={}, O=4, n_act=2, hs=(8, 8)),
+        dict(tag='ppo_full', algo='ppo', kw={}, mb=None, O=4, n_act=2,
+             hs=(8, 8)),
+        # C2's widths (BASELINE.json configs[1]: obs 4, 2 actions, MLP(64, 64))
+        dict(tag='ppo_c2', algo='ppo', kw={}, O=4, n_act=2, hs=(64, 64),
+             mb=16, P=16, lens=([16, 3, 9, 16, 1, 12, 16, 7],
+                                [5, 16, 16, 2, 11])),
+    ]
+    out = {}
+    for case in cases:
+        tag = case['tag']
+        O, n_act, hs = case['O'], case['n_act'], case['hs']
+        P = case.get('P', 8)
+        E, mb = 2, case.get('mb', 5)
+        torch.manual_seed(13)
+        rng = np.random.RandomState(13)
+        spec, pol = _ref_categorical_policy(O, n_act, P, hs)
+        vf = GaussianMLPValueFunction(spec, hidden_sizes=hs)
+        with torch.no_grad():
+            for p in list(pol.parameters()) + list(vf.parameters()):
+                p.add_(torch.randn_like(p) * 0.3)
+        out.update(state_arrays(tag + '_pol0:', pol))
+        out.update(state_arrays(tag + '_vf0:', vf))
+        # forward distribution of the initial policy at fixed inputs
+        obs = torch.Tensor(rng.randn(23, O))
+        act = torch.Tensor(rng.randint(0, n_act, size=23))
+        with torch.no_grad():
+            dist, info = pol(obs)
+            assert info == {}
+            out[tag + '_fwd_obs'] = obs.numpy()
+            out[tag + '_fwd_act'] = act.numpy()
+            out[tag + '_fwd_probs'] = dist.probs.numpy()
+            out[tag + '_fwd_log_prob'] = dist.log_prob(act).numpy()
+            out[tag + '_fwd_entropy'] = dist.entropy().numpy()
+        cls = PPO if case['algo'] == 'ppo' else VPG
+        algo = cls(env_spec=spec, policy=pol, value_function=vf, sampler=None,
+                   policy_optimizer=OptimizerWrapper(
+                       (torch.optim.Adam, dict(lr=1e-3)), pol,
+                       max_optimization_epochs=E, minibatch_size=mb),
+                   vf_optimizer=OptimizerWrapper(
+                       (torch.optim.Adam, dict(lr=1e-3)), vf,
+                       max_optimization_epochs=E, minibatch_size=mb),
+                   **case['kw'])
+        rec = ref.TabularRecorder()
+        vpg_mod.tabular = rec
+        gfun.tabular = rec
+        all_lens = case.get('lens', ([8, 3, 5, 8, 1, 6], [2, 8, 7, 4]))
+        for it in range(2):
+            eps = _categorical_batch(rng, spec, list(all_lens[it]), O, n_act)
+            np.random.seed(300 + it)
+            avg_ret = algo._train_once(it, eps)
+            pre = '%s_it%d_' % (tag, it)
+            out[pre + 'observations'] = eps.observations
+            out[pre + 'actions'] = eps.actions
+            out[pre + 'rewards'] = eps.rewards
+            out[pre + 'lengths'] = eps.lengths
+            out[pre + 'step_types'] = np.asarray(
+                [int(s) for s in eps.step_types])
+            out[pre + 'np_seed'] = np.asarray(300 + it)
+            out[pre + 'avg_return'] = np.asarray(avg_ret)
+            for k, v in rec.values.items():
+                out[pre + 'log:' + k] = np.asarray(v)
+            out.update(state_arrays(pre + 'pol:', pol))
+            out.update(state_arrays(pre + 'vf:', vf))
+            for name, opt in (('pol', algo._policy_optimizer._optimizer),
+                              ('vf', algo._vf_optimizer._optimizer)):
+                for j, p in enumerate(opt.param_groups[0]['params']):
+                    st = opt.state[p]
+                    out['%sadam_%s_%d_m' % (pre, name, j)] = \
+                        st['exp_avg'].numpy().copy()
+                    out['%sadam_%s_%d_v' % (pre, name, j)] = \
+                        st['exp_avg_sq'].numpy().copy()
+                    out['%sadam_%s_%d_step' % (pre, name, j)] = \
+                        np.asarray(float(st['step']))
+        out[tag + '_cfg'] = np.asarray([O, n_act, P, E,
+                                        -1 if mb is None else mb])
+        out[tag + '_hidden'] = np.asarray(hs)
+    save('train_once_categorical', **out)
+
+
 def gen_trpo():
     """Section 8(f).1: ``_train_once`` through the real TRPO +
     ConjugateGradientOptimizer (``torch/algos/trpo.py``,
@@ -1162,6 +1293,7 @@ if __name__ == '__main__':
     gen_networks()
     gen_compute_advantage()
     gen_train_once()
+    gen_train_once_categorical()
     gen_normalized_env()
     gen_normalized_env_actions()
     gen_log_performance()

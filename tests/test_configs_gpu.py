@@ -18,8 +18,11 @@ the three GPU configurations gets
   (b) the size-independent properties of ``test_fullsize_gpu.py`` at the full size:
       exact zeros, gradient additivity over the minibatches, bitwise
       reproducibility on both schedules.
-The categorical head has no torch counterpart in the reference:
-C2's parity is against the oracle only -- "parity unpinned" against garage itself.
+The reference has no torch ``CategoricalMLPPolicy``; the categorical
+head is pinned against the reference's ``CategoricalCNNPolicy`` configured as an MLP
+(``test_ppo_gpu.py::test_categorical_train_once_matches_real_reference``, incl. C2's
+widths), and C2's full-shape iterations here are against the oracle, itself held to
+the same fixture on the CPU.
 """
 import numpy as np
 import pytest

@@ -428,6 +428,64 @@ def test_golden_train_once(golden, tag):
                                    atol=1e-9)
 
 
+@pytest.mark.parametrize('tag', sorted(__import__('_categorical_golden').CASES))
+def test_golden_categorical_train_once(golden, tag):
+    """The categorical head against the REAL reference: two ``_train_once``
+    iterations of the real PPO / VPG on the real ``CategoricalCNNPolicy``
+    configured as an MLP (tests/_categorical_golden.py), and its forward
+    distribution at fixed inputs."""
+    import _categorical_golden as cg
+    g = golden('train_once_categorical')
+    O, n_act, P, E, mb = [int(v) for v in g[tag + '_cfg']]
+    kw = dict(cg.CASES[tag])
+    kw['algo'] = 'vpg' if tag == 'vpg' else 'ppo'
+    if kw['algo'] == 'vpg':
+        kw.setdefault('gae_lambda', 1)
+    pol0 = cg.policy_params(g, tag + '_pol0:')
+    with torch.no_grad():
+        dist = nets.categorical_dist(pol0, nets.POLICY_PREFIX,
+                                     torch.from_numpy(g[tag + '_fwd_obs']))
+        act = torch.from_numpy(g[tag + '_fwd_act'])
+        assert np.allclose(dist.probs, g[tag + '_fwd_probs'], atol=1e-6)
+        assert np.allclose(dist.log_prob(act), g[tag + '_fwd_log_prob'],
+                           atol=1e-6)
+        assert np.allclose(dist.entropy(), g[tag + '_fwd_entropy'], atol=1e-6)
+    algo = OraclePPO(pol0, cg.value_params(g, tag + '_vf0:'),
+                     max_episode_length=P, policy_kind='categorical',
+                     max_optimization_epochs=E,
+                     minibatch_size=None if mb < 0 else mb,
+                     policy_lr=1e-3, vf_lr=1e-3, **kw)
+    for it in range(2):
+        pre = '%s_it%d_' % (tag, it)
+        lens = g[pre + 'lengths']
+        b = ob.OracleEpisodeBatch(
+            observations=g[pre + 'observations'],
+            last_observations=np.zeros((len(lens), O), np.float32),
+            actions=g[pre + 'actions'], rewards=g[pre + 'rewards'],
+            step_types=g[pre + 'step_types'], lengths=lens,
+            max_episode_length=P)
+        np.random.seed(int(g[pre + 'np_seed']))
+        out = algo.train_once(b)
+        for mine, theirs in cg.LOG_KEYS.items():
+            assert np.isclose(out[mine], float(g[pre + 'log:' + theirs]),
+                              atol=1e-5, rtol=1e-5), (mine, it)
+        assert np.isclose(out['average_return'], float(g[pre + 'avg_return']))
+        pol, vf = algo.state()
+        want = cg.policy_params(g, pre + 'pol:')
+        assert sorted(pol) == sorted(want)
+        for k, v in pol.items():
+            assert np.allclose(v, want[k], atol=1e-6), k
+        for k, v in vf.items():
+            assert np.allclose(v, g[pre + 'vf:' + k], atol=1e-6), k
+        for which, name in (('policy', 'pol'), ('vf', 'vf')):
+            for j, (step, m, v) in enumerate(algo.adam_state(which)):
+                assert step == int(g['%sadam_%s_%d_step' % (pre, name, j)])
+                assert np.allclose(m, cg.flat(
+                    g['%sadam_%s_%d_m' % (pre, name, j)]), atol=1e-7)
+                assert np.allclose(v, cg.flat(
+                    g['%sadam_%s_%d_v' % (pre, name, j)]), atol=1e-9)
+
+
 def test_golden_normalized_env(golden):
     g = golden('normalized_env')
     norm = osamp.NormalizedObs(3, float(g['alpha']))

@@ -315,9 +315,10 @@ def test_full_iteration_vs_oracle():
 
 
 # ---------------------------------------------------------------------------
-# categorical head (no torch CategoricalMLPPolicy exists in the reference:
-# parity here is against the oracle's torch.distributions.Categorical
-# restatement of the reference's torch categorical convention)
+# categorical head (no torch CategoricalMLPPolicy exists in the reference,
+# the tests against the oracle's torch.distributions.Categorical
+# restatement come first, then the one against the reference's own
+# CategoricalCNNPolicy configured as an MLP, train_once_categorical.npz)
 def _discrete_spec(O, n_act, P):
     from garage_amd._dtypes import Box, Discrete, EnvSpec
     return EnvSpec(Box(-np.inf, np.inf, (O, )), Discrete(n_act),
@@ -444,6 +445,83 @@ def test_categorical_iteration_vs_oracle(kw):
             assert np.allclose(v.numpy(), wp[k], atol=1e-5), k
         for k, v in vf.state_dict().items():
             assert np.allclose(v.numpy(), wv[k], atol=1e-5), k
+
+
+@pytest.mark.parametrize('tag', sorted(__import__('_categorical_golden').CASES))
+def test_categorical_train_once_matches_real_reference(golden, tag):
+    """The categorical head against the REAL reference (not only the oracle):
+    two ``_train_once`` iterations of the real PPO / VPG on the reference's torch
+    categorical policy, ``CategoricalCNNPolicy`` configured as an MLP (a 1 x 1
+    convolution of a 1 x 1 image is a dense layer; tests/_categorical_golden.py,
+    ``categorical_cnn_policy.py:115-140``): forward distribution, 9 logged
+    scalars, post-update parameters and Adam moments; ``ppo_c2`` has C2's
+    widths (obs 4, 2 actions, MLP(64, 64))."""
+    import _categorical_golden as cg
+    from garage_amd.algos import PPO, VPG
+    from garage_amd.optimizers import OptimizerWrapper
+    from garage_amd.policies import (CategoricalMLPPolicy,
+                                     GaussianMLPValueFunction)
+    g = golden('train_once_categorical')
+    O, n_act, P, E, mb = [int(v) for v in g[tag + '_cfg']]
+    mb = None if mb < 0 else mb
+    hidden = tuple(int(h) for h in g[tag + '_hidden'])
+    spec = _discrete_spec(O, n_act, P)
+    pol = CategoricalMLPPolicy(spec, hidden_sizes=hidden)
+    vf = GaussianMLPValueFunction(spec, hidden_sizes=hidden)
+    pol.load_state_dict(cg.policy_params(g, tag + '_pol0:'))
+    vf.load_state_dict(_sd(g, tag + '_vf0:'))
+    with torch.no_grad():
+        dist, info = pol(torch.from_numpy(g[tag + '_fwd_obs']))
+        act = torch.from_numpy(g[tag + '_fwd_act']).to(dist.probs.device)
+        assert info == {}
+        assert np.allclose(dist.probs.cpu(), g[tag + '_fwd_probs'], atol=1e-6)
+        assert np.allclose(dist.log_prob(act).cpu(), g[tag + '_fwd_log_prob'],
+                           atol=2e-6)
+        assert np.allclose(dist.entropy().cpu(), g[tag + '_fwd_entropy'],
+                           atol=2e-6)
+    cls = VPG if tag == 'vpg' else PPO
+    algo = cls(env_spec=spec, policy=pol, value_function=vf, sampler=None,
+               policy_optimizer=OptimizerWrapper(
+                   (torch.optim.Adam, dict(lr=1e-3)), pol,
+                   max_optimization_epochs=E, minibatch_size=mb),
+               vf_optimizer=OptimizerWrapper(
+                   (torch.optim.Adam, dict(lr=1e-3)), vf,
+                   max_optimization_epochs=E, minibatch_size=mb),
+               **cg.CASES[tag])
+    for it in range(2):
+        pre = '%s_it%d_' % (tag, it)
+        batch = _host_batch(spec, g, pre, O)
+        assert batch.actions.dtype == np.int64 and batch.actions.ndim == 1
+        np.random.seed(int(g[pre + 'np_seed']))
+        avg = algo._train_once(it, batch)
+        for mine, theirs in cg.LOG_KEYS.items():
+            want = float(g[pre + 'log:' + theirs])
+            assert np.isclose(algo.last_tabular[mine], want, atol=1e-5,
+                              rtol=1e-5), (mine, it, algo.last_tabular[mine],
+                                           want)
+        assert np.isclose(avg, float(g[pre + 'avg_return']))
+        for k, v in algo.last_performance.items():
+            assert np.isclose(v, float(g[pre + 'log:Evaluation/' + k])), k
+        want_pol = cg.policy_params(g, pre + 'pol:')
+        assert sorted(pol.state_dict()) == sorted(want_pol)
+        for k, v in pol.state_dict().items():
+            assert np.allclose(v.numpy(), want_pol[k].numpy(), atol=2e-6), k
+        for k, v in vf.state_dict().items():
+            assert np.allclose(v.numpy(), g[pre + 'vf:' + k], atol=2e-6), k
+        for name, net in (('pol', pol.net), ('vf', vf.net)):
+            # (named_views starts with the std slot, which this head lacks)
+            views_m = [mv for mv in net.named_views(net.exp_avg)
+                       if name == 'vf' or mv[0] != '_init_std']
+            views_v = [mv for mv in net.named_views(net.exp_avg_sq)
+                       if name == 'vf' or mv[0] != '_init_std']
+            for j, ((_, m), (_, v)) in enumerate(zip(views_m, views_v)):
+                gm = cg.flat(g['%sadam_%s_%d_m' % (pre, name, j)])
+                gv = cg.flat(g['%sadam_%s_%d_v' % (pre, name, j)])
+                assert np.allclose(m.cpu().numpy().reshape(gm.shape), gm,
+                                   atol=1e-6), (name, j)
+                assert np.allclose(v.cpu().numpy().reshape(gv.shape), gv,
+                                   atol=1e-8), (name, j)
+            assert net.adam_steps == int(g['%sadam_%s_0_step' % (pre, name)])
 
 
 def test_opt_in_fused_head_loss_iteration():
