@@ -650,8 +650,13 @@ int launch_gemm(const GemmParams& p_in, int splits, hipStream_t stream) {
     ga_prof_events(GA_PROF_GEMM_NT_128 + mode, flops, &e0, &e1);
     // 8 waves (64x32 each): two workgroups per CU put 4 waves on every SIMD, so
     // the matrix pipe has work while other waves sit at the barrier / vmcnt
+#ifdef GA_GEMM_BIG_BKT  // A/B builds (tools/build_variants.sh): k-tile depth of this shape
+    hipExtLaunchKernelGGL((gemm_f32_kernel<128, 128, 2, 4, A_KC, B_KC, GA_GEMM_BIG_BKT>),
+                          grid, dim3(512), 0, stream, e0, e1, 0, p);
+#else
     hipExtLaunchKernelGGL((gemm_f32_kernel<128, 128, 2, 4, A_KC, B_KC>), grid,
                           dim3(512), 0, stream, e0, e1, 0, p);
+#endif
   }
   GA_CHECK_LAUNCH("gemm_f32");
   return GA_OK;
