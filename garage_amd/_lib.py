@@ -132,6 +132,8 @@ SIGNATURES = {
     'ga_fisher_seed_gaussian_f32': (c_int, [ptr, c_i64, c_i64, c_int, ptr, c_int,
                                             c_f32, c_int, c_f32, ptr, c_i64,
                                             ptr]),
+    'ga_fisher_seed_categorical_f32': (c_int, [ptr, c_i64, ptr, c_i64, c_i64,
+                                               c_int, c_int, ptr, c_i64, ptr]),
     'ga_gemm_nt_f32': (c_int, [ptr, c_i64, ptr, c_i64, ptr, c_i64, c_i64,
                                c_i64, c_i64, ptr]),
     'ga_reduction_workspace_doubles': (c_i64, []),

@@ -951,10 +951,14 @@ class TRPO(VPG):
     backtracking line search.  The reference takes Hessian-vector products by
     double backward; here ``A v = J^T M (J v) + reg v`` with ``J v`` a tangent
     forward pass (``ga_mlp_jvp_f32``), ``M`` the Gaussian metric
-    (``ga_fisher_seed_gaussian_f32``) and ``J^T`` the ordinary backward pass --
+    (``ga_fisher_seed_gaussian_f32``) or, for ``CategoricalMLPPolicy``, the
+    categorical one through the head's softmaxes
+    (``ga_fisher_seed_categorical_f32``), and ``J^T`` the ordinary backward pass --
     the same matrix, because the step starts at the old policy's parameters,
     where the KL's gradient with respect to the distribution vanishes and its
-    Hessian is the Fisher matrix.
+    Hessian is the Fisher matrix.  Both heads are pinned by real TRPO iterations
+    of the reference with every conjugate-gradient product recorded
+    (``tests/golden/trpo_train_once.npz``, ``trpo_categorical.npz``).
     """
 
     def __init__(self,
@@ -993,9 +997,10 @@ class TRPO(VPG):
                          use_softplus_entropy=use_softplus_entropy,
                          stop_entropy_gradient=stop_entropy_gradient,
                          entropy_method=entropy_method)
-        if policy.kind != 'gaussian':
+        if policy.kind not in ('gaussian', 'categorical'):
             raise NotImplementedError(
-                'garage_amd.algos.TRPO implements the Gaussian MLP policy')
+                'garage_amd.algos.TRPO implements the Gaussian and the '
+                'categorical MLP policy')
         hyper = self._policy_optimizer._hyper
         if hyper.get('kind') != 'cg':
             raise NotImplementedError(
@@ -1080,10 +1085,19 @@ class TRPO(VPG):
         hyper = self._policy_optimizer._hyper
         tout = net.jvp(batch.obs_dev, M, vec)
         dout = net.dout_view(M)
-        has_min, mn, has_max, mx = pol._std_args()
-        call('ga_fisher_seed_gaussian_f32', dptr(tout), tout.stride(0), M,
-             net.out_dim, dptr(net.params[0:1]), has_min, mn, has_max, mx,
-             dptr(dout), dout.stride(0), stream_ptr())
+        if pol.kind == 'gaussian':
+            has_min, mn, has_max, mx = pol._std_args()
+            call('ga_fisher_seed_gaussian_f32', dptr(tout), tout.stride(0), M,
+                 net.out_dim, dptr(net.params[0:1]), has_min, mn, has_max, mx,
+                 dptr(dout), dout.stride(0), stream_ptr())
+        else:
+            # class scores of the forward pass the step started from (nothing
+            # runs a forward between it and the conjugate-gradient products)
+            scores = net.out_view(M)
+            call('ga_fisher_seed_categorical_f32', dptr(scores),
+                 scores.stride(0), dptr(tout), tout.stride(0), M, net.out_dim,
+                 int(pol.double_softmax), dptr(dout), dout.stride(0),
+                 stream_ptr())
         net.backward(batch.obs_dev, M, dout)
         # the seed divides by this rank's M: rescale to the global batch, then
         # sum the ranks' J^T M J v (vec is replicated, so every rank ends up
@@ -1096,10 +1110,13 @@ class TRPO(VPG):
         # = 2 A at s == s_old, through the clamp's pass-through gradient
         # (and the std parameterisation: log std = f(p) has d2 KL / dp2 =
         # f'(p)^2 d2 KL / ds2 there, the first derivative of the KL being zero)
-        chain = pol.log_std_of(float(net.params[0].item()))[1]
-        if not getattr(pol, '_learn_std', True):
-            chain = 0.0
-        g[0:1].copy_(vec[0:1] * (2.0 * net.out_dim * chain * chain))
+        if pol.kind == 'gaussian':
+            chain = pol.log_std_of(float(net.params[0].item()))[1]
+            if not getattr(pol, '_learn_std', True):
+                chain = 0.0
+            g[0:1].copy_(vec[0:1] * (2.0 * net.out_dim * chain * chain))
+        else:
+            g[0:1].zero_()  # the flat layout's std slot: not a parameter here
         out.copy_(g)
         call('ga_axpby_f32', float(hyper['hvp_reg_coeff']), dptr(vec), 1.0,
              dptr(out), out.numel(), stream_ptr())
@@ -1130,7 +1147,7 @@ class TRPO(VPG):
         s_old = pol.clamped_log_std()
         net.backward(batch.obs_dev, M, dout)
         net.reduce_grads(scale=share)
-        if not getattr(pol, '_learn_std', True):
+        if pol.kind != 'gaussian' or not getattr(pol, '_learn_std', True):
             net.grads[0:1].zero_()
         if self._comm is not None:
             self._comm.all_reduce(net.grads, 'sum')

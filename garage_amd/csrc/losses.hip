@@ -1183,6 +1183,59 @@ __global__ __launch_bounds__(256) void fisher_seed_kernel(
     dout[i * ldd + j] = (j < A) ? tmean[i * ldt + j] * scale : 0.f;
 }
 
+// Categorical metric seed of the Fisher-vector product (TRPO with the categorical
+// head).  With old == new the Hessian of mean_i KL(old || new) with respect to the
+// LOGITS l of Categorical(logits=l) is (diag(q) - q q^T) / M, q = softmax(l)
+// (the KL's gradient vanishes there, so no second-derivative term of the network
+// enters: conjugate_gradient_optimizer.py:18-66 differentiates the same KL twice).
+// The reference's head feeds l = softmax(scores) (categorical_cnn_policy.py:138-139,
+// double_softmax), whose Jacobian J1 = diag(z) - z z^T is symmetric, so with the
+// tangent t of the scores:
+//   u = J1 t,  w = (diag(q) - q q^T) u,  dout = J1 w / M      (J1 = I without it).
+// One thread per row, A <= 32 classes in registers.
+constexpr int FS_MAX_A = 32;
+__global__ __launch_bounds__(256) void fisher_seed_categorical_kernel(
+    const float* scores, int64_t lds, const float* tscores, int64_t ldt, int64_t M, int A,
+    int double_softmax, float* dout, int64_t ldd) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= M) return;
+  float z[FS_MAX_A], q[FS_MAX_A], u[FS_MAX_A];
+  float mx = scores[i * lds];
+  for (int j = 1; j < A; ++j) mx = fmaxf(mx, scores[i * lds + j]);
+  float den = 0.f;
+  for (int j = 0; j < A; ++j) {
+    z[j] = expf(scores[i * lds + j] - mx);
+    den += z[j];
+  }
+  for (int j = 0; j < A; ++j) z[j] /= den;
+  if (double_softmax) {
+    float den2 = 0.f;
+    for (int j = 0; j < A; ++j) {
+      q[j] = expf(z[j]);  // z in (0, 1]: no shift needed
+      den2 += q[j];
+    }
+    for (int j = 0; j < A; ++j) q[j] /= den2;
+    float zt = 0.f;
+    for (int j = 0; j < A; ++j) zt += z[j] * tscores[i * ldt + j];
+    for (int j = 0; j < A; ++j) u[j] = z[j] * (tscores[i * ldt + j] - zt);
+  } else {
+    for (int j = 0; j < A; ++j) {
+      q[j] = z[j];
+      u[j] = tscores[i * ldt + j];
+    }
+  }
+  float qu = 0.f;
+  for (int j = 0; j < A; ++j) qu += q[j] * u[j];
+  for (int j = 0; j < A; ++j) u[j] = q[j] * (u[j] - qu);  // w
+  const float inv_m = 1.f / (float)M;
+  if (double_softmax) {
+    float zw = 0.f;
+    for (int j = 0; j < A; ++j) zw += z[j] * u[j];
+    for (int j = 0; j < A; ++j) u[j] = z[j] * (u[j] - zw);
+  }
+  for (int j = 0; j < (int)ldd; ++j) dout[i * ldd + j] = (j < A) ? u[j] * inv_m : 0.f;
+}
+
 }  // namespace
 
 extern "C" int ga_dot_f32(const float* a, const float* b, int64_t n, double* out,
@@ -1213,6 +1266,21 @@ extern "C" int ga_fisher_seed_gaussian_f32(const float* tmean, int64_t ldt, int6
                      0, stream, tmean, ldt, M, A, log_std, has_min, min_log_std,
                      has_max, max_log_std, dout, ldd);
   GA_CHECK_LAUNCH("fisher_seed");
+  return GA_OK;
+}
+
+extern "C" int ga_fisher_seed_categorical_f32(const float* scores, int64_t lds,
+                                              const float* tscores, int64_t ldt,
+                                              int64_t M, int A, int double_softmax,
+                                              float* dout, int64_t ldd,
+                                              hipStream_t stream) {
+  GA_REQUIRE(scores && tscores && dout && M > 0 && A > 0 && A <= FS_MAX_A && lds >= A &&
+                 ldt >= A && ldd >= A,
+             "ga_fisher_seed_categorical_f32: bad arguments");
+  hipLaunchKernelGGL(fisher_seed_categorical_kernel, dim3((unsigned)ga_ceil_div(M, 256)),
+                     dim3(256), 0, stream, scores, lds, tscores, ldt, M, A, double_softmax,
+                     dout, ldd);
+  GA_CHECK_LAUNCH("fisher_seed_categorical");
   return GA_OK;
 }
 

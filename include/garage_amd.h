@@ -341,6 +341,15 @@ int ga_fisher_seed_gaussian_f32(const float* tmean, int64_t ldt, int64_t M, int 
                                 const float* log_std, int has_min, float min_log_std,
                                 int has_max, float max_log_std, float* dout,
                                 int64_t ldd, ga_stream_t stream);
+/* The same seed for the categorical head (TRPO with CategoricalMLPPolicy): the KL
+ * Hessian with respect to the class scores at old == new, applied to the scores'
+ * tangent -- J1 (diag(q) - q q^T) J1 tscores / M with q the class probabilities and J1
+ * the Jacobian of the inner softmax of the reference's head
+ * (torch/policies/categorical_cnn_policy.py:138-139; identity when double_softmax = 0).
+ * A <= 32. */
+int ga_fisher_seed_categorical_f32(const float* scores, int64_t lds, const float* tscores,
+                                   int64_t ldt, int64_t M, int A, int double_softmax,
+                                   float* dout, int64_t ldd, ga_stream_t stream);
 int ga_stats_f32(const float* x, int64_t n, int what, double* stats,
                  double* workspace, ga_stream_t stream);
 int ga_adv_center_f32(float* x, int64_t n, const double* stats, float eps,

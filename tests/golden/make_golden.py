@@ -744,6 +744,119 @@ def gen_trpo():
     save('trpo_train_once', **out)
 
 
+def gen_trpo_categorical():
+    """``gen_trpo`` for the categorical head: the real TRPO +
+    ConjugateGradientOptimizer on the real ``CategoricalCNNPolicy`` configured
+    as an MLP (``_ref_categorical_policy``), CG direction / every Hessian-vector
+    product / line-search candidates recorded."""
+    from garage.torch.algos import TRPO
+    import garage.torch.optimizers.conjugate_gradient_optimizer as cgo
+    cases = [
+        dict(tag='trpo', kw={}, delta=0.01, O=4, n_act=2, hs=(8, 8)),
+        dict(tag='trpo3', kw={}, delta=0.005, O=5, n_act=3, hs=(16, 12)),
+        dict(tag='trpo_reg', delta=0.01, O=4, n_act=2, hs=(8, 8),
+             kw=dict(entropy_method='regularized', policy_ent_coeff=0.02)),
+        # C2's widths (obs 4, 2 actions, MLP(64, 64))
+        dict(tag='trpo_c2', kw={}, delta=0.01, O=4, n_act=2, hs=(64, 64)),
+    ]
+    out = {}
+    for case in cases:
+        tag = case['tag']
+        O, n_act, hs, P = case['O'], case['n_act'], case['hs'], 8
+        E, mb = 2, 5
+        torch.manual_seed(17)
+        rng = np.random.RandomState(17)
+        spec, pol = _ref_categorical_policy(O, n_act, P, hs)
+        vf = GaussianMLPValueFunction(spec, hidden_sizes=hs)
+        with torch.no_grad():
+            for p in list(pol.parameters()) + list(vf.parameters()):
+                p.add_(torch.randn_like(p) * 0.1)
+        out.update(state_arrays(tag + '_pol0:', pol))
+        out.update(state_arrays(tag + '_vf0:', vf))
+        algo = TRPO(env_spec=spec, policy=pol, value_function=vf, sampler=None,
+                    policy_optimizer=OptimizerWrapper(
+                        (cgo.ConjugateGradientOptimizer,
+                         dict(max_constraint_value=case['delta'])), pol),
+                    vf_optimizer=OptimizerWrapper(
+                        (torch.optim.Adam, dict(lr=2.5e-4)), vf,
+                        max_optimization_epochs=E, minibatch_size=mb),
+                    **case['kw'])
+        rec = ref.TabularRecorder()
+        vpg_mod.tabular = rec
+        gfun.tabular = rec
+        trace = {}
+        real_cg = cgo._conjugate_gradient
+        real_ls = cgo.ConjugateGradientOptimizer._backtracking_line_search
+
+        def spy_cg(f_Ax, b, cg_iters, residual_tol=1e-10):
+            calls = []
+
+            def rec_Ax(vec):
+                z = f_Ax(vec)
+                calls.append((vec.detach().numpy().copy(),
+                              z.detach().numpy().copy()))
+                return z
+
+            x = real_cg(rec_Ax, b, cg_iters, residual_tol)
+            trace['grad'] = b.detach().numpy().copy()
+            trace['step_dir'] = x.detach().numpy().copy()
+            trace['Ax'] = f_Ax(x).detach().numpy().copy()
+            trace['iter_p'] = np.stack([c[0] for c in calls])
+            trace['iter_Ap'] = np.stack([c[1] for c in calls])
+            return x
+
+        def spy_ls(self, params, descent_step, f_loss, f_constraint):
+            trace['descent_step'] = descent_step.detach().numpy().copy()
+            losses, kls = [], []
+
+            def rec_loss():
+                v = f_loss()
+                losses.append(float(v.detach()))
+                return v
+
+            def rec_constraint():
+                v = f_constraint()
+                kls.append(float(v.detach()))
+                return v
+
+            res = real_ls(self, params, descent_step, rec_loss, rec_constraint)
+            trace['ls_loss'] = np.asarray(losses, dtype=np.float64)
+            trace['ls_constraint'] = np.asarray(kls, dtype=np.float64)
+            return res
+
+        cgo._conjugate_gradient = spy_cg
+        cgo.ConjugateGradientOptimizer._backtracking_line_search = spy_ls
+        try:
+            for it in range(2):
+                lens = [8, 3, 5, 8, 1, 6, 8, 7] if it == 0 else [2, 8, 7, 4, 8]
+                eps = _categorical_batch(rng, spec, lens, O, n_act)
+                np.random.seed(400 + it)
+                avg_ret = algo._train_once(it, eps)
+                pre = '%s_it%d_' % (tag, it)
+                out[pre + 'observations'] = eps.observations
+                out[pre + 'actions'] = eps.actions
+                out[pre + 'rewards'] = eps.rewards
+                out[pre + 'lengths'] = eps.lengths
+                out[pre + 'step_types'] = np.asarray(
+                    [int(s) for s in eps.step_types])
+                out[pre + 'np_seed'] = np.asarray(400 + it)
+                out[pre + 'avg_return'] = np.asarray(avg_ret)
+                for k, v in rec.values.items():
+                    out[pre + 'log:' + k] = np.asarray(v)
+                for k, v in trace.items():
+                    out[pre + 'cg:' + k] = v
+                out.update(state_arrays(pre + 'pol:', pol))
+                out.update(state_arrays(pre + 'vf:', vf))
+        finally:
+            cgo._conjugate_gradient = real_cg
+            cgo.ConjugateGradientOptimizer._backtracking_line_search = real_ls
+        out[tag + '_cfg'] = np.asarray([O, n_act, P, E, mb])
+        out[tag + '_hidden'] = np.asarray(hs)
+        out[tag + '_delta'] = np.asarray(case['delta'])
+        out[tag + '_max_backtracks'] = np.asarray(15)
+    save('trpo_categorical', **out)
+
+
 def gen_policy_options():
     """``GaussianMLPPolicy`` std options through two real PPO iterations:
     fixed std, an active max clamp, an active min clamp, a small learned std
@@ -1282,6 +1395,7 @@ if __name__ == '__main__':
             globals()['gen_' + name]()
         sys.exit(0)
     gen_trpo()
+    gen_trpo_categorical()
     gen_policy_options()
     gen_policy_activations()
     gen_train_once_optimizers()

@@ -671,6 +671,110 @@ def test_golden_trpo_per_iterate_pins(golden, tag):
                           rtol=1e-4), k
 
 
+TRPO_CATEGORICAL_CASES = {
+    'trpo': {},
+    'trpo3': {},
+    'trpo_reg': dict(entropy_method='regularized', policy_ent_coeff=0.02),
+    'trpo_c2': {},
+}
+
+
+def _categorical_trpo(g, tag):
+    import _categorical_golden as cg
+    from oracle.trpo import OracleTRPO
+    O, n_act, P, E, mb = [int(v) for v in g[tag + '_cfg']]
+    algo = OracleTRPO(cg.policy_params(g, tag + '_pol0:'),
+                      cg.value_params(g, tag + '_vf0:'),
+                      max_episode_length=P, policy_kind='categorical',
+                      max_constraint_value=float(g[tag + '_delta']),
+                      max_backtracks=int(g[tag + '_max_backtracks']),
+                      max_optimization_epochs=E, minibatch_size=mb,
+                      **TRPO_CATEGORICAL_CASES[tag])
+    return algo, O, P
+
+
+def _categorical_trpo_batch(g, pre, O, P):
+    lens = g[pre + 'lengths']
+    return ob.OracleEpisodeBatch(
+        observations=g[pre + 'observations'],
+        last_observations=np.zeros((len(lens), O), np.float32),
+        actions=g[pre + 'actions'], rewards=g[pre + 'rewards'],
+        step_types=g[pre + 'step_types'], lengths=lens, max_episode_length=P)
+
+
+@pytest.mark.parametrize('tag', sorted(TRPO_CATEGORICAL_CASES))
+def test_golden_trpo_categorical_train_once(golden, tag):
+    """Two real TRPO iterations on the reference's ``CategoricalCNNPolicy``
+    configured as an MLP (tests/_categorical_golden.py; ``gen_trpo_categorical``).
+
+    End to end this comparison is LOOSE by nature, looser than the Gaussian one:
+    class probabilities do not change when every score moves by the same amount,
+    so the KL Hessian of a softmax head has a null direction (the output biases
+    along (1, ..., 1)) that only ``hvp_reg_coeff`` = 1e-5 keeps finite, and ten
+    fp32 conjugate-gradient iterations amplify last-bit differences (here: the
+    reference's first layer is a 1 x 1 convolution, the oracle's a linear layer)
+    to 0.05-2 % of the direction.  The reference's run is one sample of that
+    noise.  What is tight is the gradient the iteration starts from, the number
+    of backtracking candidates, and ``test_golden_trpo_categorical_per_iterate_
+    pins`` below: every operation at the reference's own iterates, 1e-5."""
+    import _categorical_golden as cg
+    g = golden('trpo_categorical')
+    algo, O, P = _categorical_trpo(g, tag)
+    for it in range(2):
+        pre = '%s_it%d_' % (tag, it)
+        np.random.seed(int(g[pre + 'np_seed']))
+        out = algo.train_once(_categorical_trpo_batch(g, pre, O, P))
+        tr = algo.cg.trace
+        if it == 0:
+            assert np.allclose(tr['grad'], g[pre + 'cg:grad'], atol=1e-6)
+            assert tr['accepted'] + 1 == len(g[pre + 'cg:ls_constraint'])
+        loose = 3e-2 if it == 0 else 6e-2
+        scale = np.abs(g[pre + 'cg:step_dir']).max()
+        assert np.allclose(tr['step_dir'], g[pre + 'cg:step_dir'],
+                           atol=loose * scale)
+        dscale = np.abs(g[pre + 'cg:descent_step']).max()
+        assert np.allclose(tr['descent_step'], g[pre + 'cg:descent_step'],
+                           atol=loose * dscale)
+        for mine, theirs in cg.LOG_KEYS.items():
+            assert np.isclose(out[mine], float(g[pre + 'log:' + theirs]),
+                              atol=2e-4 if it == 0 else 1e-3,
+                              rtol=5e-2), (mine, it)
+        pol, vf = algo.state()
+        want = cg.policy_params(g, pre + 'pol:')
+        for k, v in pol.items():
+            assert np.allclose(v, want[k], atol=loose * dscale), k
+        for k, v in vf.items():
+            assert np.allclose(v, g[pre + 'vf:' + k], atol=1e-6), k
+
+
+@pytest.mark.parametrize('tag', sorted(TRPO_CATEGORICAL_CASES))
+def test_golden_trpo_categorical_per_iterate_pins(golden, tag):
+    """Every Hessian-vector product and line-search candidate of the real run,
+    each at one-operation accuracy (see ``test_golden_trpo_per_iterate_pins``)."""
+    g = golden('trpo_categorical')
+    algo, O, P = _categorical_trpo(g, tag)
+    pre = tag + '_it0_'
+    algo.cg.probe_vectors = g[pre + 'cg:iter_p']
+    algo.cg.probe_descent = g[pre + 'cg:descent_step']
+    algo.cg.probe_candidates = len(g[pre + 'cg:ls_constraint'])
+    np.random.seed(int(g[pre + 'np_seed']))
+    algo.train_once(_categorical_trpo_batch(g, pre, O, P))
+    tr = algo.cg.trace
+    want = g[pre + 'cg:iter_Ap']
+    assert tr['probe_Ax'].shape == want.shape and len(want) == 10
+    for k in range(len(want)):
+        scale = np.abs(want[k]).max()
+        assert np.allclose(tr['probe_Ax'][k], want[k], atol=1e-5 * scale,
+                           rtol=1e-5), k
+    ls = tr['probe_ls']
+    assert np.isclose(ls[0], g[pre + 'cg:ls_loss'][0], atol=1e-7)
+    for k, (loss, kl) in enumerate(ls[1:]):
+        assert np.isclose(loss, g[pre + 'cg:ls_loss'][k + 1], atol=1e-6,
+                          rtol=1e-5), k
+        assert np.isclose(kl, g[pre + 'cg:ls_constraint'][k], atol=1e-7,
+                          rtol=1e-4), k
+
+
 POLICY_OPTION_CASES = ['fixed_std', 'init_small', 'max_clamp', 'min_clamp']
 
 

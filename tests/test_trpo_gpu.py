@@ -241,6 +241,236 @@ def test_fisher_vector_product_matches_double_backward(options):
                        rtol=1e-4)
 
 
+# ---------------------------------------------------------------------------
+# TRPO with the categorical head, against the real reference: TRPO +
+# ConjugateGradientOptimizer on CategoricalCNNPolicy configured as an MLP
+# (tests/_categorical_golden.py, tests/golden/trpo_categorical.npz)
+TRPO_CATEGORICAL_CASES = {
+    'trpo': {},
+    'trpo3': {},
+    'trpo_reg': dict(entropy_method='regularized', policy_ent_coeff=0.02),
+    'trpo_c2': {},
+}
+
+
+def _views_no_std(net, buf):
+    return [v for k, v in net.named_views(buf) if k != '_init_std']
+
+
+def _flat_no_pad_cat(net, buf):
+    return np.concatenate([v.detach().cpu().numpy().reshape(-1)
+                           for v in _views_no_std(net, buf)])
+
+
+def _to_padded_cat(net, flat):
+    buf = torch.zeros(net.n_flat, dtype=torch.float32, device=net.device)
+    off = 0
+    for v in _views_no_std(net, buf):
+        n = v.numel()
+        v.copy_(torch.from_numpy(
+            np.ascontiguousarray(flat[off:off + n], dtype=np.float32)
+        ).reshape(v.shape))
+        off += n
+    assert off == len(flat)
+    return buf
+
+
+def _make_categorical(g, tag, **kw):
+    import _categorical_golden as cg
+    from garage_amd.algos import TRPO
+    from garage_amd.optimizers import (ConjugateGradientOptimizer,
+                                       OptimizerWrapper)
+    from garage_amd.policies import (CategoricalMLPPolicy,
+                                     GaussianMLPValueFunction)
+    from test_ppo_gpu import _discrete_spec
+    O, n_act, P, E, mb = [int(v) for v in g[tag + '_cfg']]
+    hidden = tuple(int(h) for h in g[tag + '_hidden'])
+    spec = _discrete_spec(O, n_act, P)
+    pol = CategoricalMLPPolicy(spec, hidden_sizes=hidden)
+    vf = GaussianMLPValueFunction(spec, hidden_sizes=hidden)
+    pol.load_state_dict(cg.policy_params(g, tag + '_pol0:'))
+    vf.load_state_dict(_sd(g, tag + '_vf0:'))
+    algo = TRPO(env_spec=spec, policy=pol, value_function=vf, sampler=None,
+                policy_optimizer=OptimizerWrapper(
+                    (ConjugateGradientOptimizer,
+                     dict(max_constraint_value=float(g[tag + '_delta']),
+                          max_backtracks=int(g[tag + '_max_backtracks']))),
+                    pol),
+                vf_optimizer=OptimizerWrapper(
+                    (torch.optim.Adam, dict(lr=2.5e-4)), vf,
+                    max_optimization_epochs=E, minibatch_size=mb),
+                **kw)
+    return spec, pol, vf, algo, O
+
+
+@pytest.mark.parametrize('tag', sorted(TRPO_CATEGORICAL_CASES))
+def test_trpo_categorical_per_iterate_pins_against_real_reference(golden, tag):
+    """The categorical metric (``ga_fisher_seed_categorical_f32``) inside
+    ``A p_k = J^T M J p_k + reg p_k`` for each of the ten directions the real
+    ``_conjugate_gradient`` visited on the reference's categorical policy, and
+    (loss, constraint) of every backtracking candidate of its real descent step
+    -- each at one-operation fp32 accuracy (the end-to-end comparison of a
+    softmax head is loose by nature, see the test below)."""
+    g = golden('trpo_categorical')
+    spec, pol, vf, algo, O = _make_categorical(
+        g, tag, **TRPO_CATEGORICAL_CASES[tag])
+    pre = tag + '_it0_'
+    batch = _host_batch(spec, g, pre, O)
+    net = pol.net
+    seen = {}
+    real_train = algo._train
+
+    def probing_train(dbatch, adv, returns, old_ll):
+        M = dbatch.n_samples
+        hyper = algo._policy_optimizer._hyper
+        algo._trpo_share = 1.0
+        loss0, head_old, dout = algo._policy_loss_pass(dbatch, adv, old_ll, M,
+                                                       None, want_grad=True)
+        head_old = head_old.clone()
+        z = torch.empty(net.n_flat, dtype=torch.float32, device=net.device)
+        got = []
+        for p_k in g[pre + 'cg:iter_p']:
+            algo._fisher_vector_product(dbatch, M, _to_padded_cat(net, p_k), z)
+            got.append(_flat_no_pad_cat(net, z))
+        seen['Ap'] = np.stack(got)
+        prev = net.params.clone()
+        descent = _to_padded_cat(net, g[pre + 'cg:descent_step'])
+        ls = [float(loss0.item())]
+        for k in range(len(g[pre + 'cg:ls_constraint'])):
+            net.params.copy_(prev - float(hyper['backtrack_ratio'])**k * descent)
+            l_new, head_new, _ = algo._policy_loss_pass(dbatch, adv, old_ll, M,
+                                                        None)
+            kl = algo._kl_sum(head_old, 0.0, head_new, 0.0, M)
+            ls.append((float(l_new.item()), float(kl.item()) / M))
+        net.params.copy_(prev)
+        seen['ls'] = ls
+        return real_train(dbatch, adv, returns, old_ll)
+
+    algo._train = probing_train
+    np.random.seed(int(g[pre + 'np_seed']))
+    algo._train_once(0, batch)
+    want = g[pre + 'cg:iter_Ap']
+    assert seen['Ap'].shape == want.shape and len(want) == 10
+    for k in range(len(want)):
+        scale = np.abs(want[k]).max()
+        assert np.allclose(seen['Ap'][k], want[k], atol=1e-5 * scale,
+                           rtol=1e-5), (k, np.abs(seen['Ap'][k] - want[k]).max(),
+                                        scale)
+    ls = seen['ls']
+    assert np.isclose(ls[0], g[pre + 'cg:ls_loss'][0], atol=2e-7)
+    for k, (loss, kl) in enumerate(ls[1:]):
+        assert np.isclose(loss, g[pre + 'cg:ls_loss'][k + 1], atol=1e-6,
+                          rtol=1e-5), (k, loss)
+        assert np.isclose(kl, g[pre + 'cg:ls_constraint'][k], atol=1e-7,
+                          rtol=1e-4), (k, kl)
+
+
+@pytest.mark.parametrize('tag', sorted(TRPO_CATEGORICAL_CASES))
+def test_trpo_categorical_train_once_matches_real_reference(golden, tag):
+    """Two whole iterations.  Loose by nature (the tolerances of the oracle's own
+    test against this fixture, ``test_golden_trpo_categorical_train_once``): the
+    KL Hessian of a softmax head has the null direction "every score + c", kept
+    finite only by ``hvp_reg_coeff``, and ten fp32 CG iterations amplify last-bit
+    differences to 0.05-2 % of the direction; the starting gradient and the
+    number of backtracking candidates are tight."""
+    import _categorical_golden as cg
+    g = golden('trpo_categorical')
+    spec, pol, vf, algo, O = _make_categorical(
+        g, tag, **TRPO_CATEGORICAL_CASES[tag])
+    for it in range(2):
+        pre = '%s_it%d_' % (tag, it)
+        batch = _host_batch(spec, g, pre, O)
+        np.random.seed(int(g[pre + 'np_seed']))
+        algo._train_once(it, batch)
+        last = algo.last_cg
+        if it == 0:
+            grad = _flat_no_pad_cat(pol.net, last['grad'])
+            assert np.allclose(grad, g[pre + 'cg:grad'], atol=2e-6)
+            assert last['accepted'] + 1 == len(g[pre + 'cg:ls_constraint'])
+        loose = 3e-2 if it == 0 else 6e-2
+        sd = _flat_no_pad_cat(pol.net, last['step_dir'])
+        scale = np.abs(g[pre + 'cg:step_dir']).max()
+        assert np.allclose(sd, g[pre + 'cg:step_dir'], atol=loose * scale)
+        ds = _flat_no_pad_cat(pol.net, last['descent_step'])
+        dscale = np.abs(g[pre + 'cg:descent_step']).max()
+        assert np.allclose(ds, g[pre + 'cg:descent_step'], atol=loose * dscale)
+        for mine, theirs in cg.LOG_KEYS.items():
+            want = float(g[pre + 'log:' + theirs])
+            assert np.isclose(algo.last_tabular[mine], want,
+                              atol=2e-4 if it == 0 else 1e-3,
+                              rtol=5e-2), (mine, it, algo.last_tabular[mine],
+                                           want)
+        want_pol = cg.policy_params(g, pre + 'pol:')
+        for k, v in pol.state_dict().items():
+            assert np.allclose(v.numpy(), want_pol[k].numpy(),
+                               atol=loose * dscale), k
+        for k, v in vf.state_dict().items():
+            assert np.allclose(v.numpy(), g[pre + 'vf:' + k], atol=2e-6), k
+
+
+@pytest.mark.parametrize('double_softmax', [True, False])
+def test_categorical_fisher_vector_product_matches_double_backward(
+        double_softmax):
+    """``A v`` through the categorical metric against the reference's
+    Hessian-vector product by double backward (oracle) at 5 classes, with and
+    without the head's inner softmax."""
+    from garage_amd.algos import TRPO
+    from garage_amd.engine import pad_rows
+    from garage_amd.policies import (CategoricalMLPPolicy,
+                                     GaussianMLPValueFunction)
+    from oracle import networks as nets
+    from oracle.trpo import build_hessian_vector_product
+    from test_ppo_gpu import _discrete_spec
+    O, n_act, P, M = 11, 5, 16, 700
+    spec = _discrete_spec(O, n_act, P)
+    torch.manual_seed(4)
+    pol = CategoricalMLPPolicy(spec, hidden_sizes=(64, 32),
+                               double_softmax=double_softmax)
+    gen = torch.Generator(device='cpu').manual_seed(6)
+    for name, view in pol.net.named_views():
+        if name != '_init_std':  # away from the zero-bias init
+            view.add_(0.3 * torch.randn(view.shape, generator=gen).to(
+                view.device))
+    vf = GaussianMLPValueFunction(spec, hidden_sizes=(8, ))
+    algo = TRPO(env_spec=spec, policy=pol, value_function=vf, sampler=None)
+    rng = np.random.RandomState(0)
+    obs = rng.randn(M, O).astype(np.float32)
+
+    class B:
+        obs_dev = pad_rows(obs)
+        n_samples = M
+
+    net = pol.net
+    net.forward(B.obs_dev, M)  # activations + scores at the current parameters
+    vec = torch.zeros(net.n_flat, device=net.device)
+    for v in _views_no_std(net, vec):
+        v.copy_(torch.from_numpy(rng.randn(*v.shape).astype(np.float32)))
+    out = torch.empty_like(vec)
+    algo._fisher_vector_product(B, M, vec, out)
+    got = _flat_no_pad_cat(net, out)
+    assert float(out[0]) == 0.0  # the layout's std slot is not a parameter
+    params = OrderedDict((k, v.clone()) for k, v in pol.state_dict().items())
+    old = OrderedDict((k, v.clone()) for k, v in params.items())
+    keys = nets.trainable_keys(params)
+    for k in keys:
+        params[k].requires_grad_(True)
+    x = torch.from_numpy(obs)
+
+    def f_constraint():
+        with torch.no_grad():
+            d_old = nets.categorical_dist(old, nets.POLICY_PREFIX, x,
+                                          double_softmax)
+        d_new = nets.categorical_dist(params, nets.POLICY_PREFIX, x,
+                                      double_softmax)
+        return torch.distributions.kl.kl_divergence(d_old, d_new).mean()
+
+    f_Ax = build_hessian_vector_product(f_constraint,
+                                        [params[k] for k in keys], 1e-5)
+    want = f_Ax(torch.from_numpy(_flat_no_pad_cat(net, vec))).detach().numpy()
+    assert np.allclose(got, want, atol=2e-5 * max(1.0, np.abs(want).max()),
+                       rtol=1e-4)
+
+
 def test_trpo_iteration_matches_oracle_larger_batch():
     """One TRPO iteration on ~3000 samples, 2 hidden layers of 64: post-step
     parameters, logged scalars and the accepted backtracking index against the
