@@ -220,8 +220,10 @@ __device__ __forceinline__ void gemm_mainloop_split(const GemmParams& p, float* 
 
 // bid: the workgroup's linear id within ITS problem (a pair launch carries two)
 // SPLIT: the opt-in split-operand k-loop above (128 x 128 tiles, A_KC, weights as planes)
+// PIPE: interior tiles take the software-pipelined two-stage k-loop
+// (gemm_core.h: gemm_mainloop_pipe) -- for tile shapes with few waves per SIMD
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KC, bool B_KC, int BKT,
-          bool HEAD, bool SPLIT = false>
+          bool HEAD, bool SPLIT = false, bool PIPE = false>
 __device__ __forceinline__ void gemm_f32_body(const GemmParams& p, const int bid) {
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int TM = WM / 32, TN = WN / 32;
@@ -231,8 +233,8 @@ __device__ __forceinline__ void gemm_f32_body(const GemmParams& p, const int bid
   constexpr int B_FLOATS = B_KC ? BN * LDK : BKT * LDB_S;
   // (the epilogue stages 64 output rows in the same memory)
   constexpr int STAGE_FLOATS = (BM % 64 == 0) ? 64 * (BN + 4) : 0;
-  constexpr int TILE_FLOATS =
-      A_FLOATS + B_FLOATS > STAGE_FLOATS ? A_FLOATS + B_FLOATS : STAGE_FLOATS;
+  constexpr int OPERAND_FLOATS = (PIPE ? 2 : 1) * (A_FLOATS + B_FLOATS);
+  constexpr int TILE_FLOATS = OPERAND_FLOATS > STAGE_FLOATS ? OPERAND_FLOATS : STAGE_FLOATS;
   // HEAD: + the waves' partial head sums, [<= 4 planes][64 rows][8]
   constexpr int HEAD_PLANES = WAVES_M * WAVES_N < 4 ? WAVES_M * WAVES_N : 4;
   // (SPLIT: two buffers of three bf16 planes of the 128-row A tile)
@@ -286,7 +288,10 @@ __device__ __forceinline__ void gemm_f32_body(const GemmParams& p, const int bid
   if constexpr (SPLIT) {
     gemm_mainloop_split(p, lds, acc, m0, n0, wm0, wn0);
     __syncthreads();  // (the epilogue stages output rows over the planes)
-  } else if (full)
+  } else if (PIPE && full && !do_colsum)
+    gemm_mainloop_pipe<BM, BN, WAVES_M, WAVES_N, A_KC, B_KC, BKT>(p, lds, acc, m0, n0, kbeg,
+                                                                  kend, wm0, wn0);
+  else if (full)
     gemm_mainloop<BM, BN, WAVES_M, WAVES_N, A_KC, B_KC, BKT, true>(
         p, lds, acc, csum, do_colsum, m0, n0, kbeg, kend, wm0, wn0);
   else
@@ -303,13 +308,19 @@ __device__ __forceinline__ void gemm_f32_body(const GemmParams& p, const int bid
   // row segments instead of two 128-B ones.
   constexpr int NT_ALL = 64 * WAVES_M * WAVES_N;
   constexpr bool TR_OK = BM % 64 == 0 && (64 * (BN / 4)) % NT_ALL == 0;
-  if (TR_OK && full && p.c_cs == 1 && (p.c_rs & 3) == 0 &&
+  // (PIPE: the host has checked the layout conditions -- gemm_pipe_ok -- and N is a
+  // multiple of BN; the last row block may be ragged and guards its rows below.  The
+  // per-element path at the end is not instantiated: its loops stay rolled at 16
+  // accumulator tiles and the accumulators would then live in scratch memory.)
+  if (PIPE || (TR_OK && full && p.c_cs == 1 && (p.c_rs & 3) == 0 &&
       (reinterpret_cast<uintptr_t>(Cout) & 15u) == 0 &&
       (!p.H || ((p.ldh & 3) == 0 && (reinterpret_cast<uintptr_t>(p.H) & 15u) == 0)) &&
-      (!p.bias || (reinterpret_cast<uintptr_t>(p.bias) & 15u) == 0)) {
+      (!p.bias || (reinterpret_cast<uintptr_t>(p.bias) & 15u) == 0))) {
     constexpr int LDC = BN + 4;
     for (int hrow = 0; hrow < BM; hrow += 64) {
-      if (wm0 >= hrow && wm0 < hrow + 64) {
+      // (a wave's rows may span more than one 64-row pass: WM = 128 in the
+      // one-wave-per-SIMD A/B instantiation)
+      if (wm0 < hrow + 64 && wm0 + WM > hrow) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -318,7 +329,8 @@ __device__ __forceinline__ void gemm_f32_body(const GemmParams& p, const int bid
             for (int r = 0; r < 16; ++r) {
               const int rr =
                   wm0 - hrow + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-              if (rr < 64) lds[rr * LDC + wn0 + 32 * j + (lane & 31)] = acc[i][j][r];
+              if (rr >= 0 && rr < 64)
+                lds[rr * LDC + wn0 + 32 * j + (lane & 31)] = acc[i][j][r];
             }
       }
       __syncthreads();
@@ -327,6 +339,7 @@ __device__ __forceinline__ void gemm_f32_body(const GemmParams& p, const int bid
         const int idx = threadIdx.x + NT_ALL * q;
         const int rr = idx / (BN / 4), c4 = idx % (BN / 4);
         const int m = m0 + hrow + rr, n = n0 + 4 * c4;
+        if (PIPE && m >= p.M) continue;
         float4 v = *reinterpret_cast<const float4*>(lds + rr * LDC + 4 * c4);
         float* dst = Cout + (int64_t)m * p.c_rs + n;
         if (p.accum) {
@@ -368,6 +381,7 @@ __device__ __forceinline__ void gemm_f32_body(const GemmParams& p, const int bid
     return;
   }
 #endif
+  if constexpr (!PIPE) {
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -404,6 +418,7 @@ __device__ __forceinline__ void gemm_f32_body(const GemmParams& p, const int bid
     if ((int)threadIdx.x < W && base + (int)threadIdx.x < lim)
       p.colsum[(int64_t)split * p.colsum_split_stride + base + threadIdx.x] = csum;
   }
+  }  // !PIPE
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KC, bool B_KC,
@@ -414,6 +429,12 @@ __attribute__((amdgpu_waves_per_eu(GA_GEMM_WAVES_PER_EU, 8)))
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_f32_kernel(
     GemmParams p) {
   gemm_f32_body<BM, BN, WAVES_M, WAVES_N, A_KC, B_KC, BKT, HEAD>(p, (int)blockIdx.x);
+}
+
+// 256 x 256 tiles, 4 waves of 128 x 128: one wave per SIMD, pipelined k-loop
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_f32_pipe_kernel(GemmParams p) {
+  gemm_f32_body<256, 256, 2, 2, A_KC, B_KC, BK, false, false, true>(p, (int)blockIdx.x);
 }
 
 __global__ __launch_bounds__(512, 4) void gemm_kc_split_kernel(GemmParams p) {
@@ -650,6 +671,26 @@ int launch_gemm(const GemmParams& p_in, int splits, hipStream_t stream) {
     ga_prof_events(GA_PROF_GEMM_NT_128 + mode, flops, &e0, &e1);
     // 8 waves (64x32 each): two workgroups per CU put 4 waves on every SIMD, so
     // the matrix pipe has work while other waves sit at the barrier / vmcnt
+#ifdef GA_GEMM_BIG_TILE  // A/B builds: 4-wave workgroups with 128-row wave tiles
+    // 1: 256 x 256 tiles, waves of 128 x 128 (one per SIMD); 2: 256 x 128, waves of 128 x 64
+    if (splits == 1 && p.M >= 4096 && p.N % 256 == 0) {
+      constexpr int TBN = GA_GEMM_BIG_TILE == 2 ? 128 : 256;
+      p.gx = (int)ga_ceil_div(p.M, 256); p.gy = p.N / TBN; p.gz = 1;
+      dim3 g2((unsigned)(p.gx * p.gy));
+      const bool pipe_ok = !p.colsum && p.c_cs == 1 && (p.c_rs & 3) == 0 && ga_aligned16(p.C) &&
+                           (!p.H || ((p.ldh & 3) == 0 && ga_aligned16(p.H))) &&
+                           (!p.bias || ga_aligned16(p.bias)) && !p.accum &&
+                           p.K % BK == 0 && !p.a_idx && !p.b_idx;
+      if (GA_GEMM_BIG_TILE == 3 && pipe_ok)
+        hipExtLaunchKernelGGL((gemm_f32_pipe_kernel<A_KC, B_KC>), g2, dim3(256), 0, stream,
+                              e0, e1, 0, p);
+      else
+        hipExtLaunchKernelGGL((gemm_f32_kernel<256, TBN, 2, 2, A_KC, B_KC>), g2, dim3(256),
+                              0, stream, e0, e1, 0, p);
+      GA_CHECK_LAUNCH("gemm_f32 (256-row tiles)");
+      return GA_OK;
+    }
+#endif
 #ifdef GA_GEMM_BIG_BKT  // A/B builds (tools/build_variants.sh): k-tile depth of this shape
     hipExtLaunchKernelGGL((gemm_f32_kernel<128, 128, 2, 4, A_KC, B_KC, GA_GEMM_BIG_BKT>),
                           grid, dim3(512), 0, stream, e0, e1, 0, p);

@@ -423,4 +423,153 @@ __device__ __forceinline__ void gemm_mainloop(const GemmParams& p, float* lds,
   }
 }
 
+// LDS-only workgroup barrier: waits for this wave's LDS traffic (lgkmcnt) but not for
+// global loads in flight (__syncthreads() also waits vmcnt(0): the prefetch of the tile
+// after next would have to land first).
+__device__ __forceinline__ void ga_lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// The k-loop for FEW waves per SIMD (256 x 256 tiles: 4 waves of 128 x 128, 256
+// accumulator registers each, ONE wave per SIMD -- the shape the vendor library picks for
+// the 65536 x 512 x 512 products of C5, profiles/r03_notes.md).  gemm_mainloop above relies
+// on 4 waves per SIMD to hide its global -> LDS -> fragment latencies; with one wave the
+// loop has to be software pipelined itself:
+//   * two LDS stages, ONE barrier per k-step; tile s + 1 sits in registers while tile s
+//     is multiplied and is written to the other stage behind the MFMAs of group G - 2,
+//     after which the loads of tile s + 2 are issued (a whole k-step to land);
+//   * the fragments of group g + 1 are read while group g's MFMAs run (two register
+//     sets); the barrier sits in front of the LAST group, and the first fragments of the
+//     next tile are read right behind it, under that group's MFMAs.
+// Interior tiles only (FULL loaders; the last k-step may be partial).  Same k order per
+// accumulator as gemm_mainloop: bit-identical results.
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KC, bool B_KC, int BKT, int TM,
+          int TN>
+__device__ __forceinline__ void gemm_mainloop_pipe(const GemmParams& p, float* lds,
+                                                   f32x16 (&acc)[TM][TN], int m0, int n0,
+                                                   int kbeg, int kend, int wm0, int wn0) {
+  constexpr int NT = 64 * WAVES_M * WAVES_N;
+  constexpr int LDA_S = BM + PAD, LDB_S = BN + PAD, LDK = BKT + PAD;
+  constexpr int A_FLOATS = A_KC ? BM * LDK : BKT * LDA_S;
+  constexpr int B_FLOATS = B_KC ? BN * LDK : BKT * LDB_S;
+  constexpr int STAGE = A_FLOATS + B_FLOATS;
+  constexpr int G = BKT / 8;
+  static_assert(G >= 2 && G % 2 == 0, "the fragment sets alternate per group");
+  const int lane = threadIdx.x & 63;
+  const int half = lane >> 5, l31 = lane & 31;
+  TileLoader<BM, A_KC, NT, BKT, true> la;
+  TileLoader<BN, B_KC, NT, BKT, true> lb;
+  const int a_span = A_KC ? p.K : p.M;
+  const int b_span = B_KC ? p.K : p.N;
+  const int nk = (kend - kbeg + BKT - 1) / BKT;
+  if (nk <= 0) {
+    __syncthreads();
+    return;
+  }
+  la.init(p.a_idx, m0, p.M, kbeg, kend);
+  lb.init(p.b_idx, n0, p.N, kbeg, kend);
+  la.init_linear(p.A, p.lda, p.a_idx, m0, kbeg);
+  lb.init_linear(p.B, p.ldb, p.b_idx, n0, kbeg);
+  la.load(p.A, p.lda, m0, kbeg, a_span, nk == 1, kbeg);
+  lb.load(p.B, p.ldb, n0, kbeg, b_span, nk == 1, kbeg);
+  la.prefetch_lines(p.a_idx, kbeg + BKT, kend);
+  lb.prefetch_lines(p.b_idx, kbeg + BKT, kend);
+  la.store(lds, m0, p.M, kbeg, kend, nk == 1);
+  lb.store(lds + A_FLOATS, n0, p.N, kbeg, kend, nk == 1);
+  if (nk > 1) {
+    la.rotate();
+    lb.rotate();
+    la.load(p.A, p.lda, m0, kbeg + BKT, a_span, nk == 2, kbeg);
+    lb.load(p.B, p.ldb, n0, kbeg + BKT, b_span, nk == 2, kbeg);
+    la.prefetch_lines(p.a_idx, kbeg + 2 * BKT, kend);
+    lb.prefetch_lines(p.b_idx, kbeg + 2 * BKT, kend);
+  }
+  __syncthreads();
+
+  float fa[2][TM][4], fb[2][TN][4];
+  auto read_frags = [&](const float* As, const float* Bs, float (&a)[TM][4],
+                        float (&b)[TN][4], int g) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      if (A_KC) {
+        const float4 v = *reinterpret_cast<const float4*>(
+            As + (wm0 + 32 * i + l31) * LDK + 8 * g + 4 * half);
+        a[i][0] = v.x; a[i][1] = v.y; a[i][2] = v.z; a[i][3] = v.w;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          a[i][q] = As[(8 * g + 4 * half + q) * LDA_S + wm0 + 32 * i + l31];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      if (B_KC) {
+        const float4 v = *reinterpret_cast<const float4*>(
+            Bs + (wn0 + 32 * j + l31) * LDK + 8 * g + 4 * half);
+        b[j][0] = v.x; b[j][1] = v.y; b[j][2] = v.z; b[j][3] = v.w;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          b[j][q] = Bs[(8 * g + 4 * half + q) * LDB_S + wn0 + 32 * j + l31];
+      }
+    }
+  };
+  auto issue = [&](const float (&a)[TM][4], const float (&b)[TN][4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[j][q], acc[i][j], 0,
+                                                           0, 0);
+  };
+  read_frags(lds, lds + A_FLOATS, fa[0], fb[0], 0);
+
+  // The loop body is ONE basic block (no tail masks: the caller guarantees whole k-steps;
+  // the last step re-loads its own tile and stores it where nobody reads it), so that the
+  // machine scheduler can be told how to interleave: a wave issues in order, and what is
+  // to run beside the MFMAs has to sit BETWEEN them in the instruction stream.
+  for (int s = 0; s < nk; ++s) {
+    const float* As = lds + (s & 1) * STAGE;
+    const float* Bs = As + A_FLOATS;
+    float* An = lds + ((s + 1) & 1) * STAGE;
+    float* Bn = An + A_FLOATS;
+    const int k1 = kbeg + min(s + 1, nk - 1) * BKT;  // tile in the registers
+    const int k2 = kbeg + min(s + 2, nk - 1) * BKT;  // tile to fetch
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      if (g + 1 < G) {
+        read_frags(As, Bs, fa[(g + 1) & 1], fb[(g + 1) & 1], g + 1);
+      } else {
+        ga_lds_barrier();
+        read_frags(An, Bn, fa[0], fb[0], 0);
+      }
+      if (g == G - 2) {
+        la.store(An, m0, p.M, k1, kend, false);
+        lb.store(Bn, n0, p.N, k1, kend, false);
+        la.rotate();
+        lb.rotate();
+        la.load(p.A, p.lda, m0, k2, a_span, false, kbeg);
+        lb.load(p.B, p.ldb, n0, k2, b_span, false, kbeg);
+        la.prefetch_lines(p.a_idx, k2 + BKT, kend);
+        lb.prefetch_lines(p.b_idx, k2 + BKT, kend);
+      }
+      issue(fa[g & 1], fb[g & 1]);
+      if (g == G - 2) {
+        // 4 MFMAs, then one LDS store and one global load, 16 times
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+      }
+    }
+  }
+  __syncthreads();  // (the epilogue stages output rows over the operand stages)
+}
+
 }  // namespace
